@@ -1,0 +1,245 @@
+/*
+ * xde_hip.h — C ABI of libxde_hip.so, the MI355X (gfx950) kernels behind
+ * paddlexde_amd.functional.odeint / odeint_adjoint.
+ *
+ * The reference (DrownFish19/PaddleXDE) has no FFI: its hot path is eager Paddle ops in
+ * Python.  Each entry point below replaces a group of those ops; the reference lines it
+ * replaces are cited per function (paths relative to the reference root).
+ *
+ * Conventions
+ *  - every function returns an int status: XDE_OK, XDE_EBADARG, XDE_EHIP
+ *    (message of the last failure on the calling thread: xde_last_error());
+ *  - data pointers are DEVICE pointers borrowed from the caller (torch tensors'
+ *    data_ptr()); nothing is allocated, freed or retained by the library;
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is
+ *    enqueued asynchronously on it, the only blocking call is xde_ctrl_read();
+ *  - state arrays hold `n` elements of `dtype` (XDE_F32 / XDE_F64), contiguous; 16-byte
+ *    aligned pointers take the vector path, others a scalar path (same results);
+ *  - a state may be a concatenation of up to XDE_MAX_SEG segments (tuple state of the
+ *    adjoint pass); norms are taken per segment and combined with max, which is the
+ *    reference's `_mixed_norm` / default adjoint norm (functional/odeint_adjoint.py:284-287);
+ *  - `xde_ctrl_t` is the device-resident solver state (the reference's `_RungeKuttaState`
+ *    scalars, solver/base_adaptive_solver_rk.py:22-24): kernels read dt / select flags from
+ *    it, so the host never has to know the step size to enqueue the next step.
+ *  - thread-safe for distinct streams + workspaces.
+ */
+#ifndef XDE_HIP_H
+#define XDE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XDE_ABI_VERSION 1
+
+#define XDE_OK 0
+#define XDE_EBADARG 1
+#define XDE_EHIP 2
+
+#define XDE_F32 0
+#define XDE_F64 1
+
+#define XDE_MAX_K 14   /* operands of one combine: Dopri8 has 13 stages + f0 */
+#define XDE_MAX_SEG 16 /* segments of a tuple state */
+#define XDE_MAX_STAGE 13
+#define XDE_MAX_PARTIALS 4096 /* upper bound on blocks of a norm launch */
+
+/* combine modes (xde_stage_combine) */
+#define XDE_COMBINE_RK 0    /* out = y0 + sum_j k_j * (coef_j * dt)            base_adaptive_solver_rk.py:166-168 */
+#define XDE_COMBINE_FUSE 1  /* out = (sum_j coef_j * k_j) * dt + y0            xde/base_ode.py:58 (fuse) */
+#define XDE_COMBINE_WFUSE 2 /* out = (sum_j coef_j * (k_j * dt + y0)) * scale  base_fixed_solver.py:192-197 */
+
+/* norm kinds */
+#define XDE_NORM_RMS 0  /* utils/ode_utils.py:8-9  */
+#define XDE_NORM_LINF 1 /* utils/ode_utils.py:4-5  */
+
+/* solver status (xde_ctrl_t.status) -> the reference's AssertionError messages */
+#define XDE_STATUS_OK 0
+#define XDE_STATUS_DT_UNDERFLOW 1 /* "underflow in dt {}"                base_adaptive_solver_rk.py:200 */
+#define XDE_STATUS_NONFINITE 2    /* "non-finite values in state `y`"    base_adaptive_solver_rk.py:201-203 */
+#define XDE_STATUS_MAX_STEPS 3    /* "max_num_steps exceeded ({}>={})"   base_adaptive_solver_rk.py:120-122 */
+
+/*
+ * Device-resident solver state.  Time-like values are stored as double; when the solver's
+ * time dtype is float32 (the reference default, base_adaptive_solver_rk.py:47) every value
+ * is float-representable and all controller arithmetic is done in float.
+ */
+typedef struct xde_ctrl {
+  double t0;       /* rk_state.t0: start of the last attempted step */
+  double t1;       /* rk_state.t1: current time */
+  double dt;       /* signed step the next attempt will use (after step_t clipping) */
+  double dt_last;  /* signed step used by the last attempt */
+  double t_plan;   /* planned end time of the pending attempt (t1 + dt, or the clipped step_t point) */
+  double ratio_prev; /* error ratio of the last ACCEPTED step (opt-in PI controller only) */
+  double ratio;    /* error ratio of the last attempt */
+  double ratio_seg[XDE_MAX_SEG]; /* per-segment norm of the last attempt */
+  double nonfinite; /* count of non-finite elements of y0 seen by the last error-norm */
+  int64_t n_steps;  /* attempted steps since xde_ctrl_init */
+  int64_t n_accept;
+  int64_t n_reject;
+  int64_t steps_in_interval; /* attempts since the last emitted output (max_num_steps is per interval) */
+  int32_t accept;    /* last attempt accepted; kernels of the NEXT step use it as operand select */
+  int32_t sel_used;  /* operand select the last attempt ran with */
+  int32_t status;    /* XDE_STATUS_* (sticky) */
+  int32_t out_begin; /* rows [out_begin, out_end) of the solution are covered by the last accepted step */
+  int32_t out_end;
+  int32_t next_out;  /* next output row not yet produced */
+  int32_t n_out;     /* number of output rows (len(t_span)) */
+  int32_t done;      /* next_out == n_out */
+  int32_t next_step_index; /* index into step_t (base_adaptive_solver_rk.py:109-111) */
+  int32_t on_step_t; /* the pending dt was clipped to step_t[next_step_index] */
+  int32_t reserved[6];
+} xde_ctrl_t;
+
+/* Controller parameters (host struct, passed by pointer, copied at call time). */
+typedef struct xde_ctrl_params {
+  double rtol, atol;         /* already rounded to the time dtype by the caller */
+  double min_step, max_step; /* base_adaptive_solver_rk.py:36-37 */
+  double safety, ifactor, dfactor; /* :41-43 */
+  double order;              /* solver order (exponent = 1/order), ode_utils.py:92 */
+  int64_t max_num_steps;     /* :44 */
+  int32_t time_dtype;        /* XDE_F32 / XDE_F64: dtype of time-like scalars, :47 */
+  int32_t state_dtype;       /* dtype the ratio / stage times are rounded to */
+  int32_t direction;         /* +1 forward, -1 reverse time (D5: native signed dt instead of the t->-t flip) */
+  int32_t norm_kind;         /* XDE_NORM_* */
+  int32_t n_stage;           /* len(tableau.alpha) */
+  int32_t n_seg;             /* segments that take part in the norm */
+  int32_t n_step_t;          /* len(step_t) or 0 */
+  int32_t pi_controller;     /* 0 = reference integral controller; 1 = opt-in PI (never used for parity) */
+  double pi_beta;            /* PI only */
+  double alpha[XDE_MAX_STAGE]; /* tableau.alpha in double */
+  double seg_count[XDE_MAX_SEG]; /* GLOBAL element count of each segment (all ranks) */
+} xde_ctrl_params_t;
+
+/* Description of one state operand list + segment layout, shared by the norm kernels. */
+typedef struct xde_segments {
+  int32_t n_seg;
+  int64_t seg_start[XDE_MAX_SEG]; /* element offset of each segment in the flat state */
+  int64_t seg_len[XDE_MAX_SEG];   /* LOCAL element count of each segment */
+} xde_segments_t;
+
+const char* xde_last_error(void);
+int xde_abi_version(void);
+int64_t xde_sizeof_ctrl(void);
+/* bytes of scratch a norm launch needs (block partials + finalised per-segment sums) */
+int64_t xde_workspace_bytes(void);
+
+/*
+ * Stage combine — replaces `yi = y0 + sum(k[..., :i+1] * (beta_i * dt), -1)` of
+ * AdaptiveRKSolver._runge_kutta_step (solver/base_adaptive_solver_rk.py:166-168), BaseODE.fuse
+ * (xde/base_ode.py:58) and the stage/final formulas of rk4_alt_step_func / rk4_step_func /
+ * Euler.step / Midpoint.step (solver/base_fixed_solver.py:146-197, fixed_solver/{rk4,euler,midpoint}.py).
+ *   out, y0, k[j]: n elements.  coef: nk doubles (rounded to dtype inside, as the reference casts
+ *   its tableau, base_adaptive_solver_rk.py:73-79).  dt: read from ctrl->dt when ctrl != NULL,
+ *   else dt_host.  If y0_alt/k0_alt != NULL and ctrl != NULL the kernel uses (y0_alt, k0_alt) in
+ *   place of (y0, k[0]) when ctrl->accept != 0 (speculative enqueue: the host does not yet know
+ *   whether the previous step was accepted).
+ */
+int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k,
+                      const void* k0_alt, const double* coef, int nk, int mode, double scale,
+                      double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, void* stream);
+
+/*
+ * Error-norm partials — replaces `y1_error = sum(k * (dt * c_error), -1)` (base_adaptive_solver_rk.py:180),
+ * compute_error_ratio's element-wise chain and the reduction inside the norm (utils/ode_utils.py:80-82,
+ * :4-9), and the `isfinite(y0).all()` pass (base_adaptive_solver_rk.py:201).
+ * Writes per-block partial sums of (err/tol)^2 (or max |err/tol| for LINF) and the count of
+ * non-finite y0 elements to `ws`; xde_norm_finalize / xde_rk_control reduce them in a fixed order.
+ */
+int xde_error_norm_partial(const void* const* k, const void* k0_alt, const double* c_err, int nk,
+                           const void* y0, const void* y0_alt, const void* y1, double rtol,
+                           double atol, double dt_host, const xde_ctrl_t* ctrl,
+                           const xde_segments_t* segs, int norm_kind, int dtype, void* ws,
+                           void* stream);
+
+/*
+ * Scaled norms for the initial-step heuristic — replaces `scale = atol + abs(y0) * rtol`,
+ * `norm(a / scale)` of AdaptiveSolver.select_initial_step (solver/base_adaptive_solver.py:50-53,64).
+ *   b == NULL: partials of norm(a / scale);  b != NULL: partials of norm((a - b) / scale).
+ * Two independent results can be produced by calling it twice with slot 0 and 1.
+ */
+int xde_scaled_norm_partial(const void* a, const void* b, const void* y0, double rtol, double atol,
+                            const xde_segments_t* segs, int norm_kind, int dtype, void* ws, int slot,
+                            void* stream);
+
+/*
+ * Reduce block partials of slot `slot` to per-segment sums: sums_out[2*XDE_MAX_SEG] doubles laid
+ * out as [value(seg 0..), nonfinite(seg 0..)] on the device.  In a multi-GPU run the caller
+ * all-reduces sums_out (SUM for RMS/nonfinite, MAX for LINF) before xde_rk_control /
+ * xde_norm_result.  Replaces the tail of `_rms_norm` / `_linf_norm` (utils/ode_utils.py:4-9).
+ */
+int xde_norm_finalize(const void* ws, int slot, double* sums_out, void* stream);
+
+/*
+ * Turn finalised sums into the scalar norm max_seg f(sum_seg, count_seg) (sqrt(mean) or max) and
+ * write it, rounded to `state_dtype`, to result_out[0] (device double).  Used by the initial-step
+ * heuristic (the host reads three such scalars once per integrate()).
+ */
+int xde_norm_result(const double* sums, const double* seg_count, int n_seg, int norm_kind,
+                    int state_dtype, double* result_out, void* stream);
+
+/*
+ * Step controller — replaces the accept/reject logic and state update of
+ * AdaptiveRKSolver._adaptive_step (solver/base_adaptive_solver_rk.py:200-203,209-215,244-283),
+ * optimal_step_size (utils/ode_utils.py:85-97), the stage-time computation of _runge_kutta_step
+ * (:159-164) for the NEXT step, the `while next_t > t1` bookkeeping of step() (:116-127) and the
+ * max_num_steps assertion.  One thread.
+ *   sums: finalised (and, multi-GPU, all-reduced) sums from xde_norm_finalize, or NULL to reduce the
+ *         partials in `ws` slot 0 inside this launch (single-GPU fast path);
+ *   t_span_dev: n_out doubles (time dtype values) on the device;  step_t_dev: n_step_t doubles or NULL;
+ *   t_stage_out: n_stage values of `state_dtype` on the device — times func() is called with in the
+ *                next step.
+ */
+int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void* ws,
+                   const double* sums, const double* t_span_dev, const double* step_t_dev,
+                   void* t_stage_out, void* stream);
+
+/*
+ * Initialise the device control block before the first step (replaces the construction of
+ * `_RungeKuttaState(y0, f0, t[0], t[0], first_step, ...)`, base_adaptive_solver_rk.py:89-92, and the
+ * step_t bookkeeping :95-111).  Also writes the first step's stage times.
+ */
+int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_start,
+                  double first_step, int32_t n_out, const double* t_span_dev,
+                  const double* step_t_dev, void* t_stage_out, void* stream);
+
+/* Blocking device->host copy of the control block (the one sync point of a step). */
+int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream);
+
+/*
+ * Dense output — replaces _interp_fit + interp_fit + interp_evaluate
+ * (solver/base_adaptive_solver_rk.py:286-292; utils/ode_utils.py:28-49,52-77) for the output rows the
+ * last accepted step covers (ctrl->out_begin..out_end); predicated on ctrl->accept.  The quartic's
+ * coefficients are never materialised.  out_base is the [n_out, n] solution buffer.
+ *   k/mid: operands with non-zero mid-point weight;  f0 = k[0] by construction (k0 candidates),
+ *   f1: derivative at t1 (last stage);  y0 candidates selected by ctrl->sel_used.
+ *   expect_step: if >= 0 the kernel runs only when ctrl->n_steps == expect_step, i.e. when the
+ *   controller launch of this attempt really executed (a speculative attempt enqueued after the last
+ *   output is skipped by the controller's `done` guard and must not re-emit rows).
+ */
+int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, const double* mid,
+                   int nk, const void* y0, const void* y0_alt, const void* y1, const void* f1,
+                   const xde_ctrl_t* ctrl, const double* t_span_dev, int time_dtype, int64_t n,
+                   int dtype, int64_t expect_step, void* stream);
+
+/*
+ * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
+ * roofline figure).  When enabled every launch above is bracketed by an event pair;
+ * xde_prof_collect() synchronises and returns, per kernel id, launch count and summed milliseconds.
+ */
+#define XDE_KID_COMBINE 0
+#define XDE_KID_ERRNORM 1
+#define XDE_KID_CONTROL 2
+#define XDE_KID_DENSE 3
+#define XDE_KID_SCALEDNORM 4
+#define XDE_KID_FINALIZE 5
+#define XDE_KID_COUNT 6
+int xde_prof_enable(int on);
+int xde_prof_collect(int64_t* counts_out, double* ms_out, double* bytes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XDE_HIP_H */

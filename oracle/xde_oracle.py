@@ -1,0 +1,698 @@
+"""CPU oracle: a numpy restatement of PaddleXDE's odeint / odeint_adjoint hot path.
+
+THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The product (``paddlexde_amd``) never imports, calls or falls back to anything here.
+
+What it is
+----------
+An op-for-op restatement, on numpy arrays, of the algorithm in the reference
+(``/root/reference/paddlexde``; citations below are relative to that directory).  The
+reference is pure Python on PaddlePaddle; Paddle is not installed in the build
+container (ordinary ``ModuleNotFoundError``) so the reference cannot be executed.
+The arithmetic is restated with numpy in the dtype the reference would use
+(state dtype for state-like tensors, ``dtype=float32`` for time-like scalars unless
+``options["dtype"]`` says otherwise) and in the reference's op order, including the
+stage-innermost ``k[..., S+1]`` buffer and ``sum(axis=-1)`` stage combines.
+
+How it is pinned
+---------------------------------------
+The reference stores no golden vectors; its tests pin three analytic problems
+(``tests/testing_utils.py:8-70``) at ``rtol=1e-2`` (fixed) / ``4e-3`` (adaptive).
+``tests/test_oracle_pinning.py`` checks this oracle on those problems at the
+reference's tolerances and at tight tolerances, against scipy's independent
+Dormand-Prince implementation, by convergence order and by tableau invariants.
+Step-level and gradient-level behaviour is *not* pinned by the reference itself.
+
+Documented resolutions of reference defects
+-------------------------------------------------------------
+D1  ``xde.format`` is undefined -> identity.
+D2  ``RK4`` uses ``rk4_alt_step_func`` with stage-3 input ``k1 - k2/3`` -> reproduced.
+D3  fixed solvers concat on axis -2, adaptive solvers stack on axis 0 -> reproduced.
+D4  tuple state: flatten -> integrate -> unflatten (torchdiffeq intent).
+D5  adaptive reverse time: ``t -> -t, f -> -f`` flip (torchdiffeq intent).
+D6  backward additionally returns the gradient w.r.t. ``y0`` (superset).
+D7  ``jump_t``, ``step_size``/``grid_constructor`` sub-stepping -> NotImplementedError.
+D9  plain integral controller (``ode_utils.py:85-97``), not PI.
+"""
+from __future__ import annotations
+
+import bisect
+import collections
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# norms                                                    (paddlexde/utils/ode_utils.py)
+# --------------------------------------------------------------------------------------
+
+
+def _linf_norm(x):
+    """ode_utils.py:4-5"""
+    return np.abs(x).max()
+
+
+def _rms_norm(x):
+    """ode_utils.py:8-9  ``tensor.abs().pow(2).mean().sqrt()``"""
+    x = np.asarray(x)
+    return np.sqrt(np.mean(np.abs(x) ** 2, dtype=x.dtype))
+
+
+def _mixed_norm(tensor_tuple):
+    """ode_utils.py:16-19"""
+    if len(tensor_tuple) == 0:
+        return 0.0
+    return max([_rms_norm(t) for t in tensor_tuple])
+
+
+# --------------------------------------------------------------------------------------
+# tableaus                       (paddlexde/solver/adaptive_solver/{dopri5,bosh3,...}.py)
+# --------------------------------------------------------------------------------------
+
+ButcherTableau = collections.namedtuple("ButcherTableau", "alpha beta c_sol c_error")
+
+
+def _f64(xs):
+    return np.asarray(xs, dtype=np.float64)
+
+
+# dopri5.py:5-42
+DOPRI5_TABLEAU = ButcherTableau(
+    alpha=_f64([1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]),
+    beta=[
+        _f64([1 / 5]),
+        _f64([3 / 40, 9 / 40]),
+        _f64([44 / 45, -56 / 15, 32 / 9]),
+        _f64([19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729]),
+        _f64([9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656]),
+        _f64([35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]),
+    ],
+    c_sol=_f64([35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0]),
+    c_error=_f64(
+        [
+            35 / 384 - 1951 / 21600,
+            0,
+            500 / 1113 - 22642 / 50085,
+            125 / 192 - 451 / 720,
+            -2187 / 6784 - -12231 / 42400,
+            11 / 84 - 649 / 6300,
+            -1.0 / 60.0,
+        ]
+    ),
+)
+# dopri5.py:44-55
+DOPRI5_MID = _f64(
+    [
+        6025192743 / 30085553152 / 2,
+        0,
+        51252292925 / 65400821598 / 2,
+        -2691868925 / 45128329728 / 2,
+        187940372067 / 1594534317056 / 2,
+        -1776094331 / 19743644256 / 2,
+        11237099 / 235043384 / 2,
+    ]
+)
+
+# bosh3.py:5-18
+BOSH3_TABLEAU = ButcherTableau(
+    alpha=_f64([1 / 2, 3 / 4, 1.0]),
+    beta=[_f64([1 / 2]), _f64([0.0, 3 / 4]), _f64([2 / 9, 1 / 3, 4 / 9])],
+    c_sol=_f64([2 / 9, 1 / 3, 4 / 9, 0.0]),
+    c_error=_f64([2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8]),
+)
+BOSH3_MID = _f64([0.0, 0.5, 0.0, 0.0])
+
+# fehlberg2.py:5-15
+FEHLBERG2_TABLEAU = ButcherTableau(
+    alpha=_f64([1 / 2, 1.0]),
+    beta=[_f64([1 / 2]), _f64([1 / 256, 255 / 256])],
+    c_sol=_f64([1 / 512, 255 / 256, 1 / 512]),
+    c_error=_f64([-1 / 512, 0, 1 / 512]),
+)
+FEHLBERG2_MID = _f64([0.0, 0.5, 0.0])
+
+# adaptive_heun.py:5-21
+ADAPTIVE_HEUN_TABLEAU = ButcherTableau(
+    alpha=_f64([1.0]),
+    beta=[_f64([1.0])],
+    c_sol=_f64([0.5, 0.5]),
+    c_error=_f64([0.5, -0.5]),
+)
+ADAPTIVE_HEUN_MID = _f64([0.5, 0.0])
+
+ADAPTIVE = {
+    # name: (order, tableau, mid)                       class attrs in each solver file
+    "dopri5": (5, DOPRI5_TABLEAU, DOPRI5_MID),  # dopri5.py:58-61
+    "bosh3": (3, BOSH3_TABLEAU, BOSH3_MID),  # bosh3.py:21-24
+    "fehlberg2": (2, FEHLBERG2_TABLEAU, FEHLBERG2_MID),  # fehlberg2.py:18-21
+    "adaptive_heun": (2, ADAPTIVE_HEUN_TABLEAU, ADAPTIVE_HEUN_MID),  # adaptive_heun.py:23-26
+}
+FIXED = ("euler", "midpoint", "rk4", "rk4_classic")
+
+
+# --------------------------------------------------------------------------------------
+# step-size control and dense output                       (paddlexde/utils/ode_utils.py)
+# --------------------------------------------------------------------------------------
+
+
+def interp_fit(y0, y1, y_mid, f0, f1, dt):
+    """ode_utils.py:28-49.  Returns ``[e, d, c, b, a]``."""
+    a = 2 * dt * (f1 - f0) - 8 * (y1 + y0) + 16 * y_mid
+    b = dt * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * y_mid
+    c = dt * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * y_mid
+    d = dt * f0
+    e = y0
+    return [e, d, c, b, a]
+
+
+def interp_evaluate(coefficients, t0, t1, t):
+    """ode_utils.py:52-77"""
+    assert (t0 <= t) & (t <= t1), "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(t0, t, t1)
+    x = (t - t0) / (t1 - t0)
+    x = coefficients[0].dtype.type(x)
+    total = coefficients[0] + x * coefficients[1]
+    x_power = x
+    for coefficient in coefficients[2:]:
+        x_power = x_power * x
+        total = total + x_power * coefficient
+    return total
+
+
+def compute_error_ratio(error_estimate, rtol, atol, y0, y1, norm):
+    """ode_utils.py:80-82"""
+    error_tol = atol + rtol * np.fmax(np.abs(y0), np.abs(y1))
+    return np.abs(norm(error_estimate / error_tol))
+
+
+def optimal_step_size(last_step, error_ratio, safety, ifactor, dfactor, order):
+    """ode_utils.py:85-97 — plain integral controller (D9)."""
+    tt = type(last_step)
+    if error_ratio == 0:
+        return last_step * ifactor
+    if error_ratio < 1:
+        dfactor = tt(1)
+    error_ratio = tt(error_ratio)
+    exponent = tt(1) / tt(order)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        factor = np.fmin(ifactor, np.fmax(safety / error_ratio**exponent, dfactor))
+    return last_step * factor
+
+
+# --------------------------------------------------------------------------------------
+# fixed-grid solvers                        (paddlexde/solver/base_fixed_solver.py etc.)
+# --------------------------------------------------------------------------------------
+
+_one_third = 1 / 3
+_two_thirds = 2 / 3
+_one_sixth = 1 / 6
+
+
+def linear_interp(t0, t1, y0, y1, t):
+    """interpolation/functional/interp_fn.py:4-10"""
+    if np.array_equal(t, t0):
+        return y0
+    if np.array_equal(t, t1):
+        return y1
+    slope = (t - t0) / (t1 - t0)
+    return y0 + slope * (y1 - y0)
+
+
+def cubic_hermite_interp(t0, y0, dy0, t1, y1, dy1, t):
+    """interpolation/functional/interp_fn.py:13-20"""
+    h = (t - t0) / (t1 - t0)
+    h00 = (1 + 2 * h) * (1 - h) * (1 - h)
+    h10 = h * (1 - h) * (1 - h)
+    h01 = h * h * (3 - 2 * h)
+    h11 = h * h * (h - 1)
+    dt = t1 - t0
+    return h00 * y0 + h10 * dt * dy0 + h01 * y1 + h11 * dt * dy1
+
+
+class FixedSolver:
+    """base_fixed_solver.py:14-197 with the default grid (``grid_constructor = lambda y0, t: t``)."""
+
+    def __init__(self, func, y0, method="rk4", step_size=None, grid_constructor=None, interp="linear", perturb=False, **kwargs):
+        self.func = func
+        self.y0 = y0
+        self.method = method
+        self.interp = interp
+        # base_fixed_solver.py:45-47 — KeyError when absent, as in the reference
+        self.atol = kwargs["atol"]
+        self.rtol = kwargs["rtol"]
+        self.norm = kwargs["norm"]
+        if step_size is not None or grid_constructor is not None:
+            raise NotImplementedError("step_size / grid_constructor sub-stepping is broken in the reference (D7)")
+        self.nfe = 0
+
+    # BaseODE.move / fuse                                         xde/base_ode.py:47-58
+    def move(self, t0, dt, y0):
+        self.nfe += 1
+        return np.asarray(self.func(t0, y0))
+
+    @staticmethod
+    def fuse(dy, dt, y0):
+        return dy * dt + y0
+
+    def step(self, t0, t1, y0):
+        if self.method == "euler":  # fixed_solver/euler.py:7-11
+            dt = t1 - t0
+            dy = self.move(t0, dt, y0)
+            return self.fuse(dy, dt, y0), dy
+        if self.method == "midpoint":  # fixed_solver/midpoint.py:7-18
+            dt = t1 - t0
+            half_dt = 0.5 * dt
+            dy_half = self.move(t0, half_dt, y0)
+            y_half = self.fuse(dy_half, half_dt, y0)
+            t_half = t0 + half_dt
+            dy = self.move(t_half, dt, y_half)
+            return self.fuse(dy, dt, y0), dy
+        if self.method == "rk4":  # fixed_solver/rk4.py:7-10  (alt variant, D2)
+            f0 = self.move(t0, t1 - t0, y0)
+            return self.rk4_alt_step_func(t0, t1, y0, f0=f0), f0
+        if self.method == "rk4_classic":  # base_fixed_solver.py:146-164 (unused by the reference's RK4)
+            f0 = self.move(t0, t1 - t0, y0)
+            return self.rk4_step_func(t0, t1, y0, f0=f0), f0
+        raise ValueError(self.method)
+
+    def rk4_step_func(self, t0, t1, y0, f0=None):
+        """base_fixed_solver.py:146-164"""
+        dt = t1 - t0
+        half_dt = dt * 0.5
+        t_half = t0 + half_dt
+        k1 = f0
+        k2 = self.move(t_half, half_dt, self.fuse(k1, half_dt, y0))
+        k3 = self.move(t_half, half_dt, self.fuse(k2, half_dt, y0))
+        k4 = self.move(t1, half_dt, self.fuse(k3, dt, y0))
+        return (self.fuse(k1, dt, y0) + 2 * self.fuse(k2, dt, y0) + 2 * self.fuse(k3, dt, y0) + self.fuse(k4, dt, y0)) * y0.dtype.type(_one_sixth)
+
+    def rk4_alt_step_func(self, t0, t1, y0, f0=None):
+        """base_fixed_solver.py:166-197"""
+        dt = t1 - t0
+        dt_one_third = dt * _one_third
+        dt_two_thirds = dt * _two_thirds
+        t_one_third = t0 + dt_one_third
+        t_two_thirds = t0 + dt_two_thirds
+        k1 = f0
+        k2 = self.move(t_one_third, dt_one_third, self.fuse(k1, dt_one_third, y0))
+        k3 = self.move(t_two_thirds, dt_one_third, self.fuse(k1 - k2 * _one_third, dt, y0))
+        k4 = self.move(t1, t_one_third, self.fuse(k1 - k2 + k3, dt, y0))
+        return (self.fuse(k1, dt, y0) + 3 * self.fuse(k2, dt, y0) + 3 * self.fuse(k3, dt, y0) + self.fuse(k4, dt, y0)) * 0.125
+
+    def integrate(self, t_span):
+        """base_fixed_solver.py:103-144"""
+        pred_len = len(t_span)
+        time_grid = t_span
+        sol = [self.y0]
+        y0 = self.y0
+        for i in range(1, pred_len):
+            t0, t1 = time_grid[i - 1 : i], time_grid[i : i + 1]
+            y1, dy0 = self.step(t0, t1, y0)
+            if self.interp == "linear":
+                sol.append(linear_interp(t0, t1, y0, y1, t_span[i : i + 1]))
+            elif self.interp == "cubic":
+                y2, dy1 = self.step(t1, t1, y1)
+                sol.append(cubic_hermite_interp(t0, y0, dy0, t1, y1, dy1, t_span[i : i + 1]))
+            else:
+                sol.append(y1)
+            y0 = y1
+        return np.concatenate(sol, axis=-2)
+
+
+# --------------------------------------------------------------------------------------
+# adaptive embedded Runge-Kutta solvers
+#           (paddlexde/solver/base_adaptive_solver.py, base_adaptive_solver_rk.py)
+# --------------------------------------------------------------------------------------
+
+RKState = collections.namedtuple("RKState", "y1 f1 t0 t1 dt interp_coeff")
+StepRecord = collections.namedtuple("StepRecord", "t0 dt ratio accept")
+
+
+class AdaptiveRKSolver:
+    def __init__(
+        self,
+        func,
+        y0,
+        rtol,
+        atol,
+        method="dopri5",
+        norm=_rms_norm,
+        min_step=0,
+        max_step=float("inf"),
+        first_step=None,
+        step_t=None,
+        jump_t=None,
+        safety=0.9,
+        ifactor=10.0,
+        dfactor=0.2,
+        max_num_steps=2**31 - 1,
+        dtype=np.float32,
+        reduce_hook=None,
+        **unused,
+    ):
+        """base_adaptive_solver_rk.py:32-79.  ``dtype`` is the dtype of time-like scalars."""
+        if jump_t is not None:
+            raise NotImplementedError("jump_t calls a non-existent self.func in the reference (D7)")
+        self.func = func
+        self.y0 = y0
+        self.norm = norm
+        self.order, tableau, mid = ADAPTIVE[method]
+        tt = np.dtype(dtype).type
+        self.tt = tt
+        self.rtol = tt(rtol)
+        self.atol = tt(atol)
+        self.min_step = tt(min_step)
+        self.max_step = tt(max_step)
+        self.first_step = None if first_step is None else tt(first_step)
+        self.safety = tt(safety)
+        self.ifactor = tt(ifactor)
+        self.dfactor = tt(dfactor)
+        self.max_num_steps = max_num_steps
+        self.step_t = None if step_t is None else np.asarray(step_t, dtype=dtype)
+        yd = y0.dtype
+        # :73-79 cast tableau to the state dtype
+        self.tableau = ButcherTableau(
+            alpha=tableau.alpha.astype(yd),
+            beta=[b.astype(yd) for b in tableau.beta],
+            c_sol=tableau.c_sol.astype(yd),
+            c_error=tableau.c_error.astype(yd),
+        )
+        self.mid = mid.astype(yd)
+        self.nfe = 0
+        self.trace = []  # StepRecord per attempted step (oracle-only instrumentation)
+        self.n_accept = 0
+        self.n_reject = 0
+
+    def move(self, t0, dt, y0):
+        self.nfe += 1
+        return np.asarray(self.func(t0, y0))
+
+    @staticmethod
+    def fuse(dy, dt, y0):
+        return dy * dt + y0
+
+    # base_adaptive_solver.py:24-31
+    def integrate(self, t_span):
+        solution = np.empty((len(t_span),) + self.y0.shape, dtype=self.y0.dtype)
+        solution[0] = self.y0
+        t_span = np.asarray(t_span).astype(self.tt)
+        self._before_integrate(t_span)
+        for i in range(1, len(t_span)):
+            solution[i] = self.step(t_span[i])
+        return solution
+
+    # base_adaptive_solver.py:33-72
+    def select_initial_step(self, t0, y0, order, rtol, atol, f0=None):
+        dtype = y0.dtype.type
+        t_dtype = type(t0)
+        if f0 is None:
+            f0 = self.move(t0, 0, y0)
+        scale = atol + np.abs(y0) * rtol
+        d0 = np.abs(self.norm(y0 / scale))
+        d1 = np.abs(self.norm(f0 / scale))
+        if d0 < 1e-5 or d1 < 1e-5:
+            h0 = dtype(1e-6)
+        else:
+            h0 = 0.01 * d0 / d1
+        h0 = np.abs(h0)
+        y1 = self.fuse(f0, h0, y0)
+        f1 = self.move(t0 + h0, 0, y1)
+        d2 = np.abs(self.norm((f1 - f0) / scale) / h0)
+        if d1 <= 1e-15 and d2 <= 1e-15:
+            h1 = max(dtype(1e-6), h0 * 1e-3)
+        else:
+            h1 = (0.01 / max(d1, d2)) ** (1.0 / float(order + 1))
+        h1 = np.abs(h1)
+        return t_dtype(np.fmin(100.0 * h0, h1))
+
+    # base_adaptive_solver_rk.py:81-114
+    def _before_integrate(self, t_span):
+        t0 = t_span[0]
+        f0 = self.move(t_span[0], t_span[1] - t_span[0], self.y0)
+        if self.first_step is None:
+            first_step = self.select_initial_step(t_span[0], self.y0, self.order - 1, self.rtol, self.atol)
+        else:
+            first_step = self.first_step
+        self.rk_state = RKState(self.y0, f0, t_span[0], t_span[0], first_step, [self.y0] * 5)
+        if self.step_t is None:
+            step_t = np.asarray([], dtype=self.tt)
+        else:
+            step_t = np.sort(self.step_t[self.step_t >= t0])  # ode_utils.py:22-25
+        self.step_t = step_t
+        self.next_step_index = min(bisect.bisect(self.step_t.tolist(), t_span[0]), len(self.step_t) - 1)
+
+    # base_adaptive_solver_rk.py:116-127
+    def step(self, next_t):
+        n_steps = 0
+        while next_t > self.rk_state.t1:
+            assert n_steps < self.max_num_steps, "max_num_steps exceeded ({}>={})".format(n_steps, self.max_num_steps)
+            self.rk_state = self._adaptive_step(self.rk_state)
+            n_steps += 1
+        return interp_evaluate(self.rk_state.interp_coeff, self.rk_state.t0, self.rk_state.t1, next_t)
+
+    # base_adaptive_solver_rk.py:129-181
+    def _runge_kutta_step(self, y0, f0, t0, dt, t1, tableau):
+        t_dtype = y0.dtype.type
+        t0 = t_dtype(t0)
+        dt = t_dtype(dt)
+        t1 = t_dtype(t1)
+        k = np.empty(f0.shape + (len(tableau.alpha) + 1,), dtype=y0.dtype)
+        k[..., 0] = f0
+        for i, (alpha_i, beta_i) in enumerate(zip(tableau.alpha, tableau.beta)):
+            if alpha_i == 1.0:
+                ti = t1
+            else:
+                ti = t0 + alpha_i * dt
+            yi = y0 + np.sum(k[..., : i + 1] * (beta_i * dt), axis=-1).reshape(y0.shape)
+            f = self.move(ti, dt, yi)
+            k[..., i + 1] = f
+        if not (tableau.c_sol[-1] == 0 and (tableau.c_sol[:-1] == tableau.beta[-1]).all()):
+            yi = y0 + np.sum(k * (dt * tableau.c_sol), axis=-1).reshape(y0.shape)
+        y1 = yi
+        f1 = k[..., -1]
+        y1_error = np.sum(k * (dt * tableau.c_error), axis=-1)
+        return y1, f1, y1_error, k
+
+    # base_adaptive_solver_rk.py:183-284
+    def _adaptive_step(self, rk_state):
+        y0, f0, _, t0, dt, interp_coeff = rk_state
+        t1 = t0 + dt
+        assert t0 + dt > t0, "underflow in dt {}".format(float(dt))
+        assert np.isfinite(y0).all(), "non-finite values in state `y`: {}".format(y0)
+
+        on_step_t = False
+        if len(self.step_t):
+            next_step_t = self.step_t[self.next_step_index]
+            on_step_t = t0 < next_step_t < t0 + dt
+            if on_step_t:
+                t1 = next_step_t
+                dt = t1 - t0
+
+        with np.errstate(all="ignore"):
+            y1, f1, y1_error, k = self._runge_kutta_step(y0, f0, t0, dt, t1, tableau=self.tableau)
+            error_ratio = compute_error_ratio(y1_error, self.rtol, self.atol, y0, y1, self.norm)
+        accept_step = bool(error_ratio <= 1)
+        if dt > self.max_step:
+            accept_step = False
+        if dt <= self.min_step:
+            accept_step = True
+        self.trace.append(StepRecord(float(t0), float(dt), float(error_ratio), accept_step))
+
+        if accept_step:
+            self.n_accept += 1
+            t_next = t1
+            y_next = y1
+            interp_coeff = self._interp_fit(y0, y_next, k, dt)
+            if on_step_t:
+                if self.next_step_index != len(self.step_t) - 1:
+                    self.next_step_index += 1
+            f_next = f1
+        else:
+            self.n_reject += 1
+            t_next = t0
+            y_next = y0
+            f_next = f0
+        dt_next = optimal_step_size(dt, error_ratio, self.safety, self.ifactor, self.dfactor, self.order)
+        dt_next = self.tt(np.clip(dt_next, self.min_step, self.max_step))
+        return RKState(y_next, f_next, t0, t_next, dt_next, interp_coeff)
+
+    # base_adaptive_solver_rk.py:286-292
+    def _interp_fit(self, y0, y1, k, dt):
+        dt = y0.dtype.type(dt)
+        y_mid = y0 + np.sum(k * (dt * self.mid), axis=-1).reshape(y0.shape)
+        f0 = k[..., 0]
+        f1 = k[..., -1]
+        return interp_fit(y0, y1, y_mid, f0, f1, dt)
+
+
+# --------------------------------------------------------------------------------------
+# tuple state (D4): flatten -> integrate -> unflatten
+# --------------------------------------------------------------------------------------
+
+
+def _flatten(tensors):
+    return np.concatenate([np.asarray(x).reshape(-1) for x in tensors])
+
+
+def _unflatten(flat, shapes, lead=()):
+    """utils/misc.py:1-13 (intent).  ``flat`` has shape ``lead + (total,)``."""
+    out, total = [], 0
+    for shape in shapes:
+        n = int(np.prod(shape)) if len(shape) else 1
+        out.append(flat[..., total : total + n].reshape(tuple(lead) + tuple(shape)))
+        total += n
+    return tuple(out)
+
+
+# --------------------------------------------------------------------------------------
+# public entry points                                   (paddlexde/functional/odeint.py)
+# --------------------------------------------------------------------------------------
+
+
+def odeint(func, y0, t_span, solver, *, rtol=1e-7, atol=1e-9, options=None, return_solver=False):
+    """functional/odeint.py:9-35.
+
+    ``solver`` is one of ``FIXED`` / ``ADAPTIVE`` names.  ``func(t, y)`` takes and returns
+    numpy arrays (``t``: shape ``[1]`` for fixed solvers, 0-dim for adaptive solvers, as in the
+    reference).  Output layout (D3): fixed -> concat on axis -2; adaptive -> ``[T, *y0.shape]``.
+    """
+    options = dict({"norm": _rms_norm} if options is None else options)
+    t_span = np.asarray(t_span)
+
+    shapes = None
+    if isinstance(y0, (tuple, list)):  # D4
+        shapes = [np.shape(x) for x in y0]
+        y_dtype = np.result_type(*[np.asarray(x).dtype for x in y0])
+        user_func, user_norm = func, options.get("norm", _rms_norm)
+        y0 = _flatten(y0).astype(y_dtype)
+
+        def func(t, y):  # noqa: F811
+            return _flatten(user_func(t, _unflatten(y, shapes))).astype(y_dtype)
+
+        if solver in ADAPTIVE:
+            options["norm"] = lambda flat: user_norm(_unflatten(flat, shapes))
+    else:
+        y0 = np.asarray(y0)
+
+    if solver in FIXED:
+        s = FixedSolver(func, y0, method=solver, rtol=rtol, atol=atol, **options)
+        solution = s.integrate(t_span)
+        if shapes is not None:
+            # y0 is 1-D [total]; concat(axis=-2) is undefined for it in the reference; tuple
+            # states are therefore returned time-first like the adaptive layout.
+            raise NotImplementedError("tuple state with a fixed solver: use odeint_tuple_fixed")
+    elif solver in ADAPTIVE:
+        reverse = len(t_span) > 1 and bool(t_span[0] > t_span[1])
+        if reverse:  # D5
+            inner = func
+            func = lambda t, y: -inner(-t, y)  # noqa: E731
+            t_span = -t_span
+        s = AdaptiveRKSolver(func, y0, rtol, atol, method=solver, **options)
+        solution = s.integrate(t_span)
+        if shapes is not None:
+            solution = _unflatten(solution, shapes, lead=(len(t_span),))
+    else:
+        raise ValueError("unknown solver {!r}".format(solver))
+    return (solution, s) if return_solver else solution
+
+
+def odeint_tuple_fixed(func, y0_tuple, t_span, solver, *, rtol=1e-7, atol=1e-9, options=None):
+    """Fixed-grid integration of a tuple state, time-first output per component (D4 intent).
+
+    The flat 1-D state is given a dummy ``[1, total]`` shape so that the reference's
+    ``concat(axis=-2)`` stacks time on axis 0.
+    """
+    options = dict({"norm": _rms_norm} if options is None else options)
+    shapes = [np.shape(x) for x in y0_tuple]
+    y_dtype = np.result_type(*[np.asarray(x).dtype for x in y0_tuple])
+    flat0 = _flatten(y0_tuple).astype(y_dtype)[None, :]
+
+    def flat_func(t, y):
+        return _flatten(func(t, _unflatten(y[0], shapes))).astype(y_dtype)[None, :]
+
+    s = FixedSolver(flat_func, flat0, method=solver, rtol=rtol, atol=atol, **options)
+    sol = s.integrate(np.asarray(t_span))  # [T, total]
+    return _unflatten(sol, shapes, lead=(len(t_span),))
+
+
+# --------------------------------------------------------------------------------------
+# adjoint                                       (paddlexde/functional/odeint_adjoint.py)
+# --------------------------------------------------------------------------------------
+
+
+def odeint_adjoint(func, vjp, params, y0, t_span, solver, *, rtol=1e-7, atol=1e-9, options=None,
+                   adjoint_rtol=None, adjoint_atol=None, adjoint_solver=None, adjoint_options=None):
+    """functional/odeint_adjoint.py:170-257 (forward) and :47-167 (backward).
+
+    numpy has no autograd, so the caller supplies ``vjp(t, y, cot) -> (vjp_y, [vjp_p ...])``
+    that evaluates ``cot^T df/dy`` and ``cot^T df/dp`` for each array in ``params``.
+    Returns ``(ans, backward)`` where ``backward(grad_ans) -> (grad_y0, [grad_p ...])``;
+    ``grad_y0`` is the superset output of D6.  Gradients w.r.t. ``t_span`` are not produced
+    (``t_requires_grad=False`` path of the reference).
+    """
+    options = dict({"norm": _rms_norm} if options is None else options)
+    adjoint_rtol = rtol if adjoint_rtol is None else adjoint_rtol  # :196-201
+    adjoint_atol = atol if adjoint_atol is None else adjoint_atol
+    adjoint_solver = solver if adjoint_solver is None else adjoint_solver
+    if adjoint_options is None:  # :209-214
+        adjoint_options = {k: v for k, v in options.items() if k != "norm"}
+    else:
+        adjoint_options = dict(adjoint_options)
+    state_norm = options["norm"]
+
+    # handle_adjoint_norm_ :280-327
+    def default_adjoint_norm(tensor_tuple):
+        t, y, adj_y, *adj_params = tensor_tuple
+        return max(np.abs(t).max(), state_norm(y), state_norm(adj_y), _mixed_norm(adj_params))
+
+    def adjoint_seminorm(tensor_tuple):
+        t, y, adj_y, *adj_params = tensor_tuple
+        return max(np.abs(t).max(), state_norm(y), state_norm(adj_y))
+
+    if "norm" not in adjoint_options:
+        adjoint_options["norm"] = default_adjoint_norm
+    elif adjoint_options["norm"] == "seminorm":
+        adjoint_options["norm"] = adjoint_seminorm
+
+    t_span = np.asarray(t_span)
+    y0 = np.asarray(y0)
+    ans = odeint(func, y0, t_span, solver, rtol=rtol, atol=atol, options=options)  # :37-40
+    time_first = solver in ADAPTIVE
+
+    def backward(grad_y):
+        grad_y = np.asarray(grad_y)
+        y_ans = ans
+        if not time_first:
+            # the reference's backward indexes ``y_ans[-1]`` i.e. assumes time-first (:75-79); for the
+            # fixed layout (time on axis -2) the time axis is moved to the front (intent).
+            T = len(t_span)
+            L = y0.shape[-2]
+            y_ans = np.moveaxis(ans.reshape(y0.shape[:-2] + (T, L, y0.shape[-1])), -3, 0)
+            grad_y = np.moveaxis(grad_y.reshape(y0.shape[:-2] + (T, L, y0.shape[-1])), -3, 0)
+        aug_state = [np.zeros((), dtype=y_ans.dtype), y_ans[-1], grad_y[-1]]
+        aug_state.extend([np.zeros_like(p) for p in params])
+
+        def augmented_dynamics(t, y_aug):  # :89-124
+            y = y_aug[1]
+            adj_y = y_aug[2]
+            func_eval = np.asarray(func(t, y))
+            vjp_y, vjp_params = vjp(t, y, -adj_y)
+            vjp_t = np.zeros((), dtype=y.dtype)
+            vjp_params = [np.zeros_like(p) if v is None else v for p, v in zip(params, vjp_params)]
+            return (vjp_t, func_eval, vjp_y, *vjp_params)
+
+        for i in range(len(t_span) - 1, 0, -1):  # :134-159
+            ts = t_span[i - 1 : i + 1][::-1]
+            if adjoint_solver in ADAPTIVE:
+                aug = odeint(augmented_dynamics, tuple(aug_state), ts, adjoint_solver,
+                             rtol=adjoint_rtol, atol=adjoint_atol, options=adjoint_options)
+            else:
+                fopts = dict(adjoint_options)
+                fopts["norm"] = None
+                aug = odeint_tuple_fixed(augmented_dynamics, tuple(aug_state), ts, adjoint_solver,
+                                         rtol=adjoint_rtol, atol=adjoint_atol, options=fopts)
+            aug_state = [a[1] for a in aug]
+            aug_state[1] = y_ans[i - 1]
+            aug_state[2] = aug_state[2] + grad_y[i - 1]
+        return aug_state[2], list(aug_state[3:])
+
+    return ans, backward

@@ -1,0 +1,10 @@
+"""paddlexde_amd — MI355X-native integration engine behind the paddlexde ``odeint`` / ``odeint_adjoint`` API.
+
+The compute path is libxde_hip.so (hand-written gfx950 kernels, C ABI in include/xde_hip.h) driven from
+Python over ctypes with torch-ROCm tensors as device buffers.  There is no CPU fallback.
+"""
+__version__ = "0.1.0"
+
+from .functional import odeint, odeint_adjoint  # noqa: F401
+from .solver import *  # noqa: F401,F403
+from .xde import BaseODE, BaseXDE  # noqa: F401

@@ -1,0 +1,347 @@
+"""ctypes binding of libxde_hip.so (C ABI: include/xde_hip.h).
+
+The library is the product's only compute path.  There is NO CPU fallback: if the shared
+object is missing, or a tensor is not on a ROCm device, the calls below raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+XDE_OK, XDE_EBADARG, XDE_EHIP = 0, 1, 2
+XDE_F32, XDE_F64 = 0, 1
+XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
+COMBINE_RK, COMBINE_FUSE, COMBINE_WFUSE = 0, 1, 2
+NORM_RMS, NORM_LINF = 0, 1
+STATUS_OK, STATUS_DT_UNDERFLOW, STATUS_NONFINITE, STATUS_MAX_STEPS = 0, 1, 2, 3
+KID_NAMES = ("combine", "errnorm", "control", "dense", "scalednorm", "finalize")
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libxde_hip.so")
+
+# every symbol include/xde_hip.h declares (tests/test_cabi.py checks the export list against the header)
+SYMBOLS = (
+    "xde_last_error",
+    "xde_abi_version",
+    "xde_sizeof_ctrl",
+    "xde_workspace_bytes",
+    "xde_stage_combine",
+    "xde_error_norm_partial",
+    "xde_scaled_norm_partial",
+    "xde_norm_finalize",
+    "xde_norm_result",
+    "xde_rk_control",
+    "xde_ctrl_init",
+    "xde_ctrl_read",
+    "xde_dense_eval",
+    "xde_prof_enable",
+    "xde_prof_collect",
+)
+
+
+class XdeCtrl(C.Structure):
+    """xde_ctrl_t"""
+
+    _fields_ = [
+        ("t0", C.c_double),
+        ("t1", C.c_double),
+        ("dt", C.c_double),
+        ("dt_last", C.c_double),
+        ("t_plan", C.c_double),
+        ("ratio_prev", C.c_double),
+        ("ratio", C.c_double),
+        ("ratio_seg", C.c_double * XDE_MAX_SEG),
+        ("nonfinite", C.c_double),
+        ("n_steps", C.c_int64),
+        ("n_accept", C.c_int64),
+        ("n_reject", C.c_int64),
+        ("steps_in_interval", C.c_int64),
+        ("accept", C.c_int32),
+        ("sel_used", C.c_int32),
+        ("status", C.c_int32),
+        ("out_begin", C.c_int32),
+        ("out_end", C.c_int32),
+        ("next_out", C.c_int32),
+        ("n_out", C.c_int32),
+        ("done", C.c_int32),
+        ("next_step_index", C.c_int32),
+        ("on_step_t", C.c_int32),
+        ("reserved", C.c_int32 * 6),
+    ]
+
+
+class XdeCtrlParams(C.Structure):
+    """xde_ctrl_params_t"""
+
+    _fields_ = [
+        ("rtol", C.c_double),
+        ("atol", C.c_double),
+        ("min_step", C.c_double),
+        ("max_step", C.c_double),
+        ("safety", C.c_double),
+        ("ifactor", C.c_double),
+        ("dfactor", C.c_double),
+        ("order", C.c_double),
+        ("max_num_steps", C.c_int64),
+        ("time_dtype", C.c_int32),
+        ("state_dtype", C.c_int32),
+        ("direction", C.c_int32),
+        ("norm_kind", C.c_int32),
+        ("n_stage", C.c_int32),
+        ("n_seg", C.c_int32),
+        ("n_step_t", C.c_int32),
+        ("pi_controller", C.c_int32),
+        ("pi_beta", C.c_double),
+        ("alpha", C.c_double * XDE_MAX_STAGE),
+        ("seg_count", C.c_double * XDE_MAX_SEG),
+    ]
+
+
+class XdeSegments(C.Structure):
+    """xde_segments_t"""
+
+    _fields_ = [
+        ("n_seg", C.c_int32),
+        ("seg_start", C.c_int64 * XDE_MAX_SEG),
+        ("seg_len", C.c_int64 * XDE_MAX_SEG),
+    ]
+
+
+class XdeError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libxde_hip.so and declare prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise XdeError(
+                "paddlexde_amd: {} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python -m paddlexde_amd.csrc.build`. There is no CPU fallback.".format(LIB_PATH)
+            )
+        lib = C.CDLL(LIB_PATH)
+        vp, dp, i32, i64, dbl = C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int64, C.c_double
+        vpp = C.POINTER(C.c_void_p)
+        lib.xde_last_error.restype = C.c_char_p
+        lib.xde_last_error.argtypes = []
+        lib.xde_abi_version.restype = i32
+        lib.xde_sizeof_ctrl.restype = i64
+        lib.xde_workspace_bytes.restype = i64
+        lib.xde_stage_combine.restype = i32
+        lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp]
+        lib.xde_error_norm_partial.restype = i32
+        lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp]
+        lib.xde_scaled_norm_partial.restype = i32
+        lib.xde_scaled_norm_partial.argtypes = [vp, vp, vp, dbl, dbl, C.POINTER(XdeSegments), i32, i32, vp, i32, vp]
+        lib.xde_norm_finalize.restype = i32
+        lib.xde_norm_finalize.argtypes = [vp, i32, vp, vp]
+        lib.xde_norm_result.restype = i32
+        lib.xde_norm_result.argtypes = [vp, dp, i32, i32, i32, vp, vp]
+        lib.xde_rk_control.restype = i32
+        lib.xde_rk_control.argtypes = [vp, C.POINTER(XdeCtrlParams), vp, vp, vp, vp, vp, vp]
+        lib.xde_ctrl_init.restype = i32
+        lib.xde_ctrl_init.argtypes = [vp, C.POINTER(XdeCtrlParams), dbl, dbl, C.c_int32, vp, vp, vp, vp]
+        lib.xde_ctrl_read.restype = i32
+        lib.xde_ctrl_read.argtypes = [vp, C.POINTER(XdeCtrl), vp]
+        lib.xde_dense_eval.restype = i32
+        lib.xde_dense_eval.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i64, vp]
+        lib.xde_prof_enable.restype = i32
+        lib.xde_prof_enable.argtypes = [i32]
+        lib.xde_prof_collect.restype = i32
+        lib.xde_prof_collect.argtypes = [C.POINTER(C.c_int64), dp, dp]
+        if lib.xde_abi_version() != 1:
+            raise XdeError("libxde_hip.so ABI version mismatch")
+        if lib.xde_sizeof_ctrl() != C.sizeof(XdeCtrl):
+            raise XdeError("xde_ctrl_t layout mismatch between header and ctypes mirror")
+        _lib = lib
+    return _lib
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return XDE_F32
+    if dt == torch.float64:
+        return XDE_F64
+    raise TypeError("paddlexde_amd kernels support float32 and float64 states, got {}".format(dt))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dbl_array(xs):
+    return (C.c_double * len(xs))(*[float(x) for x in xs])
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def make_segments(segs) -> XdeSegments:
+    s = XdeSegments()
+    s.n_seg = len(segs)
+    for i, (start, length) in enumerate(segs):
+        s.seg_start[i] = int(start)
+        s.seg_len[i] = int(length)
+    return s
+
+
+class HipBackend:
+    """The production backend: every method enqueues one kernel of libxde_hip.so on torch's current stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = load_library()
+
+    # -- helpers -------------------------------------------------------------------------
+    def _check(self, rc, who):
+        if rc != XDE_OK:
+            raise XdeError("{} failed (status {}): {}".format(who, rc, self.lib.xde_last_error().decode()))
+
+    def require_device(self, *tensors):
+        self._require_device(*tensors)
+
+    @staticmethod
+    def _require_device(*tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise XdeError(
+                    "paddlexde_amd: tensors must live on a ROCm device (got device={}); there is no CPU path".format(t.device)
+                )
+
+    @staticmethod
+    def _stream(t):
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    # -- allocation (torch is the allocator; the library never allocates) -------------------
+    def new_ctrl(self, device):
+        return torch.zeros(C.sizeof(XdeCtrl), dtype=torch.uint8, device=device)
+
+    def new_workspace(self, device):
+        return torch.zeros(int(self.lib.xde_workspace_bytes()), dtype=torch.uint8, device=device)
+
+    def new_sums(self, device):
+        return torch.zeros(2 * XDE_MAX_SEG, dtype=torch.float64, device=device)
+
+    # -- kernels ---------------------------------------------------------------------------
+    def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None):
+        self._require_device(out, y0, *ks)
+        rc = self.lib.xde_stage_combine(
+            out.data_ptr(), y0.data_ptr(), _ptr(y0_alt), _ptr_array(ks), _ptr(k0_alt), _dbl_array(coef), len(ks),
+            mode, float(scale), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype), self._stream(out),
+        )
+        self._check(rc, "xde_stage_combine")
+
+    def error_norm_partial(self, ks, c_err, y0, y1, rtol, atol, segs, norm_kind, ws, *, dt_host=0.0, ctrl=None,
+                           y0_alt=None, k0_alt=None):
+        self._require_device(y0, y1, ws, *ks)
+        rc = self.lib.xde_error_norm_partial(
+            _ptr_array(ks), _ptr(k0_alt), _dbl_array(c_err), len(ks), y0.data_ptr(), _ptr(y0_alt), y1.data_ptr(),
+            float(rtol), float(atol), float(dt_host), _ptr(ctrl), C.byref(segs), norm_kind, dtype_code(y0.dtype),
+            ws.data_ptr(), self._stream(y0),
+        )
+        self._check(rc, "xde_error_norm_partial")
+
+    def scaled_norm_partial(self, a, b, y0, rtol, atol, segs, norm_kind, ws, slot):
+        self._require_device(a, b, y0, ws)
+        rc = self.lib.xde_scaled_norm_partial(
+            a.data_ptr(), _ptr(b), y0.data_ptr(), float(rtol), float(atol), C.byref(segs), norm_kind,
+            dtype_code(y0.dtype), ws.data_ptr(), slot, self._stream(y0),
+        )
+        self._check(rc, "xde_scaled_norm_partial")
+
+    def norm_finalize(self, ws, slot, sums):
+        self._require_device(ws, sums)
+        self._check(self.lib.xde_norm_finalize(ws.data_ptr(), slot, sums.data_ptr(), self._stream(ws)), "xde_norm_finalize")
+
+    def norm_result(self, sums, seg_count, norm_kind, state_dtype, result):
+        self._require_device(sums, result)
+        rc = self.lib.xde_norm_result(sums.data_ptr(), _dbl_array(seg_count), len(seg_count), norm_kind, state_dtype,
+                                      result.data_ptr(), self._stream(sums))
+        self._check(rc, "xde_norm_result")
+
+    def rk_control(self, ctrl, params, ws, sums, t_span_dev, step_t_dev, t_stage):
+        self._require_device(ctrl, t_span_dev, t_stage)
+        rc = self.lib.xde_rk_control(ctrl.data_ptr(), C.byref(params), _ptr(ws), _ptr(sums), t_span_dev.data_ptr(),
+                                     _ptr(step_t_dev), t_stage.data_ptr(), self._stream(ctrl))
+        self._check(rc, "xde_rk_control")
+
+    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage):
+        self._require_device(ctrl, t_span_dev, t_stage)
+        rc = self.lib.xde_ctrl_init(ctrl.data_ptr(), C.byref(params), float(t_start), float(first_step), int(n_out),
+                                    t_span_dev.data_ptr(), _ptr(step_t_dev), t_stage.data_ptr(), self._stream(ctrl))
+        self._check(rc, "xde_ctrl_init")
+
+    def ctrl_read(self, ctrl) -> XdeCtrl:
+        self._require_device(ctrl)
+        host = XdeCtrl()
+        self._check(self.lib.xde_ctrl_read(ctrl.data_ptr(), C.byref(host), self._stream(ctrl)), "xde_ctrl_read")
+        return host
+
+    def ctrl_read_async(self, ctrl):
+        """Enqueue a device->pinned-host copy of the control block; returns a handle for ctrl_wait()."""
+        self._require_device(ctrl)
+        host = torch.empty(ctrl.numel(), dtype=torch.uint8, pin_memory=True)
+        host.copy_(ctrl, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ctrl.device))
+        return (host, ev)
+
+    def ctrl_wait(self, handle) -> XdeCtrl:
+        host, ev = handle
+        ev.synchronize()
+        return XdeCtrl.from_buffer_copy(host.numpy().tobytes())
+
+    def dense_eval(self, out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype, *, y0_alt=None, k0_alt=None,
+                   expect_step=-1):
+        self._require_device(out_base, y0, y1, f1, ctrl, t_span_dev, *ks)
+        rc = self.lib.xde_dense_eval(
+            out_base.data_ptr(), _ptr_array(ks), _ptr(k0_alt), _dbl_array(mid), len(ks), y0.data_ptr(), _ptr(y0_alt),
+            y1.data_ptr(), f1.data_ptr(), ctrl.data_ptr(), t_span_dev.data_ptr(), time_dtype, y0.numel(),
+            dtype_code(y0.dtype), int(expect_step), self._stream(y0),
+        )
+        self._check(rc, "xde_dense_eval")
+
+    # -- profiling ---------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._check(self.lib.xde_prof_enable(1 if on else 0), "xde_prof_enable")
+
+    def prof_collect(self):
+        n = len(KID_NAMES)
+        counts = (C.c_int64 * n)()
+        ms = (C.c_double * n)()
+        by = (C.c_double * n)()
+        self._check(self.lib.xde_prof_collect(counts, ms, by), "xde_prof_collect")
+        return {KID_NAMES[i]: {"launches": int(counts[i]), "ms": float(ms[i]), "bytes": float(by[i])} for i in range(n)}
+
+
+_backend = None
+
+
+def get_backend():
+    """The HIP backend (created on first use).  Raises loudly when the library is not built."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def _set_backend_for_testing(backend):
+    """TEST HOOK ONLY (tests/ inject a CPU double to exercise host logic without a GPU).
+
+    Product code never calls this; passing None restores the HIP backend.
+    """
+    global _backend
+    _backend = backend

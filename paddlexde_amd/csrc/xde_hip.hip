@@ -1,0 +1,1364 @@
+// libxde_hip.so — hand-written gfx950 (MI355X / CDNA4) kernels for the Runge–Kutta hot path of
+// paddlexde_amd.  C ABI: include/xde_hip.h (each entry point cites the reference lines it replaces).
+//
+// All kernels are HBM-bandwidth bound (≈0.5 flop/byte): 16-byte-per-lane coalesced loads, grid-stride
+// loops sized to keep every CU's memory queue full (2048 workgroups × 256 threads = 8 waves/SIMD),
+// fp32 per-thread accumulation → wave64 __shfl_down → LDS cross-wave → one fp64 partial per workgroup,
+// reduced in a fixed order by a single workgroup (bit-reproducible, and identical on every rank after
+// the all-reduce).  No MFMA: there is no contraction on this path.
+//
+// Built with -ffp-contract=off so that element-wise results follow the reference's (unfused) op
+// order exactly; the kernels are memory bound, so FMA contraction would buy nothing.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "xde_hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kSlots = 2;
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                               \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess)                                                           \
+      return fail(XDE_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));     \
+  } while (0)
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  int x = atoi(v);
+  return x > 0 ? x : dflt;
+}
+
+int grid_cap() {
+  static int cap = env_int("XDE_GRID_BLOCKS", 2048);
+  return cap > XDE_MAX_PARTIALS ? XDE_MAX_PARTIALS : cap;
+}
+
+// ------------------------------------------------------------------------------------------
+// vector types: 16 bytes per lane
+// ------------------------------------------------------------------------------------------
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { using type = float4; static constexpr int W = 4; };
+template <> struct VecOf<double> { using type = double2; static constexpr int W = 2; };
+
+template <typename T, bool VEC> struct Pack;
+template <> struct Pack<float, true> {
+  static constexpr int W = 4;
+  float v[4];
+  __device__ static Pack load(const float* p, int64_t i) {
+    float4 x = reinterpret_cast<const float4*>(p)[i];
+    return Pack{{x.x, x.y, x.z, x.w}};
+  }
+  __device__ void store(float* p, int64_t i) const {
+    reinterpret_cast<float4*>(p)[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Pack<double, true> {
+  static constexpr int W = 2;
+  double v[2];
+  __device__ static Pack load(const double* p, int64_t i) {
+    double2 x = reinterpret_cast<const double2*>(p)[i];
+    return Pack{{x.x, x.y}};
+  }
+  __device__ void store(double* p, int64_t i) const {
+    reinterpret_cast<double2*>(p)[i] = make_double2(v[0], v[1]);
+  }
+};
+template <typename T> struct Pack<T, false> {
+  static constexpr int W = 1;
+  T v[1];
+  __device__ static Pack load(const T* p, int64_t i) { return Pack{{p[i]}}; }
+  __device__ void store(T* p, int64_t i) const { p[i] = v[0]; }
+};
+
+template <typename T> __device__ inline bool finite_(T x) { return (x - x) == T(0); }
+template <typename T> __device__ inline T abs_(T x) { return x < T(0) ? -x : x; }
+__device__ inline float abs_(float x) { return fabsf(x); }
+__device__ inline double abs_(double x) { return fabs(x); }
+__device__ inline float fmax_(float a, float b) { return fmaxf(a, b); }
+__device__ inline double fmax_(double a, double b) { return fmax(a, b); }
+// NaN-propagating max (numpy / paddle .max() semantics)
+__device__ inline double nanmax_(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+
+// ------------------------------------------------------------------------------------------
+// kernel argument blocks (passed by value)
+// ------------------------------------------------------------------------------------------
+struct CombineArgs {
+  void* out;
+  const void* y0[2];
+  const void* k[XDE_MAX_K];
+  const void* k0_alt;
+  double coef[XDE_MAX_K];
+  double scale;
+  double dt_host;
+  const xde_ctrl_t* ctrl;
+  int64_t n;
+  int nk;
+  int use_sel;
+};
+
+struct SegMap {
+  int32_t n_seg;
+  int32_t seg_blk[XDE_MAX_SEG + 1];  // block ranges per segment
+  int64_t seg_start[XDE_MAX_SEG];
+  int64_t seg_len[XDE_MAX_SEG];
+};
+
+struct NormSlot {
+  int32_t nblocks;
+  int32_t n_seg;
+  int32_t norm_kind;
+  int32_t pad;
+  int32_t seg_of_block[XDE_MAX_PARTIALS];
+  double val[XDE_MAX_PARTIALS];
+  double nf[XDE_MAX_PARTIALS];
+};
+
+struct ErrArgs {
+  const void* k[XDE_MAX_K];
+  const void* k0_alt;
+  double coef[XDE_MAX_K];
+  const void* y0[2];
+  const void* y1;
+  double rtol, atol, dt_host;
+  const xde_ctrl_t* ctrl;
+  NormSlot* slot;
+  SegMap map;
+  int nk;
+  int use_sel;
+};
+
+struct ScaledArgs {
+  const void* a;
+  const void* b;
+  const void* y0;
+  double rtol, atol;
+  NormSlot* slot;
+  SegMap map;
+};
+
+struct DenseArgs {
+  void* out_base;
+  const void* k[XDE_MAX_K];
+  const void* k0_alt;
+  double mid[XDE_MAX_K];
+  const void* y0[2];
+  const void* y1;
+  const void* f1;
+  const xde_ctrl_t* ctrl;
+  const double* t_span;
+  int64_t n;
+  int nk;
+  int use_sel;
+  int time_dtype;
+  int64_t expect_step;
+};
+
+// ------------------------------------------------------------------------------------------
+// K1: stage combine
+// ------------------------------------------------------------------------------------------
+template <typename T, int MODE, int NK, bool VEC>
+__device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __restrict__ y0,
+                                             const T* __restrict__ k0, T dt) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  T* __restrict__ out = static_cast<T*>(a.out);
+  const T* kp[NK];
+  T c[NK];
+  kp[0] = k0;
+#pragma unroll
+  for (int j = 1; j < NK; ++j) kp[j] = static_cast<const T*>(a.k[j]);
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    // reference: tableau cast to the state dtype, then `beta_i * dt` (RK) — or used as is (FUSE/WFUSE)
+    c[j] = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+  }
+  const T scale = T(a.scale);
+  const int64_t nvec = a.n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P y = P::load(y0, i);
+    P kk[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) kk[j] = P::load(kp[j], i);
+    P o;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      if (MODE == XDE_COMBINE_RK) {
+        T acc = kk[0].v[w] * c[0];
+#pragma unroll
+        for (int j = 1; j < NK; ++j) acc = acc + kk[j].v[w] * c[j];
+        o.v[w] = y.v[w] + acc;
+      } else if (MODE == XDE_COMBINE_FUSE) {
+        T acc = kk[0].v[w] * c[0];
+#pragma unroll
+        for (int j = 1; j < NK; ++j) acc = acc + kk[j].v[w] * c[j];
+        o.v[w] = acc * dt + y.v[w];
+      } else {
+        T acc = (kk[0].v[w] * dt + y.v[w]) * c[0];
+#pragma unroll
+        for (int j = 1; j < NK; ++j) acc = acc + (kk[j].v[w] * dt + y.v[w]) * c[j];
+        o.v[w] = acc * scale;
+      }
+    }
+    o.store(out, i);
+  }
+  if (VEC) {
+    // scalar tail (n % W elements), done by the first threads of block 0
+    const int64_t tail0 = nvec * W;
+    const int64_t i = tail0 + threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n) {
+      T yv = y0[i];
+      T acc;
+      if (MODE == XDE_COMBINE_WFUSE) {
+        acc = (kp[0][i] * dt + yv) * c[0];
+        for (int j = 1; j < NK; ++j) acc = acc + (kp[j][i] * dt + yv) * c[j];
+        out[i] = acc * scale;
+      } else {
+        acc = kp[0][i] * c[0];
+        for (int j = 1; j < NK; ++j) acc = acc + kp[j][i] * c[j];
+        out[i] = (MODE == XDE_COMBINE_RK) ? (yv + acc) : (acc * dt + yv);
+      }
+    }
+  }
+}
+
+// generic operand count (> 8: Dopri8) — runtime loop, same arithmetic order
+template <typename T, int MODE, bool VEC>
+__device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  T* __restrict__ out = static_cast<T*>(a.out);
+  const int nk = a.nk;
+  const T scale = T(a.scale);
+  const int64_t nvec = a.n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P y = P::load(y0, i);
+    P acc;
+    for (int j = 0; j < nk; ++j) {
+      const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+      P kk = P::load(kj, i);
+      T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        T term = (MODE == XDE_COMBINE_WFUSE) ? (kk.v[w] * dt + y.v[w]) * cj : kk.v[w] * cj;
+        acc.v[w] = (j == 0) ? term : acc.v[w] + term;
+      }
+    }
+    P o;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      o.v[w] = (MODE == XDE_COMBINE_RK) ? y.v[w] + acc.v[w]
+               : (MODE == XDE_COMBINE_FUSE) ? acc.v[w] * dt + y.v[w]
+                                            : acc.v[w] * scale;
+    }
+    o.store(out, i);
+  }
+  if (VEC) {
+    const int64_t i = nvec * W + threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n) {
+      T yv = y0[i];
+      T acc = T(0);
+      for (int j = 0; j < nk; ++j) {
+        const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+        T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+        T term = (MODE == XDE_COMBINE_WFUSE) ? (kj[i] * dt + yv) * cj : kj[i] * cj;
+        acc = (j == 0) ? term : acc + term;
+      }
+      out[i] = (MODE == XDE_COMBINE_RK) ? yv + acc : (MODE == XDE_COMBINE_FUSE) ? acc * dt + yv : acc * scale;
+    }
+  }
+}
+
+template <typename T, int MODE, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
+  int sel = 0;
+  T dt;
+  if (a.ctrl) {
+    dt = T(a.ctrl->dt);
+    if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+  } else {
+    dt = T(a.dt_host);
+  }
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  switch (a.nk) {
+    case 1: combine_body<T, MODE, 1, VEC>(a, y0, k0, dt); break;
+    case 2: combine_body<T, MODE, 2, VEC>(a, y0, k0, dt); break;
+    case 3: combine_body<T, MODE, 3, VEC>(a, y0, k0, dt); break;
+    case 4: combine_body<T, MODE, 4, VEC>(a, y0, k0, dt); break;
+    case 5: combine_body<T, MODE, 5, VEC>(a, y0, k0, dt); break;
+    case 6: combine_body<T, MODE, 6, VEC>(a, y0, k0, dt); break;
+    case 7: combine_body<T, MODE, 7, VEC>(a, y0, k0, dt); break;
+    default: combine_generic<T, MODE, VEC>(a, y0, k0, dt); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// block reduction: fp64 value (sum or nan-max) + fp64 non-finite count → one partial per block
+// ------------------------------------------------------------------------------------------
+template <int NORM>
+__device__ __forceinline__ double merge_(double a, double b) {
+  return NORM == XDE_NORM_RMS ? a + b : nanmax_(a, b);
+}
+
+template <int NORM>
+__device__ void block_reduce_store(double val, double nf, NormSlot* slot, int seg) {
+  __shared__ double s_val[kWaves];
+  __shared__ double s_nf[kWaves];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    val = merge_<NORM>(val, __shfl_down(val, off, 64));
+    nf += __shfl_down(nf, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_val[wave] = val;
+    s_nf[wave] = nf;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = s_val[0], f = s_nf[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) {
+      v = merge_<NORM>(v, s_val[w]);
+      f += s_nf[w];
+    }
+    slot->val[blockIdx.x] = v;
+    slot->nf[blockIdx.x] = f;
+    slot->seg_of_block[blockIdx.x] = seg;
+  }
+}
+
+__device__ __forceinline__ int find_segment(const SegMap& m, int b) {
+  int s = 0;
+  while (s + 1 < m.n_seg && b >= m.seg_blk[s + 1]) ++s;
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: fused error combine + tolerance scaling + norm partials (+ non-finite count of y0)
+// ------------------------------------------------------------------------------------------
+template <typename T, int NK, int NORM, bool VEC>
+__device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0,
+                                             T dt, int seg, int lb, int nb, T& acc_out, int& nf_out) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const T* kp[NK];
+  T c[NK];
+  kp[0] = k0;
+#pragma unroll
+  for (int j = 1; j < NK; ++j) kp[j] = static_cast<const T*>(a.k[j]);
+#pragma unroll
+  for (int j = 0; j < NK; ++j) c[j] = dt * T(a.coef[j]);  // `dt * tableau.c_error`
+  const T* __restrict__ y1 = static_cast<const T*>(a.y1);
+  const T rtol = T(a.rtol), atol = T(a.atol);
+  const int64_t start = a.map.seg_start[seg];
+  const int64_t len = a.map.seg_len[seg];
+  const int64_t nvec = len / W;
+  const int64_t vbase = start / W;  // host guarantees start % W == 0 on the vector path
+  const int64_t stride = int64_t(nb) * kBlock;
+  T acc = T(0);
+  int nf = 0;
+  auto one = [&](T e, T y0v, T y1v) {
+    T tol = atol + rtol * fmax_(abs_(y0v), abs_(y1v));
+    T r = e / tol;
+    if (NORM == XDE_NORM_RMS) {
+      T ar = abs_(r);
+      acc = acc + ar * ar;
+    } else {
+      T ar = abs_(r);
+      acc = (ar != ar || acc != acc) ? (ar != ar ? ar : acc) : (ar > acc ? ar : acc);
+    }
+    nf += finite_(y0v) ? 0 : 1;
+  };
+  for (int64_t i = int64_t(lb) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P y0v = P::load(y0, vbase + i);
+    P y1v = P::load(y1, vbase + i);
+    P kk[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) kk[j] = P::load(kp[j], vbase + i);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      T e = kk[0].v[w] * c[0];
+#pragma unroll
+      for (int j = 1; j < NK; ++j) e = e + kk[j].v[w] * c[j];
+      one(e, y0v.v[w], y1v.v[w]);
+    }
+  }
+  if (VEC && lb == 0) {
+    const int64_t i = start + nvec * W + threadIdx.x;
+    if (i < start + len) {
+      T e = kp[0][i] * c[0];
+      for (int j = 1; j < NK; ++j) e = e + kp[j][i] * c[j];
+      one(e, y0[i], y1[i]);
+    }
+  }
+  acc_out = acc;
+  nf_out = nf;
+}
+
+// operand count > 8 (Dopri8): runtime loop over operands, same arithmetic order
+template <typename T, int NORM, bool VEC>
+__device__ void errnorm_generic(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt, int seg,
+                                int lb, int nb, T& acc_out, int& nf_out) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const int nk = a.nk;
+  const T* __restrict__ y1 = static_cast<const T*>(a.y1);
+  const T rtol = T(a.rtol), atol = T(a.atol);
+  const int64_t start = a.map.seg_start[seg];
+  const int64_t len = a.map.seg_len[seg];
+  const int64_t nvec = len / W;
+  const int64_t vbase = start / W;
+  const int64_t stride = int64_t(nb) * kBlock;
+  T acc = T(0);
+  int nf = 0;
+  auto one = [&](T e, T y0v, T y1v) {
+    T tol = atol + rtol * fmax_(abs_(y0v), abs_(y1v));
+    T ar = abs_(e / tol);
+    if (NORM == XDE_NORM_RMS) {
+      acc = acc + ar * ar;
+    } else {
+      acc = (ar != ar || acc != acc) ? (ar != ar ? ar : acc) : (ar > acc ? ar : acc);
+    }
+    nf += finite_(y0v) ? 0 : 1;
+  };
+  for (int64_t i = int64_t(lb) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P y0v = P::load(y0, vbase + i);
+    P y1v = P::load(y1, vbase + i);
+    P e;
+    for (int j = 0; j < nk; ++j) {
+      const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+      P kk = P::load(kj, vbase + i);
+      T cj = dt * T(a.coef[j]);
+#pragma unroll
+      for (int w = 0; w < W; ++w) e.v[w] = (j == 0) ? kk.v[w] * cj : e.v[w] + kk.v[w] * cj;
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) one(e.v[w], y0v.v[w], y1v.v[w]);
+  }
+  if (VEC && lb == 0) {
+    const int64_t i = start + nvec * W + threadIdx.x;
+    if (i < start + len) {
+      T e = T(0);
+      for (int j = 0; j < nk; ++j) {
+        const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+        T term = kj[i] * (dt * T(a.coef[j]));
+        e = (j == 0) ? term : e + term;
+      }
+      one(e, y0[i], y1[i]);
+    }
+  }
+  acc_out = acc;
+  nf_out = nf;
+}
+
+template <typename T, int NORM, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
+  int sel = 0;
+  T dt;
+  if (a.ctrl) {
+    dt = T(a.ctrl->dt);
+    if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+  } else {
+    dt = T(a.dt_host);
+  }
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  const int seg = find_segment(a.map, blockIdx.x);
+  const int lb = blockIdx.x - a.map.seg_blk[seg];
+  const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
+  T acc = T(0);
+  int nf = 0;
+  switch (a.nk) {
+    case 1: errnorm_body<T, 1, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 2: errnorm_body<T, 2, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 3: errnorm_body<T, 3, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 4: errnorm_body<T, 4, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 5: errnorm_body<T, 5, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 6: errnorm_body<T, 6, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 7: errnorm_body<T, 7, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 8: errnorm_body<T, 8, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    default: errnorm_generic<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.slot->nblocks = gridDim.x;
+    a.slot->n_seg = a.map.n_seg;
+    a.slot->norm_kind = NORM;
+  }
+  block_reduce_store<NORM>(double(acc), double(nf), a.slot, seg);
+}
+
+// ------------------------------------------------------------------------------------------
+// scaled norms for select_initial_step:  norm(a / scale)  or  norm((a - b) / scale)
+// ------------------------------------------------------------------------------------------
+template <typename T, int NORM, bool VEC, bool DIFF>
+__global__ __launch_bounds__(kBlock) void xde_scalednorm_kernel(ScaledArgs s) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const T* __restrict__ a = static_cast<const T*>(s.a);
+  const T* __restrict__ b = static_cast<const T*>(s.b);
+  const T* __restrict__ y0 = static_cast<const T*>(s.y0);
+  const int seg = find_segment(s.map, blockIdx.x);
+  const int lb = blockIdx.x - s.map.seg_blk[seg];
+  const int nb = s.map.seg_blk[seg + 1] - s.map.seg_blk[seg];
+  const T rtol = T(s.rtol), atol = T(s.atol);
+  const int64_t start = s.map.seg_start[seg];
+  const int64_t len = s.map.seg_len[seg];
+  const int64_t nvec = len / W;
+  const int64_t vbase = start / W;
+  const int64_t stride = int64_t(nb) * kBlock;
+  T acc = T(0);
+  int nf = 0;
+  auto one = [&](T av, T bv, T yv) {
+    T scale = atol + abs_(yv) * rtol;
+    T num = DIFF ? (av - bv) : av;
+    T r = abs_(num / scale);
+    if (NORM == XDE_NORM_RMS) {
+      acc = acc + r * r;
+    } else {
+      acc = (r != r || acc != acc) ? (r != r ? r : acc) : (r > acc ? r : acc);
+    }
+    nf += finite_(yv) ? 0 : 1;
+  };
+  for (int64_t i = int64_t(lb) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P av = P::load(a, vbase + i);
+    P yv = P::load(y0, vbase + i);
+    P bv = av;
+    if (DIFF) bv = P::load(b, vbase + i);
+#pragma unroll
+    for (int w = 0; w < W; ++w) one(av.v[w], bv.v[w], yv.v[w]);
+  }
+  if (VEC && lb == 0) {
+    const int64_t i = start + nvec * W + threadIdx.x;
+    if (i < start + len) one(a[i], DIFF ? b[i] : a[i], y0[i]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    s.slot->nblocks = gridDim.x;
+    s.slot->n_seg = s.map.n_seg;
+    s.slot->norm_kind = NORM;
+  }
+  block_reduce_store<NORM>(double(acc), double(nf), s.slot, seg);
+}
+
+// ------------------------------------------------------------------------------------------
+// fixed-order reduction of block partials → per-segment sums (one workgroup)
+// ------------------------------------------------------------------------------------------
+__device__ void reduce_partials(const NormSlot* slot, double* seg_val, double* seg_nf) {
+  // called by all kBlock threads of ONE block; results valid in thread 0's view of seg_val/seg_nf
+  // (shared memory arrays of XDE_MAX_SEG)
+  __shared__ double r_val[kBlock];
+  __shared__ double r_nf[kBlock];
+  const int nblocks = slot->nblocks;
+  const int n_seg = slot->n_seg;
+  const bool rms = slot->norm_kind == XDE_NORM_RMS;
+  for (int s = 0; s < n_seg; ++s) {
+    double v = 0.0, f = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+      if (slot->seg_of_block[b] == s) {
+        v = rms ? v + slot->val[b] : nanmax_(v, slot->val[b]);
+        f += slot->nf[b];
+      }
+    }
+    r_val[threadIdx.x] = v;
+    r_nf[threadIdx.x] = f;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+      if (threadIdx.x < off) {
+        r_val[threadIdx.x] = rms ? r_val[threadIdx.x] + r_val[threadIdx.x + off]
+                                 : nanmax_(r_val[threadIdx.x], r_val[threadIdx.x + off]);
+        r_nf[threadIdx.x] += r_nf[threadIdx.x + off];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      seg_val[s] = r_val[0];
+      seg_nf[s] = r_nf[0];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void xde_finalize_kernel(const NormSlot* slot, double* sums_out) {
+  __shared__ double seg_val[XDE_MAX_SEG];
+  __shared__ double seg_nf[XDE_MAX_SEG];
+  if (threadIdx.x < XDE_MAX_SEG) {
+    seg_val[threadIdx.x] = 0.0;
+    seg_nf[threadIdx.x] = 0.0;
+  }
+  __syncthreads();
+  reduce_partials(slot, seg_val, seg_nf);
+  if (threadIdx.x < XDE_MAX_SEG) {
+    sums_out[threadIdx.x] = seg_val[threadIdx.x];
+    sums_out[XDE_MAX_SEG + threadIdx.x] = seg_nf[threadIdx.x];
+  }
+}
+
+__device__ inline double round_to(double x, int dtype) { return dtype == XDE_F32 ? double(float(x)) : x; }
+
+// norm value from finalised sums: max over segments of sqrt(sum/count) (RMS) or of max (LINF),
+// in the state dtype like `_rms_norm` (utils/ode_utils.py:8-9).  NaN propagates.
+__device__ double norm_from_sums(const double* seg_val, const double* seg_count, int n_seg, int norm_kind,
+                                 int state_dtype, double* per_seg_out) {
+  double ratio = 0.0;
+  for (int s = 0; s < n_seg; ++s) {
+    double r;
+    if (norm_kind == XDE_NORM_RMS) {
+      double mean = round_to(seg_val[s] / seg_count[s], state_dtype);
+      r = round_to(sqrt(mean), state_dtype);
+    } else {
+      r = round_to(seg_val[s], state_dtype);
+    }
+    r = fabs(r);
+    if (per_seg_out) per_seg_out[s] = r;
+    ratio = s == 0 ? r : nanmax_(ratio, r);
+  }
+  return ratio;
+}
+
+struct SegCounts {
+  double c[XDE_MAX_SEG];
+};
+
+__global__ void xde_norm_result_kernel(const double* sums, SegCounts counts, int n_seg, int norm_kind, int state_dtype,
+                                       double* result_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    result_out[0] = norm_from_sums(sums, counts.c, n_seg, norm_kind, state_dtype, nullptr);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: controller
+// ------------------------------------------------------------------------------------------
+template <typename TT> __device__ inline TT pow_(TT a, TT b);
+template <> __device__ inline float pow_<float>(float a, float b) { return powf(a, b); }
+template <> __device__ inline double pow_<double>(double a, double b) { return pow(a, b); }
+template <typename TT> __device__ inline TT fmin__(TT a, TT b);
+template <> __device__ inline float fmin__<float>(float a, float b) { return fminf(a, b); }
+template <> __device__ inline double fmin__<double>(double a, double b) { return fmin(a, b); }
+template <typename TT> __device__ inline TT fmax__(TT a, TT b);
+template <> __device__ inline float fmax__<float>(float a, float b) { return fmaxf(a, b); }
+template <> __device__ inline double fmax__<double>(double a, double b) { return fmax(a, b); }
+
+// Plan the pending attempt: step_t clipping (base_adaptive_solver_rk.py:209-215), the underflow and
+// max_num_steps assertions (:200, :120-122) and the stage times of _runge_kutta_step (:159-164).
+template <typename TT>
+__device__ void plan_next(xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* step_t, void* t_stage_out) {
+  const TT dir = TT(p.direction);
+  TT t0 = TT(c->t1);
+  TT dt = TT(c->dt);
+  TT t1 = t0 + dt;
+  int on = 0;
+  if (p.n_step_t > 0 && step_t) {
+    TT nxt = TT(step_t[c->next_step_index]);
+    if (dir * t0 < dir * nxt && dir * nxt < dir * (t0 + dt)) {
+      on = 1;
+      t1 = nxt;
+      dt = t1 - t0;
+    }
+  }
+  c->on_step_t = on;
+  c->dt = double(dt);
+  c->t_plan = double(t1);
+  if (!c->done) {
+    if (!(dir * (t0 + dt) > dir * t0) && c->status == XDE_STATUS_OK) c->status = XDE_STATUS_DT_UNDERFLOW;
+    if (c->steps_in_interval >= p.max_num_steps && c->status == XDE_STATUS_OK) c->status = XDE_STATUS_MAX_STEPS;
+  }
+  // stage times in the state dtype: `t0.astype(t_dtype)`, `ti = t1 if alpha_i == 1 else t0 + alpha_i * dt`
+  for (int i = 0; i < p.n_stage; ++i) {
+    if (p.state_dtype == XDE_F32) {
+      float a = float(p.alpha[i]);
+      float ti = (a == 1.0f) ? float(t1) : float(t0) + a * float(dt);
+      static_cast<float*>(t_stage_out)[i] = ti;
+    } else {
+      double a = p.alpha[i];
+      double ti = (a == 1.0) ? double(t1) : double(t0) + a * double(dt);
+      static_cast<double*>(t_stage_out)[i] = ti;
+    }
+  }
+}
+
+template <typename TT>
+__device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double ratio_d, double nonfinite,
+                             const double* t_span, const double* step_t, void* t_stage_out) {
+  const TT dir = TT(p.direction);
+  const TT t0 = TT(c->t1);
+  const TT dt = TT(c->dt);
+  const TT t1 = TT(c->t_plan);
+  const TT min_step = TT(p.min_step), max_step = TT(p.max_step);
+
+  if (nonfinite > 0.0 && c->status == XDE_STATUS_OK) c->status = XDE_STATUS_NONFINITE;
+
+  // accept / reject                                         base_adaptive_solver_rk.py:244-250
+  int accept = (ratio_d <= 1.0) ? 1 : 0;  // NaN -> reject
+  if (dir * dt > max_step) accept = 0;
+  if (dir * dt <= min_step) accept = 1;
+
+  // optimal_step_size                                                  utils/ode_utils.py:85-97
+  TT dt_next;
+  if (ratio_d == 0.0) {
+    dt_next = dt * TT(p.ifactor);
+  } else {
+    TT dfactor = TT(p.dfactor);
+    if (ratio_d < 1.0) dfactor = TT(1);
+    TT ratio = TT(ratio_d);
+    TT factor;
+    if (p.pi_controller) {
+      // opt-in PI controller (Hairer's dopri5 form); never used for parity
+      TT beta = TT(p.pi_beta);
+      TT alpha = TT(1) / TT(p.order) - TT(0.75) * beta;
+      TT prev = TT(c->ratio_prev > 1e-4 ? c->ratio_prev : 1e-4);
+      factor = fmin__<TT>(TT(p.ifactor), fmax__<TT>(TT(p.safety) * pow_<TT>(prev, beta) / pow_<TT>(ratio, alpha), dfactor));
+    } else {
+      TT exponent = TT(1) / TT(p.order);
+      factor = fmin__<TT>(TT(p.ifactor), fmax__<TT>(TT(p.safety) / pow_<TT>(ratio, exponent), dfactor));
+    }
+    dt_next = dt * factor;
+  }
+  // dt_next.clip(min_step, max_step) on the magnitude (direction-aware)
+  {
+    TT mag = dir * dt_next;
+    if (mag < min_step) mag = min_step;
+    if (mag > max_step) mag = max_step;
+    dt_next = (mag != mag) ? dt_next : dir * mag;
+  }
+
+  c->n_steps += 1;
+  c->steps_in_interval += 1;
+  if (accept) {
+    c->n_accept += 1;
+    if (ratio_d == ratio_d) c->ratio_prev = ratio_d;
+  } else {
+    c->n_reject += 1;
+  }
+  c->sel_used = c->accept;
+  c->accept = accept;
+  c->ratio = ratio_d;
+  c->nonfinite = nonfinite;
+  c->t0 = double(t0);
+  c->t1 = accept ? double(t1) : double(t0);
+  c->dt_last = double(dt);
+  c->dt = double(dt_next);
+
+  // outputs covered by this step: step() loops `while next_t > rk_state.t1`  (:116-127)
+  int b = c->next_out;
+  int e = b;
+  if (accept) {
+    while (e < c->n_out && dir * TT(t_span[e]) <= dir * t1) ++e;
+  }
+  c->out_begin = b;
+  c->out_end = e;
+  c->next_out = e;
+  if (e > b) c->steps_in_interval = 0;
+  c->done = (e >= c->n_out) ? 1 : 0;
+
+  if (accept && c->on_step_t && c->next_step_index != p.n_step_t - 1) c->next_step_index += 1;  // :263-265
+
+  plan_next<TT>(c, p, step_t, t_stage_out);
+}
+
+__global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const NormSlot* slot,
+                                                             const double* sums, const double* t_span,
+                                                             const double* step_t, void* t_stage_out) {
+  __shared__ double seg_val[XDE_MAX_SEG];
+  __shared__ double seg_nf[XDE_MAX_SEG];
+  if (sums) {
+    if (threadIdx.x < XDE_MAX_SEG) {
+      seg_val[threadIdx.x] = sums[threadIdx.x];
+      seg_nf[threadIdx.x] = sums[XDE_MAX_SEG + threadIdx.x];
+    }
+    __syncthreads();
+  } else {
+    if (threadIdx.x < XDE_MAX_SEG) {
+      seg_val[threadIdx.x] = 0.0;
+      seg_nf[threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+    reduce_partials(slot, seg_val, seg_nf);
+  }
+  if (threadIdx.x == 0 && !c->done) {  // a speculative attempt past the last output is a no-op
+    double ratio = norm_from_sums(seg_val, p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, c->ratio_seg);
+    double nf = 0.0;
+    for (int s = 0; s < p.n_seg; ++s) nf += seg_nf[s];
+    if (p.time_dtype == XDE_F32)
+      control_step<float>(c, p, ratio, nf, t_span, step_t, t_stage_out);
+    else
+      control_step<double>(c, p, ratio, nf, t_span, step_t, t_stage_out);
+  }
+}
+
+__global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
+                                     int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  xde_ctrl_t z;
+  memset(&z, 0, sizeof(z));
+  z.t0 = t_start;
+  z.t1 = t_start;
+  z.dt = first_step;
+  z.n_out = n_out;
+  z.ratio_prev = 1e-4;
+  // rows whose time equals the start time are y0 itself (the reference's `while next_t > t1` does not
+  // step for them); the host fills them.
+  const double dir = double(p.direction);
+  int e = 1;
+  while (e < n_out && dir * t_span[e] <= dir * t_start) ++e;
+  z.next_out = e;
+  z.out_begin = e;
+  z.out_end = e;
+  z.done = (e >= n_out) ? 1 : 0;
+  // next_step_index = min(bisect(step_t, t0), len-1)                 base_adaptive_solver_rk.py:109-111
+  int idx = 0;
+  if (p.n_step_t > 0 && step_t) {
+    while (idx < p.n_step_t && dir * step_t[idx] <= dir * t_start) ++idx;
+    if (idx > p.n_step_t - 1) idx = p.n_step_t - 1;
+  }
+  z.next_step_index = idx;
+  *c = z;
+  if (p.time_dtype == XDE_F32)
+    plan_next<float>(c, p, step_t, t_stage_out);
+  else
+    plan_next<double>(c, p, step_t, t_stage_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: dense output (quartic through y0, y_mid, y1, f0, f1), coefficients never materialised
+// ------------------------------------------------------------------------------------------
+template <typename T, typename TT, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const xde_ctrl_t* c = a.ctrl;
+  if (!c->accept) return;
+  if (a.expect_step >= 0 && c->n_steps != a.expect_step) return;
+  const int ob = c->out_begin, oe = c->out_end;
+  if (oe <= ob) return;
+  const int sel = a.use_sel ? (c->sel_used ? 1 : 0) : 0;
+  const T* __restrict__ y0 = static_cast<const T*>(a.y0[sel]);
+  const T* __restrict__ k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  const T* __restrict__ y1 = static_cast<const T*>(a.y1);
+  const T* __restrict__ f1p = static_cast<const T*>(a.f1);
+  T* __restrict__ out = static_cast<T*>(a.out_base);
+  const T dt = T(TT(c->dt_last));  // `dt.astype(y0.dtype)`
+  const TT t0 = TT(c->t0), t1 = TT(c->t1);
+  const int nk = a.nk;
+  const int64_t nvec = a.n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+
+  auto eval = [&](T y0v, T y1v, T f0v, T f1v, T ymid, T x) -> T {
+    // interp_fit (utils/ode_utils.py:44-49) + interp_evaluate (:69-77), same op order
+    T ca = T(2) * dt * (f1v - f0v) - T(8) * (y1v + y0v) + T(16) * ymid;
+    T cb = dt * (T(5) * f0v - T(3) * f1v) + T(18) * y0v + T(14) * y1v - T(32) * ymid;
+    T cc = dt * (f1v - T(4) * f0v) - T(11) * y0v - T(5) * y1v + T(16) * ymid;
+    T cd = dt * f0v;
+    T total = y0v + x * cd;
+    T xp = x;
+    xp = xp * x;
+    total = total + xp * cc;
+    xp = xp * x;
+    total = total + xp * cb;
+    xp = xp * x;
+    total = total + xp * ca;
+    return total;
+  };
+
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P y0v = P::load(y0, i);
+    P y1v = P::load(y1, i);
+    P f0v = P::load(k0, i);
+    P f1v = P::load(f1p, i);
+    P acc;
+    for (int j = 0; j < nk; ++j) {
+      const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+      P kk = (j == 0) ? f0v : P::load(kj, i);
+      T cj = dt * T(a.mid[j]);  // `dt * self.mid`
+#pragma unroll
+      for (int w = 0; w < W; ++w) acc.v[w] = (j == 0) ? kk.v[w] * cj : acc.v[w] + kk.v[w] * cj;
+    }
+    for (int r = ob; r < oe; ++r) {
+      TT xt = (TT(a.t_span[r]) - t0) / (t1 - t0);
+      T x = T(xt);
+      P o;
+#pragma unroll
+      for (int w = 0; w < W; ++w) o.v[w] = eval(y0v.v[w], y1v.v[w], f0v.v[w], f1v.v[w], y0v.v[w] + acc.v[w], x);
+      o.store(out + int64_t(r) * a.n, i);
+    }
+  }
+  if (VEC) {
+    const int64_t i = nvec * W + threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n) {
+      T acc = T(0);
+      for (int j = 0; j < nk; ++j) {
+        const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+        T term = kj[i] * (dt * T(a.mid[j]));
+        acc = (j == 0) ? term : acc + term;
+      }
+      for (int r = ob; r < oe; ++r) {
+        TT xt = (TT(a.t_span[r]) - t0) / (t1 - t0);
+        out[int64_t(r) * a.n + i] = eval(y0[i], y1[i], k0[i], f1p[i], y0[i] + acc, T(xt));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct ProfRec {
+  int kid;
+  hipEvent_t start, stop;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_event_pool;
+double g_prof_bytes[XDE_KID_COUNT] = {0};
+int64_t g_prof_counts[XDE_KID_COUNT] = {0};
+double g_prof_ms[XDE_KID_COUNT] = {0};
+
+hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {
+  bool on;
+  int kid;
+  hipStream_t st;
+  hipEvent_t start, stop;
+  ProfScope(int kid_, hipStream_t st_, double bytes) : on(g_prof_on), kid(kid_), st(st_) {
+    if (on) {
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      start = get_event();
+      stop = get_event();
+      g_prof_bytes[kid] += bytes;
+      (void)hipEventRecord(start, st);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      (void)hipEventRecord(stop, st);
+      g_prof_recs.push_back(ProfRec{kid, start, stop});
+    }
+  }
+};
+
+int build_segmap(const xde_segments_t* segs, int width, bool vec, SegMap* m, int* nblocks_out) {
+  if (!segs || segs->n_seg < 1 || segs->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, "segments: n_seg out of range");
+  const int cap = grid_cap();
+  m->n_seg = segs->n_seg;
+  int64_t total = 0;
+  for (int s = 0; s < segs->n_seg; ++s) {
+    if (segs->seg_len[s] < 0 || segs->seg_start[s] < 0) return fail(XDE_EBADARG, "segments: negative start/len");
+    if (vec && (segs->seg_start[s] % width) != 0) return fail(XDE_EBADARG, "segments: start not vector aligned");
+    total += segs->seg_len[s];
+  }
+  int b = 0;
+  for (int s = 0; s < segs->n_seg; ++s) {
+    m->seg_start[s] = segs->seg_start[s];
+    m->seg_len[s] = segs->seg_len[s];
+    m->seg_blk[s] = b;
+    int64_t per_block = int64_t(kBlock) * width;
+    int64_t want = (segs->seg_len[s] + per_block - 1) / per_block;
+    // share the grid cap between segments proportionally to their length, at least one block each
+    int64_t share = total > 0 ? (int64_t(cap) * segs->seg_len[s] + total - 1) / total : 1;
+    if (share < 1) share = 1;
+    if (want > share) want = share;
+    if (want < 1) want = 1;
+    b += int(want);
+  }
+  m->seg_blk[segs->n_seg] = b;
+  if (b > XDE_MAX_PARTIALS) return fail(XDE_EBADARG, "segments: too many blocks");
+  *nblocks_out = b;
+  return XDE_OK;
+}
+
+bool segs_vec_ok(const xde_segments_t* segs, int width) {
+  for (int s = 0; s < segs->n_seg; ++s)
+    if (segs->seg_start[s] % width) return false;
+  return true;
+}
+
+inline NormSlot* slot_ptr(void* ws, int slot) { return reinterpret_cast<NormSlot*>(ws) + slot; }
+inline const NormSlot* slot_ptr(const void* ws, int slot) { return reinterpret_cast<const NormSlot*>(ws) + slot; }
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+const char* xde_last_error(void) { return g_last_error.c_str(); }
+int xde_abi_version(void) { return XDE_ABI_VERSION; }
+int64_t xde_sizeof_ctrl(void) { return int64_t(sizeof(xde_ctrl_t)); }
+int64_t xde_workspace_bytes(void) { return int64_t(sizeof(NormSlot)) * kSlots; }
+
+int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
+                      const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
+                      int64_t n, int dtype, void* stream) {
+  if (!out || !y0 || !k || !coef) return fail(XDE_EBADARG, "xde_stage_combine: null pointer");
+  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_stage_combine: nk out of range");
+  if (n < 0) return fail(XDE_EBADARG, "xde_stage_combine: negative n");
+  if (mode < 0 || mode > 2) return fail(XDE_EBADARG, "xde_stage_combine: bad mode");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_stage_combine: bad dtype");
+  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: y0_alt/k0_alt must come together");
+  if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_stage_combine: operand select needs ctrl");
+  if (n == 0) return XDE_OK;
+  CombineArgs a;
+  memset(&a, 0, sizeof(a));
+  a.out = out;
+  a.y0[0] = y0;
+  a.y0[1] = y0_alt ? y0_alt : y0;
+  a.k0_alt = k0_alt ? k0_alt : k[0];
+  a.use_sel = y0_alt ? 1 : 0;
+  bool vec = aligned16(out) && aligned16(y0) && aligned16(a.y0[1]) && aligned16(a.k0_alt);
+  for (int j = 0; j < nk; ++j) {
+    if (!k[j]) return fail(XDE_EBADARG, "xde_stage_combine: null k[j]");
+    a.k[j] = k[j];
+    a.coef[j] = coef[j];
+    vec = vec && aligned16(k[j]);
+  }
+  a.scale = scale;
+  a.dt_host = dt_host;
+  a.ctrl = ctrl;
+  a.n = n;
+  a.nk = nk;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const int64_t work = vec ? (n + width - 1) / width : n;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double elt = dtype == XDE_F32 ? 4.0 : 8.0;
+  ProfScope prof(XDE_KID_COMBINE, st, double(nk + 2) * double(n) * elt);
+  dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+#define LAUNCH_COMBINE(T, MODE)                                                     \
+  do {                                                                              \
+    if (vec)                                                                        \
+      hipLaunchKernelGGL((xde_combine_kernel<T, MODE, true>), g, b, 0, st, a);      \
+    else                                                                            \
+      hipLaunchKernelGGL((xde_combine_kernel<T, MODE, false>), g, b, 0, st, a);     \
+  } while (0)
+  if (dtype == XDE_F32) {
+    if (mode == XDE_COMBINE_RK) LAUNCH_COMBINE(float, XDE_COMBINE_RK);
+    else if (mode == XDE_COMBINE_FUSE) LAUNCH_COMBINE(float, XDE_COMBINE_FUSE);
+    else LAUNCH_COMBINE(float, XDE_COMBINE_WFUSE);
+  } else {
+    if (mode == XDE_COMBINE_RK) LAUNCH_COMBINE(double, XDE_COMBINE_RK);
+    else if (mode == XDE_COMBINE_FUSE) LAUNCH_COMBINE(double, XDE_COMBINE_FUSE);
+    else LAUNCH_COMBINE(double, XDE_COMBINE_WFUSE);
+  }
+#undef LAUNCH_COMBINE
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_error_norm_partial(const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
+                           const void* y0_alt, const void* y1, double rtol, double atol, double dt_host,
+                           const xde_ctrl_t* ctrl, const xde_segments_t* segs, int norm_kind, int dtype, void* ws,
+                           void* stream) {
+  if (!k || !c_err || !y0 || !y1 || !ws || !segs) return fail(XDE_EBADARG, "xde_error_norm_partial: null pointer");
+  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_error_norm_partial: nk out of range");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_error_norm_partial: bad dtype");
+  if (norm_kind != XDE_NORM_RMS && norm_kind != XDE_NORM_LINF) return fail(XDE_EBADARG, "xde_error_norm_partial: bad norm");
+  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_error_norm_partial: y0_alt/k0_alt must come together");
+  if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_error_norm_partial: operand select needs ctrl");
+  ErrArgs a;
+  memset(&a, 0, sizeof(a));
+  a.y0[0] = y0;
+  a.y0[1] = y0_alt ? y0_alt : y0;
+  a.k0_alt = k0_alt ? k0_alt : k[0];
+  a.use_sel = y0_alt ? 1 : 0;
+  a.y1 = y1;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  bool vec = aligned16(y0) && aligned16(a.y0[1]) && aligned16(y1) && aligned16(a.k0_alt) && segs_vec_ok(segs, width);
+  for (int j = 0; j < nk; ++j) {
+    if (!k[j]) return fail(XDE_EBADARG, "xde_error_norm_partial: null k[j]");
+    a.k[j] = k[j];
+    a.coef[j] = c_err[j];
+    vec = vec && aligned16(k[j]);
+  }
+  a.rtol = rtol;
+  a.atol = atol;
+  a.dt_host = dt_host;
+  a.ctrl = ctrl;
+  a.slot = slot_ptr(ws, 0);
+  a.nk = nk;
+  int nblocks = 0;
+  int rc = build_segmap(segs, vec ? width : 1, vec, &a.map, &nblocks);
+  if (rc != XDE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double total = 0;
+  for (int s = 0; s < segs->n_seg; ++s) total += double(segs->seg_len[s]);
+  ProfScope prof(XDE_KID_ERRNORM, st, double(nk + 2) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 g(nblocks), b(kBlock);
+#define LAUNCH_ERR(T, NORM)                                                       \
+  do {                                                                            \
+    if (vec)                                                                      \
+      hipLaunchKernelGGL((xde_errnorm_kernel<T, NORM, true>), g, b, 0, st, a);    \
+    else                                                                          \
+      hipLaunchKernelGGL((xde_errnorm_kernel<T, NORM, false>), g, b, 0, st, a);   \
+  } while (0)
+  if (dtype == XDE_F32) {
+    if (norm_kind == XDE_NORM_RMS) LAUNCH_ERR(float, XDE_NORM_RMS);
+    else LAUNCH_ERR(float, XDE_NORM_LINF);
+  } else {
+    if (norm_kind == XDE_NORM_RMS) LAUNCH_ERR(double, XDE_NORM_RMS);
+    else LAUNCH_ERR(double, XDE_NORM_LINF);
+  }
+#undef LAUNCH_ERR
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_scaled_norm_partial(const void* av, const void* bv, const void* y0, double rtol, double atol,
+                            const xde_segments_t* segs, int norm_kind, int dtype, void* ws, int slot, void* stream) {
+  if (!av || !y0 || !ws || !segs) return fail(XDE_EBADARG, "xde_scaled_norm_partial: null pointer");
+  if (slot < 0 || slot >= kSlots) return fail(XDE_EBADARG, "xde_scaled_norm_partial: bad slot");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_scaled_norm_partial: bad dtype");
+  if (norm_kind != XDE_NORM_RMS && norm_kind != XDE_NORM_LINF) return fail(XDE_EBADARG, "xde_scaled_norm_partial: bad norm");
+  ScaledArgs s;
+  memset(&s, 0, sizeof(s));
+  s.a = av;
+  s.b = bv;
+  s.y0 = y0;
+  s.rtol = rtol;
+  s.atol = atol;
+  s.slot = slot_ptr(ws, slot);
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  bool vec = aligned16(av) && aligned16(y0) && (!bv || aligned16(bv)) && segs_vec_ok(segs, width);
+  int nblocks = 0;
+  int rc = build_segmap(segs, vec ? width : 1, vec, &s.map, &nblocks);
+  if (rc != XDE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double total = 0;
+  for (int i = 0; i < segs->n_seg; ++i) total += double(segs->seg_len[i]);
+  ProfScope prof(XDE_KID_SCALEDNORM, st, (bv ? 3.0 : 2.0) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 g(nblocks), b(kBlock);
+#define LAUNCH_SC(T, NORM, DIFF)                                                          \
+  do {                                                                                    \
+    if (vec)                                                                              \
+      hipLaunchKernelGGL((xde_scalednorm_kernel<T, NORM, true, DIFF>), g, b, 0, st, s);   \
+    else                                                                                  \
+      hipLaunchKernelGGL((xde_scalednorm_kernel<T, NORM, false, DIFF>), g, b, 0, st, s);  \
+  } while (0)
+#define LAUNCH_SC2(T, NORM)              \
+  do {                                   \
+    if (bv) LAUNCH_SC(T, NORM, true);    \
+    else LAUNCH_SC(T, NORM, false);      \
+  } while (0)
+  if (dtype == XDE_F32) {
+    if (norm_kind == XDE_NORM_RMS) LAUNCH_SC2(float, XDE_NORM_RMS);
+    else LAUNCH_SC2(float, XDE_NORM_LINF);
+  } else {
+    if (norm_kind == XDE_NORM_RMS) LAUNCH_SC2(double, XDE_NORM_RMS);
+    else LAUNCH_SC2(double, XDE_NORM_LINF);
+  }
+#undef LAUNCH_SC2
+#undef LAUNCH_SC
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_norm_finalize(const void* ws, int slot, double* sums_out, void* stream) {
+  if (!ws || !sums_out) return fail(XDE_EBADARG, "xde_norm_finalize: null pointer");
+  if (slot < 0 || slot >= kSlots) return fail(XDE_EBADARG, "xde_norm_finalize: bad slot");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_FINALIZE, st, 0.0);
+  hipLaunchKernelGGL(xde_finalize_kernel, dim3(1), dim3(kBlock), 0, st, slot_ptr(ws, slot), sums_out);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_norm_result(const double* sums, const double* seg_count, int n_seg, int norm_kind, int state_dtype,
+                    double* result_out, void* stream) {
+  if (!sums || !seg_count || !result_out) return fail(XDE_EBADARG, "xde_norm_result: null pointer");
+  if (n_seg < 1 || n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, "xde_norm_result: n_seg out of range");
+  SegCounts p;
+  memset(&p, 0, sizeof(p));
+  for (int s = 0; s < n_seg; ++s) p.c[s] = seg_count[s];
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(xde_norm_result_kernel, dim3(1), dim3(64), 0, st, sums, p, n_seg, norm_kind, state_dtype, result_out);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+static int check_params(const xde_ctrl_params_t* p, const char* who) {
+  if (!p) return fail(XDE_EBADARG, std::string(who) + ": null params");
+  if (p->n_stage < 1 || p->n_stage > XDE_MAX_STAGE) return fail(XDE_EBADARG, std::string(who) + ": n_stage out of range");
+  if (p->n_seg < 1 || p->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, std::string(who) + ": n_seg out of range");
+  if (p->direction != 1 && p->direction != -1) return fail(XDE_EBADARG, std::string(who) + ": direction must be +-1");
+  if (p->time_dtype != XDE_F32 && p->time_dtype != XDE_F64) return fail(XDE_EBADARG, std::string(who) + ": bad time_dtype");
+  if (p->state_dtype != XDE_F32 && p->state_dtype != XDE_F64) return fail(XDE_EBADARG, std::string(who) + ": bad state_dtype");
+  if (!(p->order > 0)) return fail(XDE_EBADARG, std::string(who) + ": order must be positive");
+  return XDE_OK;
+}
+
+int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void* ws, const double* sums,
+                   const double* t_span_dev, const double* step_t_dev, void* t_stage_out, void* stream) {
+  if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_rk_control: null pointer");
+  if (!ws && !sums) return fail(XDE_EBADARG, "xde_rk_control: need ws or sums");
+  int rc = check_params(params, "xde_rk_control");
+  if (rc != XDE_OK) return rc;
+  if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_rk_control: n_step_t > 0 without step_t_dev");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_CONTROL, st, 0.0);
+  hipLaunchKernelGGL(xde_control_kernel, dim3(1), dim3(kBlock), 0, st, ctrl, *params,
+                     ws ? slot_ptr(ws, 0) : nullptr, sums, t_span_dev, step_t_dev, t_stage_out);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_start, double first_step, int32_t n_out,
+                  const double* t_span_dev, const double* step_t_dev, void* t_stage_out, void* stream) {
+  if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_ctrl_init: null pointer");
+  int rc = check_params(params, "xde_ctrl_init");
+  if (rc != XDE_OK) return rc;
+  if (n_out < 1) return fail(XDE_EBADARG, "xde_ctrl_init: n_out must be >= 1");
+  if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_ctrl_init: n_step_t > 0 without step_t_dev");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(xde_ctrl_init_kernel, dim3(1), dim3(64), 0, st, ctrl, *params, t_start, first_step, n_out,
+                     t_span_dev, step_t_dev, t_stage_out);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream) {
+  if (!ctrl_dev || !host_out) return fail(XDE_EBADARG, "xde_ctrl_read: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(host_out, ctrl_dev, sizeof(xde_ctrl_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return XDE_OK;
+}
+
+int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, const double* mid, int nk, const void* y0,
+                   const void* y0_alt, const void* y1, const void* f1, const xde_ctrl_t* ctrl, const double* t_span_dev,
+                   int time_dtype, int64_t n, int dtype, int64_t expect_step, void* stream) {
+  if (!out_base || !k || !mid || !y0 || !y1 || !f1 || !ctrl || !t_span_dev) return fail(XDE_EBADARG, "xde_dense_eval: null pointer");
+  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_dense_eval: nk out of range");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_dense_eval: bad dtype");
+  if (time_dtype != XDE_F32 && time_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_dense_eval: bad time_dtype");
+  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_dense_eval: y0_alt/k0_alt must come together");
+  if (n < 0) return fail(XDE_EBADARG, "xde_dense_eval: negative n");
+  if (n == 0) return XDE_OK;
+  DenseArgs a;
+  memset(&a, 0, sizeof(a));
+  a.out_base = out_base;
+  a.y0[0] = y0;
+  a.y0[1] = y0_alt ? y0_alt : y0;
+  a.k0_alt = k0_alt ? k0_alt : k[0];
+  a.use_sel = y0_alt ? 1 : 0;
+  a.y1 = y1;
+  a.f1 = f1;
+  a.ctrl = ctrl;
+  a.t_span = t_span_dev;
+  a.n = n;
+  a.nk = nk;
+  a.time_dtype = time_dtype;
+  a.expect_step = expect_step;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  // every output row starts at out_base + r*n elements: rows stay 16-byte aligned only if n % width == 0
+  bool vec = aligned16(out_base) && (n % width == 0) && aligned16(y0) && aligned16(a.y0[1]) && aligned16(y1) &&
+             aligned16(f1) && aligned16(a.k0_alt);
+  for (int j = 0; j < nk; ++j) {
+    if (!k[j]) return fail(XDE_EBADARG, "xde_dense_eval: null k[j]");
+    a.k[j] = k[j];
+    a.mid[j] = mid[j];
+    vec = vec && aligned16(k[j]);
+  }
+  const int64_t work = vec ? (n + width - 1) / width : n;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_DENSE, st, double(nk + 4) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+#define LAUNCH_DENSE(T, TT)                                                     \
+  do {                                                                          \
+    if (vec)                                                                    \
+      hipLaunchKernelGGL((xde_dense_kernel<T, TT, true>), g, b, 0, st, a);      \
+    else                                                                        \
+      hipLaunchKernelGGL((xde_dense_kernel<T, TT, false>), g, b, 0, st, a);     \
+  } while (0)
+  if (dtype == XDE_F32) {
+    if (time_dtype == XDE_F32) LAUNCH_DENSE(float, float);
+    else LAUNCH_DENSE(float, double);
+  } else {
+    if (time_dtype == XDE_F32) LAUNCH_DENSE(double, float);
+    else LAUNCH_DENSE(double, double);
+  }
+#undef LAUNCH_DENSE
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  if (on) {
+    for (int i = 0; i < XDE_KID_COUNT; ++i) {
+      g_prof_bytes[i] = 0;
+      g_prof_counts[i] = 0;
+      g_prof_ms[i] = 0;
+    }
+    for (auto& r : g_prof_recs) {
+      g_event_pool.push_back(r.start);
+      g_event_pool.push_back(r.stop);
+    }
+    g_prof_recs.clear();
+  }
+  return XDE_OK;
+}
+
+int xde_prof_collect(int64_t* counts_out, double* ms_out, double* bytes_out) {
+  if (!counts_out || !ms_out || !bytes_out) return fail(XDE_EBADARG, "xde_prof_collect: null pointer");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) {
+    HIP_TRY(hipEventSynchronize(r.stop));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+    g_prof_counts[r.kid] += 1;
+    g_prof_ms[r.kid] += double(ms);
+    g_event_pool.push_back(r.start);
+    g_event_pool.push_back(r.stop);
+  }
+  g_prof_recs.clear();
+  for (int i = 0; i < XDE_KID_COUNT; ++i) {
+    counts_out[i] = g_prof_counts[i];
+    ms_out[i] = g_prof_ms[i];
+    bytes_out[i] = g_prof_bytes[i];
+  }
+  return XDE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""``odeint`` — forward entry point (reference: paddlexde/functional/odeint.py:9-35).
+
+Same signature, defaults and output layouts as the reference (fixed solvers: time concatenated on
+axis -2; adaptive solvers: ``[T, *y0.shape]`` — SURVEY D3).  ``xde.format`` is the identity (D1).
+A tuple/list ``y0`` is flattened into one padded buffer, integrated, and unflattened time-first
+(the torchdiffeq behaviour the reference's commented-out code intended).
+"""
+from typing import Union
+
+import torch
+
+from ..solver.base_fixed_solver import FixedSolver
+from ..utils.ode_utils import _rms_norm
+from ..xde import BaseODE
+
+
+def odeint(
+    func: callable,
+    y0: Union[tuple, torch.Tensor],
+    t_span,
+    solver,
+    *,
+    rtol=1e-7,
+    atol=1e-9,
+    options: object = {"norm": _rms_norm},
+):
+    """Integrate ``dy/dt = func(t, y), y(t[0]) = y0`` and return y at every ``t_span`` point."""
+    if not torch.is_tensor(t_span):
+        t_span = torch.as_tensor(t_span)
+    if isinstance(y0, (tuple, list)):
+        return _odeint_tuple(func, tuple(y0), t_span, solver, rtol=rtol, atol=atol, options=options)
+
+    xde = BaseODE(func, y0=y0, t_span=t_span)
+
+    s = solver(xde=xde, y0=xde.y0, rtol=rtol, atol=atol, **options)
+    solution = s.integrate(t_span)
+
+    solution = xde.format(solution)
+
+    return solution
+
+
+def _segment_layout(tensors):
+    """Element offsets of each tensor in the flat buffer; every segment starts 16-byte aligned."""
+    dtype = tensors[0].dtype
+    for x in tensors:
+        if x.dtype != dtype:
+            dtype = torch.promote_types(dtype, x.dtype)
+    width = 16 // torch.empty((), dtype=dtype).element_size()
+    segs, off = [], 0
+    for x in tensors:
+        n = x.numel()
+        segs.append((off, n))
+        off += -(-max(n, 1) // width) * width
+    return dtype, segs, off
+
+
+def _pack(tensors, segs, total, dtype, device):
+    flat = torch.zeros(total, dtype=dtype, device=device)
+    for x, (s, n) in zip(tensors, segs):
+        if n:
+            flat[s : s + n].copy_(x.reshape(-1))
+    return flat
+
+
+def _odeint_tuple(func, y0, t_span, solver, *, rtol, atol, options):
+    shapes = [tuple(x.shape) for x in y0]
+    dtype, segs, total = _segment_layout(y0)
+    device = y0[0].device
+    flat0 = _pack(y0, segs, total, dtype, device)
+    fixed = isinstance(solver, type) and issubclass(solver, FixedSolver)
+
+    def unpack(flat):
+        return tuple(flat[s : s + n].view(shape) for (s, n), shape in zip(segs, shapes))
+
+    if fixed:
+        # fixed solvers stack time on axis -2: a [1, total] state gives a time-first [T, total] result
+        def flat_func(t, y):
+            return _pack(func(t, unpack(y[0])), segs, total, dtype, device)[None, :]
+
+        y_in = flat0[None, :]
+        opts = options
+    else:
+        def flat_func(t, y):
+            return _pack(func(t, unpack(y)), segs, total, dtype, device)
+
+        y_in = flat0
+        opts = dict(options)
+        opts["_xde_segments"] = segs
+
+    xde = BaseODE(flat_func, y0=y_in, t_span=t_span)
+    s = solver(xde=xde, y0=xde.y0, rtol=rtol, atol=atol, **opts)
+    sol = s.integrate(t_span)  # [T, total]
+    T = sol.shape[0]
+    return tuple(sol[:, st : st + n].reshape((T,) + shape) for (st, n), shape in zip(segs, shapes))

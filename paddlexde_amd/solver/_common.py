@@ -1,0 +1,41 @@
+"""Host-side helpers shared by the solvers: operand hygiene and time tables."""
+import numpy as np
+import torch
+
+_NP = {torch.float32: np.float32, torch.float64: np.float64}
+
+
+def np_dtype(dt):
+    try:
+        return _NP[dt]
+    except KeyError:
+        raise TypeError("paddlexde_amd supports float32 / float64, got {}".format(dt))
+
+
+def as_operand(x, like=None):
+    """Contiguous, 16-byte aligned tensor the kernels can consume (clone only when needed)."""
+    if like is not None:
+        if x.dtype != like.dtype:
+            x = x.to(like.dtype)
+        if x.shape != like.shape:
+            x = x.expand_as(like)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if x.data_ptr() % 16:
+        y = torch.empty_like(x)
+        y.copy_(x)
+        x = y
+    return x
+
+
+def storage_ptr(x):
+    return x.untyped_storage().data_ptr()
+
+
+def t_span_to_host(t_span, np_time_dtype):
+    """One device->host copy of the output times (the only place a device t_span is read)."""
+    if torch.is_tensor(t_span):
+        arr = t_span.detach().to("cpu").numpy()
+    else:
+        arr = np.asarray(t_span)
+    return arr.astype(np_time_dtype)

@@ -1,0 +1,82 @@
+"""Adaptive-step solver base: output loop and initial-step heuristic.
+
+Reference: paddlexde/solver/base_adaptive_solver.py:6-72.  ``integrate`` keeps the reference's contract
+(``solution[T, *y0.shape]``, ``solution[0] = y0``, ``t_span.astype(dtype)``); the norms inside
+``select_initial_step`` (``norm(y0/scale)``, ``norm(f0/scale)``, ``norm((f1-f0)/scale)``, :50-64) are
+xde_scaled_norm_partial launches, the Euler probe ``y0 + h0*f0`` (:59) is one xde_stage_combine.
+"""
+import abc
+
+import numpy as np
+import torch
+
+from .. import _hip
+from ._common import as_operand, np_dtype, t_span_to_host
+
+
+class AdaptiveSolver(metaclass=abc.ABCMeta):
+    def __init__(self, xde, dtype, y0, norm, **unused_kwargs):
+        self.dtype = dtype
+        self.y0 = y0
+        self.norm = norm
+
+        self.xde = xde
+        self.move = self.xde.move
+        self.fuse = self.xde.fuse
+
+    @abc.abstractmethod
+    def _before_integrate(self, t_span):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def step(self, next_t):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def _run(self, solution):
+        raise NotImplementedError
+
+    def integrate(self, t_span):
+        """base_adaptive_solver.py:24-31.  The per-output ``step(t_span[i])`` loop of the reference is
+        driven by the device controller (ctrl.next_out) inside ``_run``."""
+        y0 = self.y0
+        self.backend.require_device(y0)
+        self.y0 = y0 = as_operand(y0.detach())
+        t_host = t_span_to_host(t_span, np_dtype(self.dtype))  # t_span.astype(self.dtype)
+        solution = torch.empty((len(t_host),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+        solution[0] = y0
+        if len(t_host) < 2:
+            return solution
+        self._before_integrate(t_host)
+        self._run(solution)
+        return solution
+
+    # base_adaptive_solver.py:33-72
+    def select_initial_step(self, t0, y0, order, rtol, atol, f0=None):
+        """Hairer's initial-step heuristic.  Host arithmetic is done in the state dtype with the
+        reference's op order; the three norms are device reductions (one 3-scalar read in total)."""
+        be = self.backend
+        yt = np_dtype(y0.dtype)
+        tt = np_dtype(self.dtype)
+        t0h = tt(t0)
+        if f0 is None:
+            f0 = self._eval(self._scalar_t(t0h, self.dtype), y0)
+        d = self._scaled_norms([(y0, None), (f0, None)], y0, rtol, atol)
+        d0, d1 = yt(abs(d[0])), yt(abs(d[1]))
+        if d0 < 1e-5 or d1 < 1e-5:
+            h0 = yt(1e-6)
+        else:
+            h0 = 0.01 * d0 / d1
+        h0 = abs(h0)
+        y1 = torch.empty_like(y0)
+        be.stage_combine(y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, dt_host=float(h0))  # fuse(f0, h0, y0)
+        f1 = self._eval(self._scalar_t(t0h + h0, torch.promote_types(self.dtype, y0.dtype)), y1)
+        (n2,) = self._scaled_norms([(f1, f0)], y0, rtol, atol)
+        with np.errstate(all="ignore"):
+            d2 = abs(yt(n2) / h0)
+            if d1 <= 1e-15 and d2 <= 1e-15:
+                h1 = max(yt(1e-6), h0 * 1e-3)
+            else:
+                h1 = (0.01 / max(d1, d2)) ** (1.0 / float(order + 1))
+            h1 = abs(h1)
+            return tt(np.fmin(100.0 * h0, h1))

@@ -1,0 +1,194 @@
+"""Fixed-grid solvers on the HIP combine kernel.
+
+Reference: paddlexde/solver/base_fixed_solver.py:14-197.  The loop structure, the ``step`` protocol
+``(t0, t1, y0) -> (y1, dy0)``, the option names and the output layout (``concat(axis=-2)``,
+SURVEY D3) are the reference's; every ``fuse`` (``dy * dt + y0``, xde/base_ode.py:58) and every
+stage formula is one xde_stage_combine launch instead of 2-9 eager element-wise ops.
+
+Times: the reference slices ``time_grid[i-1:i]`` (shape ``[1]`` tensors) and derives stage times with
+eager ops.  Here the whole table of stage times is computed once on the host, in the time dtype and
+with the reference's op order, and uploaded once; ``func`` receives shape-``[1]`` device views of it.
+"""
+import abc
+
+import numpy as np
+import torch
+
+from .. import _hip
+from ..xde.base_ode import BaseODE
+from ._common import as_operand, np_dtype, storage_ptr, t_span_to_host
+
+_one_third = 1 / 3
+_two_thirds = 2 / 3
+_one_sixth = 1 / 6
+
+
+class FixedSolver(metaclass=abc.ABCMeta):
+    order: int
+
+    def __init__(self, xde, y0, step_size=None, grid_constructor=None, interp="linear", perturb=False, **kwargs):
+        self.xde = xde
+        self.y0 = y0
+        self.dtype = y0.dtype
+        self.step_size = step_size
+        self.interp = interp
+        self.perturb = perturb
+
+        # base_fixed_solver.py:45-47 — KeyError when absent, as in the reference
+        self.atol = kwargs["atol"]
+        self.rtol = kwargs["rtol"]
+        self.norm = kwargs["norm"]
+
+        if step_size is not None and grid_constructor is not None:
+            raise ValueError("step_size and grid_constructor are mutually exclusive arguments.")
+        if step_size is not None or grid_constructor is not None:
+            # In the reference the loop walks only len(t_span) grid points whatever the grid is
+            # (base_fixed_solver.py:126-127), so sub-stepping never worked.
+            raise NotImplementedError("step_size / grid_constructor sub-stepping is broken in the reference (SURVEY D7)")
+        self.grid_constructor = lambda y0, t: t
+
+        self.move = self.xde.move
+        self.fuse = self.xde.fuse
+        self.on_integrate_step_end = self.xde.on_integrate_step_end
+        if getattr(type(xde), "fuse", None) is not BaseODE.fuse:
+            raise NotImplementedError("only BaseODE.fuse (dy * dt + y0) is mapped onto the HIP combine kernel")
+
+        self.backend = _hip.get_backend()
+        self.nfe = 0
+        self._dt = None  # host dt (numpy scalar of the time dtype) while integrate() drives step()
+        self._row = None  # current row of the uploaded time table
+        self._y1_out = None  # where the step's final combine should write (a slice of the output)
+        self._tdev_cache = {}
+
+    # -- framework call -----------------------------------------------------------------------
+    def _f(self, t, dt, y):
+        self.nfe += 1
+        f = self.move(t, dt, y)
+        f = as_operand(f, like=y)
+        if storage_ptr(f) == storage_ptr(y):
+            f = f.clone()
+        return f
+
+    def _combine(self, y0, ks, coef, mode, dt, scale=1.0, out=None):
+        if out is None:
+            out = torch.empty_like(y0)
+        self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, dt_host=float(dt))
+        return out
+
+    # -- time handling ----------------------------------------------------------------------------
+    def _host_dt(self, t0, t1):
+        if self._dt is not None:
+            return self._dt
+        return np_dtype(t0.dtype)((t1 - t0).item())  # direct step() call outside integrate(): one device read
+
+    @staticmethod
+    def _time_values(dt):
+        """Host scalars (time dtype) the step hands to ``move`` besides t0/t1, in the order ``_times`` returns them."""
+        return ()
+
+    def _times(self, t0, dt):
+        vals = self._time_values(dt)
+        if self._row is not None:
+            return [self._row[j : j + 1] for j in range(len(vals))]
+        return [self._tdev(v, t0) for v in vals]
+
+    def _tdev(self, value, like):
+        key = (float(value), like.dtype)
+        t = self._tdev_cache.get(key)
+        if t is None:
+            t = torch.tensor([float(value)], dtype=like.dtype, device=like.device)
+            if len(self._tdev_cache) < 1024:
+                self._tdev_cache[key] = t
+        return t
+
+    @abc.abstractmethod
+    def step(self, t0, t1, y0):
+        """Propose a step from t0 to t1. Returns (y1, dy0)."""
+        raise NotImplementedError
+
+    # -- base_fixed_solver.py:103-144 ------------------------------------------------------------
+    def integrate(self, t_span):
+        if not torch.is_tensor(t_span):
+            t_span = torch.as_tensor(t_span)
+        y0 = self.y0
+        self.backend.require_device(y0)
+        if y0.dim() < 2:
+            raise ValueError("fixed solvers concatenate on axis -2: y0 needs >= 2 dims (reference layout [..., L, D])")
+        pred_len = len(t_span)
+        t_dtype = t_span.dtype if t_span.dtype in (torch.float32, torch.float64) else torch.float32
+        t_host = t_span_to_host(t_span, np_dtype(t_dtype))
+        t_dev = t_span.detach().to(device=y0.device, dtype=t_dtype)
+
+        # one upload: per step [t-like values the step passes to move()]
+        rows = []
+        for i in range(1, pred_len):
+            t0h = t_host[i - 1]
+            dt = t_host[i] - t_host[i - 1]
+            rows.append([t0h + v if is_time else v for v, is_time in self._time_values_tagged(dt)])
+        table = None
+        if rows and len(rows[0]):
+            table = torch.from_numpy(np.asarray(rows, dtype=np_dtype(t_dtype))).to(y0.device)
+
+        y0 = as_operand(y0.detach())
+        L, D = y0.shape[-2], y0.shape[-1]
+        lead = y0.shape[:-2]
+        out = torch.empty(*lead, pred_len * L, D, dtype=y0.dtype, device=y0.device)
+        direct = (int(np.prod(lead)) == 1) if len(lead) else True  # output rows are contiguous slices
+        out.narrow(-2, 0, L).copy_(y0)
+
+        try:
+            for i in range(1, pred_len):
+                t0, t1 = t_dev[i - 1 : i], t_dev[i : i + 1]
+                self._dt = t_host[i] - t_host[i - 1]
+                self._row = table[i - 1] if table is not None else None
+                dst = out.narrow(-2, i * L, L)
+                self._y1_out = dst.view(y0.shape) if (direct and dst.data_ptr() % 16 == 0) else None
+                y1, dy0 = self.step(t0, t1, y0)
+                if self.interp == "cubic":
+                    # base_fixed_solver.py:133-137: an extra step(t1, t1, y1) supplies dy1; the Hermite cubic
+                    # evaluated at t == t1 is y1 itself (h00 = h10 = h11 = 0, h01 = 1), so only the NFE matter.
+                    self._dt = t_host[i] - t_host[i]
+                    self._row = None
+                    self._y1_out = None
+                    self.step(t1, t1, y1)
+                # "linear": linear_interp returns y1 when t == t1 (interp_fn.py:7-8); any other value: raw y1
+                if y1.data_ptr() != dst.data_ptr():
+                    dst.copy_(y1)
+                y0 = y1
+        finally:
+            self._dt = None
+            self._row = None
+            self._y1_out = None
+        return out
+
+    def _time_values_tagged(self, dt):
+        """[(value, is_offset_from_t0)] matching ``_time_values``; default: every value is a plain dt-like."""
+        return [(v, False) for v in self._time_values(dt)]
+
+    # -- base_fixed_solver.py:146-164 (classical RK4; unused by the reference's RK4 class) ------------
+    def rk4_step_func(self, t0, t1, y0, f0=None):
+        dt = self._host_dt(t0, t1)
+        half_dt = dt * 0.5
+        dtt, hdt, t_half = self._tdev(dt, t0), self._tdev(half_dt, t0), self._tdev(float(t0.item()) + half_dt, t0)
+        k1 = f0
+        if k1 is None:
+            k1 = self._f(t0, dtt, y0)
+        k2 = self._f(t_half, hdt, self._combine(y0, [k1], [1.0], _hip.COMBINE_FUSE, half_dt))
+        k3 = self._f(t_half, hdt, self._combine(y0, [k2], [1.0], _hip.COMBINE_FUSE, half_dt))
+        k4 = self._f(t1, hdt, self._combine(y0, [k3], [1.0], _hip.COMBINE_FUSE, dt))
+        return self._combine(y0, [k1, k2, k3, k4], [1.0, 2.0, 2.0, 1.0], _hip.COMBINE_WFUSE, dt, scale=_one_sixth,
+                             out=self._y1_out)
+
+    # -- base_fixed_solver.py:166-197 ---------------------------------------------------------------
+    def rk4_alt_step_func(self, t0, t1, y0, f0=None):
+        """The reference's "3/8-rule" variant as written: stage-3 input is ``k1 - k2/3``."""
+        dt = self._host_dt(t0, t1)
+        dtt, d13, t_one_third, t_two_thirds = self._times(t0, dt)
+        k1 = f0
+        if k1 is None:
+            k1 = self._f(t0, dtt, y0)
+        k2 = self._f(t_one_third, d13, self._combine(y0, [k1], [1.0], _hip.COMBINE_FUSE, dt * _one_third))
+        k3 = self._f(t_two_thirds, d13, self._combine(y0, [k1, k2], [1.0, -_one_third], _hip.COMBINE_FUSE, dt))
+        k4 = self._f(t1, t_one_third, self._combine(y0, [k1, k2, k3], [1.0, -1.0, 1.0], _hip.COMBINE_FUSE, dt))
+        return self._combine(y0, [k1, k2, k3, k4], [1.0, 3.0, 3.0, 1.0], _hip.COMBINE_WFUSE, dt, scale=0.125,
+                             out=self._y1_out)

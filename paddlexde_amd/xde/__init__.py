@@ -1,0 +1,2 @@
+from .base_ode import BaseODE  # noqa: F401
+from .base_xde import BaseXDE  # noqa: F401

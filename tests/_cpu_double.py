@@ -1,0 +1,341 @@
+"""TEST DOUBLE of paddlexde_amd._hip.HipBackend on CPU tensors (numpy arithmetic).
+
+Lives in tests/ on purpose: it lets `-m "not gpu"` tests drive the product's HOST logic (stepping loops,
+operand plans, buffer rotation, output bookkeeping, tuple flattening, the adjoint, the process-group
+reduction hook) in a container without a GPU.  It is never importable from the product package and the
+product has no code path that selects it.  Each method states the kernel contract of include/xde_hip.h
+in numpy, in the same op order as csrc/xde_hip.hip.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from paddlexde_amd import _hip
+from paddlexde_amd._hip import XdeCtrl
+
+_NP = {torch.float32: np.float32, torch.float64: np.float64}
+
+
+def _np(t):
+    return t.detach().numpy()
+
+
+class NumpyDoubleBackend:
+    name = "numpy-double(test)"
+
+    def __init__(self):
+        self._slots = {}
+        self.launches = []
+
+    def require_device(self, *tensors):
+        pass
+
+    # -- allocation ---------------------------------------------------------------------------
+    def new_ctrl(self, device):
+        return torch.zeros(C.sizeof(XdeCtrl), dtype=torch.uint8)
+
+    def new_workspace(self, device):
+        return torch.zeros(64, dtype=torch.uint8)
+
+    def new_sums(self, device):
+        return torch.zeros(2 * _hip.XDE_MAX_SEG, dtype=torch.float64)
+
+    @staticmethod
+    def _c(ctrl) -> XdeCtrl:
+        return XdeCtrl.from_buffer(ctrl.numpy())
+
+    # -- K1 -------------------------------------------------------------------------------------
+    def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None):
+        self.launches.append("combine")
+        T = _NP[out.dtype]
+        sel = 0
+        if ctrl is not None:
+            c = self._c(ctrl)
+            dt = T(c.dt)
+            if y0_alt is not None and c.accept:
+                sel = 1
+        else:
+            dt = T(dt_host)
+        y = _np(y0_alt if sel else y0).reshape(-1)
+        kk = [_np(k0_alt if sel else ks[0]).reshape(-1)] + [_np(k).reshape(-1) for k in ks[1:]]
+        o = _np(out).reshape(-1)
+        with np.errstate(all="ignore"):
+            if mode == _hip.COMBINE_RK:
+                cs = [T(c_) * dt for c_ in coef]
+                acc = kk[0] * cs[0]
+                for j in range(1, len(kk)):
+                    acc = acc + kk[j] * cs[j]
+                o[...] = y + acc
+            elif mode == _hip.COMBINE_FUSE:
+                cs = [T(c_) for c_ in coef]
+                acc = kk[0] * cs[0]
+                for j in range(1, len(kk)):
+                    acc = acc + kk[j] * cs[j]
+                o[...] = acc * dt + y
+            else:
+                cs = [T(c_) for c_ in coef]
+                acc = (kk[0] * dt + y) * cs[0]
+                for j in range(1, len(kk)):
+                    acc = acc + (kk[j] * dt + y) * cs[j]
+                o[...] = acc * T(scale)
+
+    # -- K2 -------------------------------------------------------------------------------------
+    @staticmethod
+    def _seg_reduce(r, yv, segs, norm_kind):
+        vals, nfs = [], []
+        for i in range(segs.n_seg):
+            s, l = segs.seg_start[i], segs.seg_len[i]
+            rs = np.abs(r[s : s + l])
+            if norm_kind == _hip.NORM_RMS:
+                vals.append(float(np.sum((rs * rs).astype(np.float64))))
+            else:
+                vals.append(float(rs.max()) if l else 0.0)
+            nfs.append(float(np.count_nonzero(~np.isfinite(yv[s : s + l]))))
+        return vals, nfs
+
+    def error_norm_partial(self, ks, c_err, y0, y1, rtol, atol, segs, norm_kind, ws, *, dt_host=0.0, ctrl=None,
+                           y0_alt=None, k0_alt=None):
+        self.launches.append("errnorm")
+        T = _NP[y0.dtype]
+        sel = 0
+        if ctrl is not None:
+            c = self._c(ctrl)
+            dt = T(c.dt)
+            if y0_alt is not None and c.accept:
+                sel = 1
+        else:
+            dt = T(dt_host)
+        y0v = _np(y0_alt if sel else y0).reshape(-1)
+        y1v = _np(y1).reshape(-1)
+        kk = [_np(k0_alt if sel else ks[0]).reshape(-1)] + [_np(k).reshape(-1) for k in ks[1:]]
+        with np.errstate(all="ignore"):
+            cs = [dt * T(c_) for c_ in c_err]
+            e = kk[0] * cs[0]
+            for j in range(1, len(kk)):
+                e = e + kk[j] * cs[j]
+            tol = T(atol) + T(rtol) * np.fmax(np.abs(y0v), np.abs(y1v))
+            r = e / tol
+        self._slots[0] = self._seg_reduce(r, y0v, segs, norm_kind) + (norm_kind, segs.n_seg)
+
+    def scaled_norm_partial(self, a, b, y0, rtol, atol, segs, norm_kind, ws, slot):
+        self.launches.append("scalednorm")
+        T = _NP[y0.dtype]
+        yv = _np(y0).reshape(-1)
+        av = _np(a).reshape(-1)
+        with np.errstate(all="ignore"):
+            scale = T(atol) + np.abs(yv) * T(rtol)
+            num = av - _np(b).reshape(-1) if b is not None else av
+            r = num / scale
+        self._slots[slot] = self._seg_reduce(r, yv, segs, norm_kind) + (norm_kind, segs.n_seg)
+
+    def norm_finalize(self, ws, slot, sums):
+        self.launches.append("finalize")
+        vals, nfs, _, n_seg = self._slots[slot]
+        s = sums.numpy()
+        s[:] = 0.0
+        s[:n_seg] = vals
+        s[_hip.XDE_MAX_SEG : _hip.XDE_MAX_SEG + n_seg] = nfs
+
+    @staticmethod
+    def _norm_from_sums(vals, counts, norm_kind, state_dtype):
+        rnd = (lambda x: float(np.float32(x))) if state_dtype == _hip.XDE_F32 else float
+        ratio, per = 0.0, []
+        with np.errstate(all="ignore"):
+            for i, (v, n) in enumerate(zip(vals, counts)):
+                if norm_kind == _hip.NORM_RMS:
+                    r = rnd(np.sqrt(rnd(np.float64(v) / np.float64(n))))
+                else:
+                    r = rnd(v)
+                r = abs(r)
+                per.append(r)
+                if i == 0:
+                    ratio = r
+                else:
+                    ratio = ratio if ratio != ratio else (r if r != r else max(ratio, r))
+        return ratio, per
+
+    def norm_result(self, sums, seg_count, norm_kind, state_dtype, result):
+        s = sums.numpy()
+        ratio, _ = self._norm_from_sums(list(s[: len(seg_count)]), seg_count, norm_kind, state_dtype)
+        result.numpy()[0] = ratio
+
+    # -- K3 -------------------------------------------------------------------------------------
+    @staticmethod
+    def _plan_next(c, p, step_t, t_stage):
+        TT = np.float32 if p.time_dtype == _hip.XDE_F32 else np.float64
+        d = TT(p.direction)
+        t0, dt = TT(c.t1), TT(c.dt)
+        with np.errstate(all="ignore"):
+            t1 = t0 + dt
+            on = 0
+            if p.n_step_t > 0 and step_t is not None:
+                nxt = TT(step_t[c.next_step_index])
+                if d * t0 < d * nxt < d * (t0 + dt):
+                    on, t1 = 1, nxt
+                    dt = t1 - t0
+            c.on_step_t = on
+            c.dt = float(dt)
+            c.t_plan = float(t1)
+            if not c.done:
+                if not (d * (t0 + dt) > d * t0) and c.status == 0:
+                    c.status = _hip.STATUS_DT_UNDERFLOW
+                if c.steps_in_interval >= p.max_num_steps and c.status == 0:
+                    c.status = _hip.STATUS_MAX_STEPS
+            Y = np.float32 if p.state_dtype == _hip.XDE_F32 else np.float64
+            ts = t_stage.numpy()
+            for i in range(p.n_stage):
+                a = Y(p.alpha[i])
+                ts[i] = Y(t1) if a == 1.0 else Y(t0) + a * Y(dt)
+
+    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage):
+        c = self._c(ctrl)
+        C.memset(C.addressof(c), 0, C.sizeof(c))
+        c.t0 = c.t1 = float(t_start)
+        c.dt = float(first_step)
+        c.n_out = n_out
+        c.ratio_prev = 1e-4
+        d = float(params.direction)
+        ts = t_span_dev.numpy()
+        e = 1
+        while e < n_out and d * ts[e] <= d * t_start:
+            e += 1
+        c.next_out = c.out_begin = c.out_end = e
+        c.done = 1 if e >= n_out else 0
+        idx = 0
+        if params.n_step_t > 0 and step_t_dev is not None:
+            st = step_t_dev.numpy()
+            while idx < params.n_step_t and d * st[idx] <= d * t_start:
+                idx += 1
+            idx = min(idx, params.n_step_t - 1)
+        c.next_step_index = idx
+        self._plan_next(c, params, None if step_t_dev is None else step_t_dev.numpy(), t_stage)
+
+    def rk_control(self, ctrl, params, ws, sums, t_span_dev, step_t_dev, t_stage):
+        self.launches.append("control")
+        c, p = self._c(ctrl), params
+        if c.done:
+            return
+        if sums is not None:
+            s = sums.numpy()
+            vals, nfs = list(s[: p.n_seg]), list(s[_hip.XDE_MAX_SEG : _hip.XDE_MAX_SEG + p.n_seg])
+        else:
+            vals, nfs, _, _ = self._slots[0]
+        counts = [p.seg_count[i] for i in range(p.n_seg)]
+        ratio, per = self._norm_from_sums(vals, counts, p.norm_kind, p.state_dtype)
+        for i, r in enumerate(per):
+            c.ratio_seg[i] = r
+        nonfinite = float(sum(nfs))
+        TT = np.float32 if p.time_dtype == _hip.XDE_F32 else np.float64
+        d = TT(p.direction)
+        t0, dt, t1 = TT(c.t1), TT(c.dt), TT(c.t_plan)
+        min_step, max_step = TT(p.min_step), TT(p.max_step)
+        if nonfinite > 0 and c.status == 0:
+            c.status = _hip.STATUS_NONFINITE
+        accept = 1 if ratio <= 1.0 else 0
+        if d * dt > max_step:
+            accept = 0
+        if d * dt <= min_step:
+            accept = 1
+        with np.errstate(all="ignore"):
+            if ratio == 0.0:
+                dt_next = dt * TT(p.ifactor)
+            else:
+                dfactor = TT(1) if ratio < 1.0 else TT(p.dfactor)
+                r = TT(ratio)
+                if p.pi_controller:
+                    beta = TT(p.pi_beta)
+                    alpha = TT(1) / TT(p.order) - TT(0.75) * beta
+                    prev = TT(max(c.ratio_prev, 1e-4))
+                    factor = np.fmin(TT(p.ifactor), np.fmax(TT(p.safety) * prev**beta / r**alpha, dfactor))
+                else:
+                    exponent = TT(1) / TT(p.order)
+                    factor = np.fmin(TT(p.ifactor), np.fmax(TT(p.safety) / r**exponent, dfactor))
+                dt_next = dt * TT(factor)
+            mag = d * dt_next
+            if mag == mag:
+                mag = min(max(mag, min_step), max_step)
+                dt_next = d * mag
+        c.n_steps += 1
+        c.steps_in_interval += 1
+        if accept:
+            c.n_accept += 1
+            if ratio == ratio:
+                c.ratio_prev = ratio
+        else:
+            c.n_reject += 1
+        c.sel_used = c.accept
+        c.accept = accept
+        c.ratio = ratio
+        c.nonfinite = nonfinite
+        c.t0 = float(t0)
+        c.t1 = float(t1) if accept else float(t0)
+        c.dt_last = float(dt)
+        c.dt = float(dt_next)
+        ts = t_span_dev.numpy()
+        b = e = c.next_out
+        if accept:
+            while e < c.n_out and d * TT(ts[e]) <= d * t1:
+                e += 1
+        c.out_begin, c.out_end, c.next_out = b, e, e
+        if e > b:
+            c.steps_in_interval = 0
+        c.done = 1 if e >= c.n_out else 0
+        if accept and c.on_step_t and c.next_step_index != p.n_step_t - 1:
+            c.next_step_index += 1
+        self._plan_next(c, p, None if step_t_dev is None else step_t_dev.numpy(), t_stage)
+
+    def ctrl_read(self, ctrl) -> XdeCtrl:
+        return XdeCtrl.from_buffer_copy(ctrl.numpy().tobytes())
+
+    def ctrl_read_async(self, ctrl):
+        return self.ctrl_read(ctrl)
+
+    def ctrl_wait(self, handle):
+        return handle
+
+    # -- K4 -------------------------------------------------------------------------------------
+    def dense_eval(self, out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype, *, y0_alt=None, k0_alt=None,
+                   expect_step=-1):
+        self.launches.append("dense")
+        c = self._c(ctrl)
+        if not c.accept or c.out_end <= c.out_begin:
+            return
+        if expect_step >= 0 and c.n_steps != expect_step:
+            return
+        T = _NP[y0.dtype]
+        TT = np.float32 if time_dtype == _hip.XDE_F32 else np.float64
+        sel = 1 if (y0_alt is not None and c.sel_used) else 0
+        y0v = _np(y0_alt if sel else y0).reshape(-1)
+        f0v = _np(k0_alt if sel else ks[0]).reshape(-1)
+        y1v, f1v = _np(y1).reshape(-1), _np(f1).reshape(-1)
+        kk = [f0v] + [_np(k).reshape(-1) for k in ks[1:]]
+        dt = T(TT(c.dt_last))
+        acc = kk[0] * (dt * T(mid[0]))
+        for j in range(1, len(kk)):
+            acc = acc + kk[j] * (dt * T(mid[j]))
+        ymid = y0v + acc
+        t0, t1 = TT(c.t0), TT(c.t1)
+        ts = t_span_dev.numpy()
+        out = _np(out_base).reshape(out_base.shape[0], -1)
+        two, five, three, four = T(2), T(5), T(3), T(4)
+        ca = two * dt * (f1v - f0v) - T(8) * (y1v + y0v) + T(16) * ymid
+        cb = dt * (five * f0v - three * f1v) + T(18) * y0v + T(14) * y1v - T(32) * ymid
+        cc = dt * (f1v - four * f0v) - T(11) * y0v - T(5) * y1v + T(16) * ymid
+        cd = dt * f0v
+        for r in range(c.out_begin, c.out_end):
+            x = T((TT(ts[r]) - t0) / (t1 - t0))
+            total = y0v + x * cd
+            xp = x * x
+            total = total + xp * cc
+            xp = xp * x
+            total = total + xp * cb
+            xp = xp * x
+            total = total + xp * ca
+            out[r, :] = total
+
+    def prof_enable(self, on=True):
+        pass
+
+    def prof_collect(self):
+        return {}
