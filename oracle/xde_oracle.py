@@ -568,7 +568,9 @@ def odeint(func, y0, t_span, solver, *, rtol=1e-7, atol=1e-9, options=None, retu
         def func(t, y):  # noqa: F811
             return _flatten(user_func(t, _unflatten(y, shapes))).astype(y_dtype)
 
-        if solver in ADAPTIVE:
+        if solver in ADAPTIVE and user_norm not in (_rms_norm, _linf_norm):
+            # tuple-aware norms (the adjoint's mixed norms) receive the unflattened tuple; the plain
+            # tensor norms are taken over the flat state
             options["norm"] = lambda flat: user_norm(_unflatten(flat, shapes))
     else:
         y0 = np.asarray(y0)

@@ -238,6 +238,8 @@ class HipBackend:
     # -- kernels ---------------------------------------------------------------------------
     def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None):
         self._require_device(out, y0, *ks)
+        if out.numel() == 0:
+            return
         rc = self.lib.xde_stage_combine(
             out.data_ptr(), y0.data_ptr(), _ptr(y0_alt), _ptr_array(ks), _ptr(k0_alt), _dbl_array(coef), len(ks),
             mode, float(scale), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype), self._stream(out),
@@ -307,6 +309,8 @@ class HipBackend:
     def dense_eval(self, out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype, *, y0_alt=None, k0_alt=None,
                    expect_step=-1):
         self._require_device(out_base, y0, y1, f1, ctrl, t_span_dev, *ks)
+        if y0.numel() == 0:
+            return
         rc = self.lib.xde_dense_eval(
             out_base.data_ptr(), _ptr_array(ks), _ptr(k0_alt), _dbl_array(mid), len(ks), y0.data_ptr(), _ptr(y0_alt),
             y1.data_ptr(), f1.data_ptr(), ctrl.data_ptr(), t_span_dev.data_ptr(), time_dtype, y0.numel(),

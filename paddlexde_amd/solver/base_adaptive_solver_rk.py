@@ -327,46 +327,87 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self.rk_state = _RungeKuttaState(base[0], base[1], c.t0, c.t1, c.dt, None)
 
     def _run(self, solution):
+        self._solution = solution
+        self._base = (self.rk_state.y1, self.rk_state.f1)
+        self._pending = None  # lag pipeline: (y1, ks, read handle) of the newest, unresolved attempt
+        self._n_attempts = 0
+        self._last = None
+        self.advance(None)
+        self._solution = None
+
+    def advance(self, max_attempts=None):
+        """Run attempted steps until every output is produced (``max_attempts=None``) or exactly
+        ``max_attempts`` attempts were made.  Returns the last control block read from the device.
+
+        Callable after ``_before_integrate`` as a stepping API (bench.py drives it with a fixed count)."""
+        if getattr(self, "_base", None) is None:
+            self._solution = None
+            self._base = (self.rk_state.y1, self.rk_state.f1)
+            self._pending = None
+            self._n_attempts = 0
+            self._last = None
         if self.pipeline == "lag":
-            return self._run_lag(solution)
+            c = self._advance_lag(max_attempts)
+        else:
+            c = self._advance_sync(max_attempts)
+        self._finish(c, self._base)
+        return c
+
+    def _advance_sync(self, max_attempts):
         be = self.backend
-        base = (self.rk_state.y1, self.rk_state.f1)
-        while True:
+        c = self._last
+        done = 0
+        while max_attempts is None or done < max_attempts:
+            base = self._base
             y1, ks = self._attempt(base)
+            self._n_attempts += 1
+            done += 1
             c = be.ctrl_read(self._ctrl)  # the step's one host sync
             if c.accept:
-                if c.out_end > c.out_begin:
-                    self._dense(solution, base, y1, ks)
-                base = (y1, ks[-1])
+                if c.out_end > c.out_begin and self._solution is not None:
+                    self._dense(self._solution, base, y1, ks)
+                self._base = (y1, ks[-1])
             self._raise_status(c)
-            if c.done:
+            if c.done and max_attempts is None:
                 break
-        self._finish(c, base)
+        self._last = c
+        return c
 
-    def _run_lag(self, solution):
+    def _resolve_pending(self):
+        c = self.backend.ctrl_wait(self._pending[2])
+        if c.accept:
+            self._base = (self._pending[0], self._pending[1][-1])
+        self._pending = None
+        self._raise_status(c)
+        return c
+
+    def _advance_lag(self, max_attempts):
         """Speculative pipeline: the host resolves attempt n-1 only after attempt n is enqueued."""
         be = self.backend
-        base = (self.rk_state.y1, self.rk_state.f1)
-        pending = None  # (y1, ks, read handle) of the newest attempt, not yet resolved
-        n = 0
-        while True:
-            alt = (pending[0], pending[1][-1]) if pending is not None else None
+        c = self._last
+        done = 0
+        while max_attempts is None or done < max_attempts:
+            base = self._base
+            alt = (self._pending[0], self._pending[1][-1]) if self._pending is not None else None
             y1, ks = self._attempt(base, alt)
-            n += 1
-            self._dense(solution, base, y1, ks, alt, expect_step=n)
+            self._n_attempts += 1
+            done += 1
+            if self._solution is not None:
+                self._dense(self._solution, base, y1, ks, alt, expect_step=self._n_attempts)
             handle = be.ctrl_read_async(self._ctrl)
-            if pending is not None:
-                c = be.ctrl_wait(pending[2])
-                if c.accept:
-                    base = (pending[0], pending[1][-1])
-                self._raise_status(c)
-                if c.done:
-                    # the attempt just enqueued is a device-side no-op (ctrl->done guards the controller
-                    # and the dense kernel); its func evaluations are the price of never stalling the GPU
+            if self._pending is not None:
+                c = self._resolve_pending()
+                if c.done and max_attempts is None:
+                    # the attempt just enqueued is a device-side no-op (ctrl->done guards the controller and
+                    # the dense kernel); its func evaluations are the price of never stalling the GPU
                     self.nfe -= self._n_stage
-                    break
-            pending = (y1, ks, handle)
-        self._finish(c, base)
+                    self._last = c
+                    return c
+            self._pending = (y1, ks, handle)
+        if self._pending is not None:  # drain: the caller gets a fully resolved state
+            c = self._resolve_pending()
+        self._last = c
+        return c
 
     # base_adaptive_solver_rk.py:116-127 — kept for API parity: advance to `next_t` and interpolate
     def step(self, next_t):

@@ -1,0 +1,334 @@
+"""Parity cases, end to end (collected by test_gpu_odeint.py on the GPU and by test_host_logic.py on the CPU double): paddlexde_amd.odeint / odeint_adjoint (HIP path through the C ABI) against the
+CPU oracle on the same seeded inputs, plus the reference's own analytic acceptance tests and
+size-independent properties at BASELINE.json's full sizes.
+
+Bar (north_star): |got - ref| <= 1e-7 + 1e-5 |ref| for floating point.  Where fp32 round-off in the error
+estimate makes two correct implementations pick step sizes one ulp apart ("accept/reject
+divergence") the test states the slack factor it allows and an fp64 twin of the test holds the tight bar."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import xde_oracle as O
+from paddlexde_amd import RK4, AdaptiveHeun, Bosh3, Dopri5, Euler, Fehlberg2, Midpoint, _hip, odeint, odeint_adjoint
+from paddlexde_amd.utils import _linf_norm, _rms_norm
+
+from . import problems as P
+
+
+FIXED = {"euler": Euler, "midpoint": Midpoint, "rk4": RK4}
+ADAPTIVE = {"dopri5": Dopri5, "bosh3": Bosh3, "fehlberg2": Fehlberg2, "adaptive_heun": AdaptiveHeun}
+
+
+def test_native_library_is_the_one_running(dev):
+    be = _hip.get_backend()
+    if str(dev).startswith("cuda"):
+        assert be.name == "hip" and isinstance(be, _hip.HipBackend)
+    else:
+        assert be.name.startswith("numpy-double")
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's own acceptance tests (tests/functional/test_fixed_solver.py:26-44,
+# tests/functional/test_adaptive_solver.py:32-87): analytic problems at the reference's tolerances
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(FIXED))
+def test_reference_fixed_constant(dev, name):
+    p, y0, t, sol = P.construct_problem("constant")
+    y = odeint(p.f_torch(dev), torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), solver=FIXED[name])
+    assert y.shape == (10, 1)  # concat on axis -2 of y0 [1, 1]
+    assert np.allclose(sol, y.cpu().numpy(), rtol=1e-2, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", list(ADAPTIVE))
+@pytest.mark.parametrize("ode", ["sine", "linear"])
+def test_reference_adaptive(dev, name, ode):
+    p, y0, t, sol = P.construct_problem(ode)
+    y = odeint(p.f_torch(dev), torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), solver=ADAPTIVE[name])
+    assert y.shape == (10,) + y0.shape  # time first
+    rtol = 1e-2 if (name == "adaptive_heun" and ode == "linear") else 4e-3
+    assert np.allclose(sol[:, None, :], y.cpu().numpy(), rtol=rtol, atol=1e-8)
+
+
+# ----------------------------------------------------------------------------------------------
+# config 1: the spiral demo, RK4 (reference variant), batch=1, dim=2 — against the oracle
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(FIXED) )
+def test_spiral_fixed_vs_oracle(dev, name):
+    y0 = np.array([[2.0, 0.0]], dtype=np.float32)
+    t = np.linspace(0.0, 25.0, 1000).astype(np.float32)
+    if name == "euler":  # first-order: needs a finer grid to stay bounded on the cubic spiral
+        t = np.linspace(0.0, 2.0, 400).astype(np.float32)
+    ref = O.odeint(P.spiral_np, y0, t, name)
+    got = odeint(P.spiral_torch, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), solver=FIXED[name])
+    assert got.shape == ref.shape == (len(t), 2)
+    # every kernel is bit-exact and func uses only +,-,*: the whole trajectory is bit-exact
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_fixed_layout_batched(dev):
+    """y0 [B, L, D] -> [B, T*L, D] against the oracle."""
+    rng = np.random.RandomState(0)
+    y0 = rng.uniform(-2, 2, size=(7, 3, 2)).astype(np.float32)
+    t = np.linspace(0.0, 0.2, 9).astype(np.float32)
+    ref = O.odeint(P.spiral_np, y0, t, "rk4")
+    got = odeint(P.spiral_torch, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), solver=RK4)
+    assert got.shape == (7, 27, 2)
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+# ----------------------------------------------------------------------------------------------
+# config 2 at oracle-sized batches: linear ODE, Dopri5, rtol 1e-5 / atol 1e-7
+# ----------------------------------------------------------------------------------------------
+def _linear(B, D, dtype):
+    A = P.skew_matrix(D).to(dtype)
+    y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(0)).to(dtype)
+    return A, y0
+
+
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+@pytest.mark.parametrize("name", list(ADAPTIVE))
+def test_linear_adaptive_vs_oracle_fp64(dev, name, pipeline):
+    """fp64 state and time: step decisions are robust, so the tight bar applies."""
+    A, y0 = _linear(64, 32, torch.float64)
+    t = torch.linspace(0.0, 1.0, 6, dtype=torch.float64)
+    tol = dict(rtol=1e-6, atol=1e-8) if name != "adaptive_heun" else dict(rtol=1e-4, atol=1e-6)
+    An = A.numpy()
+    ref, so = O.odeint(lambda t_, y: y @ An.T, y0.numpy(), t.numpy(), name, options={"norm": O._rms_norm, "dtype": np.float64},
+                       return_solver=True, **tol)
+    Ad = A.to(dev)
+    from paddlexde_amd.xde import BaseODE
+
+    xde = BaseODE(lambda t_, y: y @ Ad.T, y0=y0.to(dev), t_span=t)
+    s = ADAPTIVE[name](xde=xde, y0=xde.y0, norm=_rms_norm, dtype=torch.float64, pipeline=pipeline, **tol)
+    got = s.integrate(t)
+    assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-9, atol=1e-11), P.worst(got.cpu().numpy(), ref, 1e-9, 1e-11)
+    assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == (so.n_accept, so.n_reject, so.nfe)
+
+
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+def test_linear_dopri5_vs_oracle_fp32(dev, pipeline):
+    A, y0 = _linear(512, 128, torch.float32)
+    t = torch.linspace(0.0, 1.0, 11)
+    An = A.numpy()
+    ref, so = O.odeint(lambda t_, y: y @ An.T, y0.numpy(), t.numpy(), "dopri5", rtol=1e-5, atol=1e-7, return_solver=True)
+    Ad = A.to(dev)
+    got = odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t.to(dev), solver=Dopri5, rtol=1e-5, atol=1e-7,
+                 options={"norm": _rms_norm, "pipeline": pipeline})
+    # fp32: two correct implementations differ by an ulp in the error ratio (reduction order), hence in dt, and
+    # fp32 cancellation noise in the error estimate amplifies that to ~1e-6 absolute on O(1) values.  The bar is
+    # therefore taken against the solution's scale: max|diff| <= 1e-5 * max|ref| (north_star: "<=1e-5 relative").
+    assert P.rel_err(got.cpu().numpy(), ref) <= 1e-5, P.rel_err(got.cpu().numpy(), ref)
+
+
+def test_lag_pipeline_is_bitwise_equal_to_sync(dev):
+    A, y0 = _linear(4096, 64, torch.float32)
+    t = torch.linspace(0.0, 2.0, 7).to(dev)
+    Ad = A.to(dev)
+    f = lambda t_, y: y @ Ad.T  # noqa: E731
+    a = odeint(f, y0.to(dev), t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "pipeline": "sync"})
+    b = odeint(f, y0.to(dev), t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "pipeline": "lag"})
+    assert torch.equal(a, b)
+
+
+def test_reverse_time_vs_oracle(dev):
+    A, y0 = _linear(64, 32, torch.float64)
+    t = torch.linspace(1.0, 0.0, 5, dtype=torch.float64)
+    An = A.numpy()
+    ref = O.odeint(lambda t_, y: y @ An.T, y0.numpy(), t.numpy(), "dopri5", rtol=1e-7, atol=1e-9,
+                   options={"norm": O._rms_norm, "dtype": np.float64})
+    Ad = A.to(dev)
+    got = odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, rtol=1e-7, atol=1e-9,
+                 options={"norm": _rms_norm, "dtype": torch.float64})
+    assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
+
+
+def test_linf_norm_and_options(dev):
+    A, y0 = _linear(64, 32, torch.float64)
+    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64)
+    An = A.numpy()
+    opts_o = {"norm": O._linf_norm, "dtype": np.float64, "first_step": 0.01, "max_step": 0.2, "safety": 0.8}
+    ref = O.odeint(lambda t_, y: y @ An.T, y0.numpy(), t.numpy(), "dopri5", rtol=1e-6, atol=1e-8, options=opts_o)
+    Ad = A.to(dev)
+    opts = {"norm": _linf_norm, "dtype": torch.float64, "first_step": 0.01, "max_step": 0.2, "safety": 0.8}
+    got = odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, rtol=1e-6, atol=1e-8, options=opts)
+    assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
+
+
+def test_step_t_option(dev):
+    A, y0 = _linear(16, 8, torch.float64)
+    t = torch.linspace(0.0, 1.0, 3, dtype=torch.float64)
+    An = A.numpy()
+    st = [0.13, 0.61, 0.4]
+    ref, so = O.odeint(lambda t_, y: y @ An.T, y0.numpy(), t.numpy(), "dopri5", rtol=1e-6, atol=1e-8,
+                       options={"norm": O._rms_norm, "dtype": np.float64, "step_t": st}, return_solver=True)
+    Ad = A.to(dev)
+    got = odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, rtol=1e-6, atol=1e-8,
+                 options={"norm": _rms_norm, "dtype": torch.float64, "step_t": st})
+    assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
+
+
+# ----------------------------------------------------------------------------------------------
+# error conventions
+# ----------------------------------------------------------------------------------------------
+def test_assertion_messages(dev):
+    y0 = torch.ones(4, 2, device=dev)
+    t = torch.tensor([0.0, 1.0], device=dev)
+    with pytest.raises(AssertionError, match="max_num_steps exceeded"):
+        odeint(P.vdp_torch(1000.0), y0 * 2, t, solver=Dopri5, rtol=1e-6, atol=1e-8, options={"norm": _rms_norm, "max_num_steps": 5})
+    bad = y0.clone()
+    bad[1, 1] = float("nan")
+    with pytest.raises(AssertionError, match="non-finite values in state"):
+        odeint(lambda t_, y: -y, bad, t, solver=Dopri5, options={"norm": _rms_norm, "first_step": 0.1})
+    # without first_step the NaN reaches dt through select_initial_step and the reference's FIRST assertion fires
+    with pytest.raises(AssertionError, match="underflow in dt nan"):
+        odeint(lambda t_, y: -y, bad, t, solver=Dopri5, options={"norm": _rms_norm})
+    with pytest.raises(AssertionError, match="underflow in dt"):
+        odeint(lambda t_, y: y * float("inf"), y0, t, solver=Dopri5, options={"norm": _rms_norm})
+    with pytest.raises(KeyError):
+        RK4(xde=__import__("paddlexde_amd").BaseODE(lambda t_, y: y, y0=y0, t_span=t), y0=y0)
+    if str(dev).startswith("cuda"):
+        with pytest.raises(_hip.XdeError):
+            odeint(lambda t_, y: -y, torch.ones(4, 2), torch.tensor([0.0, 1.0]), solver=Dopri5)  # CPU tensors: no fallback
+
+
+# ----------------------------------------------------------------------------------------------
+# config 5: stiff Van der Pol, step-rejection stress
+# ----------------------------------------------------------------------------------------------
+def test_vdp_rejections_vs_oracle_fp64(dev):
+    mu = 50.0
+    y0 = np.array([2.0, 0.0]) + 0.01 * np.random.RandomState(0).randn(64, 2)
+    t = np.array([0.0, 1.0])
+    ref, so = O.odeint(P.vdp_np(mu), y0, t, "dopri5", rtol=1e-6, atol=1e-8, options={"norm": O._rms_norm, "dtype": np.float64},
+                       return_solver=True)
+    from paddlexde_amd.xde import BaseODE
+
+    y0t = torch.from_numpy(y0).to(dev)
+    xde = BaseODE(P.vdp_torch(mu), y0=y0t, t_span=torch.from_numpy(t))
+    s = Dopri5(xde=xde, y0=y0t, rtol=1e-6, atol=1e-8, norm=_rms_norm, dtype=torch.float64)
+    got = s.integrate(torch.from_numpy(t))
+    assert so.n_reject > 0
+    assert (s.stats["n_accept"], s.stats["n_reject"]) == (so.n_accept, so.n_reject)
+    assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-8, atol=1e-10), P.worst(got.cpu().numpy(), ref, 1e-8, 1e-10)
+
+
+# ----------------------------------------------------------------------------------------------
+# config 3: neural-ODE adjoint (2-layer MLP on y**3), gradients for 252 params
+# ----------------------------------------------------------------------------------------------
+class ODEFunc(nn.Module):
+    """example/ode_demo.py:17-33: Linear(2,50) -> Tanh -> Linear(50,2) on y**3, weights 0.1*randn, biases 0."""
+
+    def __init__(self, dtype):
+        super().__init__()
+        g = torch.Generator().manual_seed(42)
+        self.W1 = nn.Parameter(0.1 * torch.randn(2, 50, generator=g, dtype=dtype))
+        self.b1 = nn.Parameter(torch.zeros(50, dtype=dtype))
+        self.W2 = nn.Parameter(0.1 * torch.randn(50, 2, generator=g, dtype=dtype))
+        self.b2 = nn.Parameter(torch.zeros(2, dtype=dtype))
+
+    def forward(self, t, y):
+        return torch.tanh((y * y * y) @ self.W1 + self.b1) @ self.W2 + self.b2
+
+
+def _mlp_numpy(m):
+    W1, b1, W2, b2 = [p.detach().cpu().numpy() for p in m.parameters()]
+
+    def fn(t, y):
+        return np.tanh((y * y * y) @ W1 + b1) @ W2 + b2
+
+    def vjp(t, y, cot):
+        u = y * y * y
+        a = np.tanh(u @ W1 + b1)
+        gh = (cot @ W2.T) * (1 - a * a)
+        return (gh @ W1.T) * 3 * y * y, [u.T @ gh, gh.sum(0), a.T @ cot, cot.sum(0)]
+
+    return fn, vjp, [W1, b1, W2, b2]
+
+
+@pytest.mark.parametrize("solver", ["dopri5", "rk4"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_adjoint_gradients_vs_oracle(dev, solver, dtype):
+    m = ODEFunc(dtype)
+    fn, vjp, params = _mlp_numpy(m)
+    m = m.to(dev)
+    y0 = (torch.rand(256, 2, generator=torch.Generator().manual_seed(0), dtype=dtype) * 4 - 2)
+    t = torch.linspace(0.0, 25.0, 1000, dtype=dtype)[:8]
+    tight = dtype == torch.float64
+    tol = dict(rtol=1e-8, atol=1e-10) if tight else dict(rtol=1e-5, atol=1e-7)
+    S = {**FIXED, **ADAPTIVE}[solver]
+    opts = {"norm": _rms_norm}
+    oopts = {"norm": O._rms_norm}
+    if solver == "dopri5":
+        opts["dtype"] = dtype
+        oopts["dtype"] = np.float64 if tight else np.float32
+    y0g = y0.clone().to(dev).requires_grad_(True)
+    sol = odeint_adjoint(m, y0g, t.to(dev), solver=S, options=opts, **tol)
+    loss = sol.abs().mean()
+    loss.backward()
+    ans, bw = O.odeint_adjoint(fn, vjp, params, y0.numpy(), t.numpy(), solver, options=oopts, **tol)
+    gy0, gps = bw(np.sign(ans) / ans.size)
+    bar = 1e-8 if tight else 1e-5  # relative to each tensor's scale (see test_linear_dopri5_vs_oracle_fp32)
+    assert P.rel_err(sol.detach().cpu().numpy(), ans) <= bar
+    assert P.rel_err(y0g.grad.cpu().numpy(), gy0) <= bar, P.rel_err(y0g.grad.cpu().numpy(), gy0)
+    for p_, g_ in zip(m.parameters(), gps):
+        assert P.rel_err(p_.grad.cpu().numpy(), g_) <= bar, P.rel_err(p_.grad.cpu().numpy(), g_)
+
+
+def test_adjoint_argument_validation(dev):
+    y0 = torch.ones(2, 2, device=dev)
+    t = torch.tensor([0.0, 1.0], device=dev)
+    with pytest.raises(ValueError, match="func must be an instance of nn.Module"):
+        odeint_adjoint(lambda t_, y: y, y0, t, solver=Dopri5)
+    m = ODEFunc(torch.float32).to(dev)
+    with pytest.raises(ValueError, match="cannot infer `adjoint_options`"):
+        odeint_adjoint(m, y0, t, solver=Dopri5, adjoint_solver=RK4)
+
+
+def test_tuple_state_vs_oracle(dev):
+    ya = np.random.RandomState(1).randn(5, 3)
+    yb = np.random.RandomState(2).randn(7)
+    t = np.linspace(0.0, 1.0, 4)
+
+    def f_np(t_, y):
+        a, b = y
+        return (-0.5 * a, 0.3 * b + a.sum())
+
+    def f_t(t_, y):
+        a, b = y
+        return (-0.5 * a, 0.3 * b + a.sum())
+
+    ref = O.odeint(f_np, (ya, yb), t, "dopri5", rtol=1e-7, atol=1e-9, options={"norm": O._rms_norm, "dtype": np.float64})
+    got = odeint(f_t, (torch.from_numpy(ya).to(dev), torch.from_numpy(yb).to(dev)), torch.from_numpy(t), solver=Dopri5,
+                 rtol=1e-7, atol=1e-9, options={"norm": _rms_norm, "dtype": torch.float64})
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape
+        assert P.parity_ok(g.cpu().numpy(), r, 1e-9, 1e-11)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle cannot run these in seconds)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_config2_full_size_properties(dev):
+    """batch=65536 x dim=128 Dopri5: (i) rows checked against the exact solution expm(tA) y0, (ii) the flow
+    of a skew-symmetric A is a rotation: row norms are conserved, (iii) forward-then-backward round trip."""
+    import scipy.linalg
+
+    B, D = 65536, 128
+    A = P.skew_matrix(D)
+    y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(0))
+    Ad, y0d = A.to(dev), y0.to(dev)
+    f = lambda t_, y: y @ Ad.T  # noqa: E731
+    t = torch.tensor([0.0, 0.5, 1.0], device=dev)
+    sol = odeint(f, y0d, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "pipeline": "lag"})
+    assert sol.shape == (3, B, D)
+    rows = [0, 1, 4097, 65535]
+    E = scipy.linalg.expm(A.double().numpy() * 1.0)
+    exact = y0[rows].double().numpy() @ E.T
+    assert np.allclose(sol[2][rows].cpu().numpy(), exact, rtol=1e-4, atol=2e-5)
+    n0 = y0d.double().norm(dim=1)
+    n1 = sol[2].double().norm(dim=1)
+    assert torch.allclose(n0, n1, rtol=2e-5)
+    back = odeint(f, sol[2], torch.tensor([1.0, 0.0], device=dev), solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm})
+    assert torch.allclose(back[1], y0d, rtol=1e-4, atol=5e-5)

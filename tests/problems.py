@@ -1,0 +1,141 @@
+"""Test problems shared by the CPU and GPU suites.
+
+The three analytic problems restate the reference's fixtures (tests/testing_utils.py:8-70: ConstantXDE,
+SineXDE, LinearXDE on t = linspace(1, 8, 10)); the spiral is the demo system (example/demo_utils.py:136-164).
+Each problem offers a numpy ``f_np`` for the oracle and a torch ``f_torch(device)`` for the product; both use
+only +, -, * and matmul/sin so that the two frameworks agree to rounding.
+"""
+import math
+
+import numpy as np
+import scipy.linalg
+import torch
+
+
+class Constant:
+    a, b = 0.2, 3.0
+
+    def f_np(self, t, y):
+        d = y - (np.float32(self.a) * t + np.float32(self.b)).astype(y.dtype)
+        return (np.float32(self.a) + d * d * d * d * d).astype(y.dtype)
+
+    def f_torch(self, device):
+        a, b = self.a, self.b
+
+        def f(t, y):
+            d = y - (a * t + b).to(y.dtype)
+            return a + d * d * d * d * d
+
+        return f
+
+    def exact(self, t):
+        return (self.a * t + self.b)[:, None]  # [T, 1]
+
+
+class Sine:
+    def f_np(self, t, y):
+        t = np.asarray(t, dtype=y.dtype)
+        return (2 * y / t + t**4 * np.sin(2 * t) - t**2 + 4 * t**3).astype(y.dtype)
+
+    def f_torch(self, device):
+        def f(t, y):
+            t = t.to(y.dtype)
+            return 2 * y / t + t**4 * torch.sin(2 * t) - t**2 + 4 * t**3
+
+        return f
+
+    def exact(self, t):
+        return (
+            -0.5 * t**4 * np.cos(2 * t) + 0.5 * t**3 * np.sin(2 * t) + 0.25 * t**2 * np.cos(2 * t) - t**3 + 2 * t**4
+            + (math.pi - 0.25) * t**2
+        )[:, None]
+
+
+class Linear:
+    def __init__(self, dim=10, seed=0):
+        rng = np.random.RandomState(seed)
+        U = (rng.randn(dim, dim) * 0.1).astype(np.float32)
+        self.A = (2 * U - (U + U.T)).astype(np.float32)
+        self.dim = dim
+
+    def f_np(self, t, y):
+        return (y @ self.A.T.astype(y.dtype)).astype(y.dtype)
+
+    def f_torch(self, device):
+        A = torch.from_numpy(self.A).to(device)
+
+        def f(t, y):
+            return y @ A.T.to(y.dtype)
+
+        return f
+
+    def exact(self, t):
+        y0 = np.ones((self.dim, 1))
+        return np.stack([(scipy.linalg.expm(self.A.astype(np.float64) * ti) @ y0)[:, 0] for ti in t])  # [T, dim]
+
+
+PROBLEMS = {"constant": Constant, "sine": Sine, "linear": Linear}
+
+
+def construct_problem(name, npts=10, dtype=np.float32):
+    """tests/testing_utils.py:83-98 — returns (problem, y0 [1, D], t [T], sol [T, D])."""
+    p = PROBLEMS[name]()
+    t = np.linspace(1, 8, npts).astype(np.float32)
+    sol = p.exact(t.astype(np.float64)).astype(dtype)
+    return p, sol[0][None, :].copy(), t, sol
+
+
+SPIRAL_A = np.array([[-0.1, 2.0], [-2.0, -0.1]], dtype=np.float32)
+
+
+def spiral_np(t, y):
+    c = y * y * y
+    A = SPIRAL_A.astype(y.dtype)
+    return np.stack([c[..., 0] * A[0, 0] + c[..., 1] * A[1, 0], c[..., 0] * A[0, 1] + c[..., 1] * A[1, 1]], axis=-1)
+
+
+def spiral_torch(t, y):
+    c = y * y * y
+    A = SPIRAL_A
+    return torch.stack(
+        [c[..., 0] * float(A[0, 0]) + c[..., 1] * float(A[1, 0]), c[..., 0] * float(A[0, 1]) + c[..., 1] * float(A[1, 1])], dim=-1
+    )
+
+
+def skew_matrix(dim, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    U = 0.1 * torch.randn(dim, dim, generator=g)
+    return (U - U.T).contiguous()
+
+
+def vdp_np(mu):
+    def f(t, y):
+        x, v = y[..., 0], y[..., 1]
+        return np.stack([v, mu * (1 - x * x) * v - x], axis=-1).astype(y.dtype)
+
+    return f
+
+
+def vdp_torch(mu):
+    def f(t, y):
+        x, v = y[..., 0], y[..., 1]
+        return torch.stack([v, mu * (1 - x * x) * v - x], dim=-1)
+
+    return f
+
+
+def parity_ok(got, ref, rtol=1e-5, atol=1e-7, slack=1.0):
+    """north_star bar: |got - ref| <= atol + rtol * |ref| (optionally with a stated slack factor)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return bool((np.abs(got - ref) <= slack * (atol + rtol * np.abs(ref))).all())
+
+
+def worst(got, ref, rtol=1e-5, atol=1e-7):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float((np.abs(got - ref) / (atol + rtol * np.abs(ref))).max())
+
+
+def rel_err(got, ref):
+    """max |got - ref| / max |ref|: relative error against the solution's scale (fp32 free-running bar)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300))

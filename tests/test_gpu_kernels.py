@@ -1,0 +1,201 @@
+"""GPU parity, kernel level: every C-ABI kernel against the numpy statement of its contract
+(tests/_cpu_double.py, same op order as the reference's eager ops).  Element-wise kernels must be
+BIT-EXACT (the library is built with -ffp-contract=off); reductions agree to fp64-accumulation accuracy."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from paddlexde_amd import _hip
+
+from ._cpu_double import NumpyDoubleBackend
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "f64": torch.float64}
+
+
+def _rand(n, dtype, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, generator=g, dtype=dtype).to(dev)
+
+
+@pytest.fixture(scope="module")
+def be():
+    return _hip.get_backend()
+
+
+@pytest.fixture(scope="module")
+def dbl():
+    return NumpyDoubleBackend()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("mode", [_hip.COMBINE_RK, _hip.COMBINE_FUSE, _hip.COMBINE_WFUSE])
+@pytest.mark.parametrize("nk", [1, 2, 3, 5, 7, 9, 14])
+@pytest.mark.parametrize("n", [0, 1, 3, 257, 4096 + 5, 1 << 20])
+def test_stage_combine_bit_exact(be, dbl, dtype, mode, nk, n):
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    y0 = _rand(n, dt, 1, dev)
+    ks = [_rand(n, dt, 10 + j, dev) for j in range(nk)]
+    coef = list(np.linspace(-1.3, 2.1, nk))
+    out = torch.empty_like(y0)
+    be.stage_combine(out, y0, ks, coef, mode, scale=0.125, dt_host=0.0371)
+    ref = torch.empty(n, dtype=dt)
+    dbl.stage_combine(ref, y0.cpu(), [k.cpu() for k in ks], coef, mode, scale=0.125, dt_host=0.0371)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_stage_combine_misaligned_and_select(be, dbl, dtype):
+    """Unaligned views take the scalar path; ctrl-driven dt and operand select."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    n = 10007
+    big = _rand(4 * (n + 8), dt, 3, dev)
+    y0 = big[1 : 1 + n]  # 4/8-byte offset: not 16-byte aligned
+    k0 = big[n + 9 : 2 * n + 9]
+    k1 = _rand(n, dt, 4, dev)
+    y0b = _rand(n, dt, 5, dev)
+    k0b = _rand(n, dt, 6, dev)
+    out = torch.empty(n, dtype=dt, device=dev)
+    ctrl_h = _hip.XdeCtrl()
+    ctrl_h.dt = float(np.float32(0.0123))
+    for accept in (0, 1):
+        ctrl_h.accept = accept
+        ctrl = torch.frombuffer(bytearray(bytes(ctrl_h)), dtype=torch.uint8).to(dev)
+        be.stage_combine(out, y0, [k0, k1], [0.3, -0.7], _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0b, k0_alt=k0b)
+        ref = torch.empty(n, dtype=dt)
+        cc = torch.frombuffer(bytearray(bytes(ctrl_h)), dtype=torch.uint8)
+        dbl.stage_combine(ref, y0.cpu(), [k0.cpu(), k1.cpu()], [0.3, -0.7], _hip.COMBINE_RK, ctrl=cc, y0_alt=y0b.cpu(), k0_alt=k0b.cpu())
+        assert torch.equal(out.cpu(), ref)
+
+
+def test_bad_arguments_fail_loudly(be):
+    dev = torch.device("cuda:0")
+    y = torch.zeros(8, device=dev)
+    with pytest.raises(_hip.XdeError):
+        be.stage_combine(y, y, [y] * 15, [1.0] * 15, _hip.COMBINE_RK)  # nk > XDE_MAX_K
+    with pytest.raises(_hip.XdeError):
+        be.stage_combine(y, y, [y], [1.0], 7)  # bad mode
+    with pytest.raises(_hip.XdeError):
+        be.stage_combine(torch.zeros(8), torch.zeros(8), [torch.zeros(8)], [1.0], 0)  # CPU tensors
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("norm_kind", [_hip.NORM_RMS, _hip.NORM_LINF])
+@pytest.mark.parametrize("n", [1, 5, 1000, (1 << 21) + 3])
+def test_error_norm_and_control(be, dbl, dtype, norm_kind, n):
+    """K2 partials + K3 controller against the numpy contract: ratio to 1e-6 relative, decisions identical."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    y0 = _rand(n, dt, 1, dev)
+    y1 = y0 + 1e-3 * _rand(n, dt, 2, dev)
+    ks = [_rand(n, dt, 20 + j, dev) for j in range(6)]
+    c_err = [1.2e-3, -7.5e-3, 4.1e-3, -2.0e-3, 9.9e-4, -1.0 / 60.0]
+    segs = _hip.make_segments([(0, n)])
+    p = _hip.XdeCtrlParams()
+    p.rtol, p.atol, p.min_step, p.max_step = 1e-3, 1e-5, 0.0, float("inf")
+    p.safety, p.ifactor, p.dfactor, p.order = 0.9, 10.0, 0.2, 5.0
+    p.max_num_steps = 2**31 - 1
+    p.time_dtype = _hip.XDE_F32
+    p.state_dtype = _hip.dtype_code(dt)
+    p.direction, p.norm_kind, p.n_stage, p.n_seg = 1, norm_kind, 6, 1
+    for i, a in enumerate([0.2, 0.3, 0.8, 8 / 9, 1.0, 1.0]):
+        p.alpha[i] = a
+    p.seg_count[0] = float(n)
+    t_span = torch.tensor([0.0, 0.004, 0.03, 10.0], dtype=torch.float64)
+
+    def run(backend, device):
+        ctrl = backend.new_ctrl(device)
+        ws = backend.new_workspace(device)
+        ts = torch.zeros(_hip.XDE_MAX_STAGE, dtype=dt, device=device)
+        tsd = t_span.to(device)
+        backend.ctrl_init(ctrl, p, 0.0, 0.01, 4, tsd, None, ts)
+        recs = []
+        mv = (lambda x: x.to(device))
+        for _ in range(4):
+            backend.error_norm_partial([mv(k) for k in ks], c_err, mv(y0), mv(y1), p.rtol, p.atol, segs, norm_kind, ws, ctrl=ctrl)
+            backend.rk_control(ctrl, p, ws, None, tsd, None, ts)
+            c = backend.ctrl_read(ctrl)
+            recs.append((c.ratio, c.accept, c.t0, c.t1, c.dt, c.out_begin, c.out_end, c.next_out, c.n_accept, c.n_reject, c.status,
+                         ts.cpu().numpy()[:6].copy()))
+        return recs
+
+    got = run(be, dev)
+    ref = run(dbl, torch.device("cpu"))
+    for g, r in zip(got, ref):
+        assert g[0] == pytest.approx(r[0], rel=2e-6)
+        assert g[1] == r[1]
+        assert g[2:5] == pytest.approx(r[2:5], rel=3e-6)
+        assert g[5:11] == r[5:11]
+        assert np.allclose(g[11], r[11], rtol=3e-6)
+
+
+def test_error_norm_nonfinite_flag(be):
+    dev = torch.device("cuda:0")
+    n = 5000
+    y0 = torch.ones(n, device=dev)
+    y0[1234] = float("inf")
+    y0[77] = float("nan")
+    k = torch.ones(n, device=dev)
+    ws = be.new_workspace(dev)
+    sums = be.new_sums(dev)
+    be.error_norm_partial([k], [1.0], y0, y0, 1e-3, 1e-6, _hip.make_segments([(0, n)]), _hip.NORM_RMS, ws, dt_host=0.1)
+    be.norm_finalize(ws, 0, sums)
+    assert sums[_hip.XDE_MAX_SEG].item() == 2.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_segmented_norm(be, dbl, dtype):
+    """Mixed norm over a padded tuple layout: per-segment RMS, max over segments."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    w = 4 if dt == torch.float32 else 2
+    lens = [1, 4099, 4099, 100, 50, 100, 2]
+    segs, off = [], 0
+    for l in lens:
+        segs.append((off, l))
+        off += -(-l // w) * w
+    a = _rand(off, dt, 1, dev)
+    y0 = _rand(off, dt, 2, dev)
+    xs = _hip.make_segments(segs)
+    counts = [float(l) for l in lens]
+    res = torch.zeros(1, dtype=torch.float64, device=dev)
+    ws, sums = be.new_workspace(dev), be.new_sums(dev)
+    be.scaled_norm_partial(a, None, y0, 1e-2, 1e-3, xs, _hip.NORM_RMS, ws, 0)
+    be.norm_finalize(ws, 0, sums)
+    be.norm_result(sums, counts, _hip.NORM_RMS, _hip.dtype_code(dt), res)
+    an, yn = a.cpu().numpy(), y0.cpu().numpy()
+    per = []
+    for s, l in segs:
+        r = an[s : s + l] / (yn.dtype.type(1e-3) + np.abs(yn[s : s + l]) * yn.dtype.type(1e-2))
+        per.append(np.sqrt(np.mean(r.astype(np.float64) ** 2)))
+    assert res.item() == pytest.approx(max(per), rel=2e-6)
+    got = sums[: len(lens)].cpu().numpy() / np.asarray(counts)
+    assert np.allclose(np.sqrt(got), per, rtol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n", [3, 1000, 65536 + 2])
+def test_dense_eval_bit_exact(be, dbl, dtype, n):
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    y0, y1 = _rand(n, dt, 1, dev), _rand(n, dt, 2, dev)
+    ks = [_rand(n, dt, 30 + j, dev) for j in range(6)]
+    f1 = ks[-1]
+    mid = [0.10013, 0.39185, -0.02982, 0.05893, -0.04497, 0.023904]
+    t_span = torch.tensor([0.0, 0.51, 0.55, 0.9], dtype=torch.float64)
+    ch = _hip.XdeCtrl()
+    ch.t0, ch.t1, ch.dt_last = 0.5, float(np.float32(0.6)), float(np.float32(0.6) - np.float32(0.5))
+    ch.accept, ch.out_begin, ch.out_end = 1, 1, 3
+    raw = bytearray(bytes(ch))
+    out = torch.zeros(4, n, dtype=dt, device=dev)
+    be.dense_eval(out, ks, mid, y0, y1, f1, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev), t_span.to(dev), _hip.XDE_F32)
+    ref = torch.zeros(4, n, dtype=dt)
+    dbl.dense_eval(ref, [k.cpu() for k in ks], mid, y0.cpu(), y1.cpu(), f1.cpu(), torch.frombuffer(bytearray(raw), dtype=torch.uint8), t_span, _hip.XDE_F32)
+    assert torch.equal(out.cpu(), ref)
+    assert (out[0] == 0).all() and (out[3] == 0).all()
