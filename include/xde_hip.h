@@ -90,8 +90,12 @@ typedef struct xde_ctrl {
   int32_t done;      /* next_out == n_out */
   int32_t next_step_index; /* index into step_t (base_adaptive_solver_rk.py:109-111) */
   int32_t on_step_t; /* the pending dt was clipped to step_t[next_step_index] */
-  int32_t reserved[6];
+  int64_t seq;       /* controller launches so far (incl. no-op ones after `done`); orders the host mirror */
+  int32_t reserved[4];
 } xde_ctrl_t;
+
+#define XDE_MIRROR_SLOTS 4 /* host mirror ring: slot[seq % XDE_MIRROR_SLOTS] */
+#define XDE_ETIMEOUT 3
 
 /* Controller parameters (host struct, passed by pointer, copied at call time). */
 typedef struct xde_ctrl_params {
@@ -190,11 +194,15 @@ int xde_norm_result(const double* sums, const double* seg_count, int n_seg, int 
  *         partials in `ws` slot 0 inside this launch (single-GPU fast path);
  *   t_span_dev: n_out doubles (time dtype values) on the device;  step_t_dev: n_step_t doubles or NULL;
  *   t_stage_out: n_stage values of `state_dtype` on the device — times func() is called with in the
- *                next step.
+ *                next step;
+ *   host_mirror: NULL, or a ring of XDE_MIRROR_SLOTS control blocks in pinned, device-mapped host memory
+ *                (xde_host_alloc): the controller publishes the updated block to slot[seq % SLOTS] with a
+ *                system-scope release, so the host learns accept/t/dt by polling (xde_ctrl_wait) — no copy
+ *                command and no event packet on the stream.
  */
 int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void* ws,
                    const double* sums, const double* t_span_dev, const double* step_t_dev,
-                   void* t_stage_out, void* stream);
+                   void* t_stage_out, xde_ctrl_t* host_mirror, void* stream);
 
 /*
  * Initialise the device control block before the first step (replaces the construction of
@@ -203,10 +211,24 @@ int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void
  */
 int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_start,
                   double first_step, int32_t n_out, const double* t_span_dev,
-                  const double* step_t_dev, void* t_stage_out, void* stream);
+                  const double* step_t_dev, void* t_stage_out, int64_t seq0, void* stream);
 
-/* Blocking device->host copy of the control block (the one sync point of a step). */
+/* Blocking device->host copy of the control block (hipMemcpyAsync + stream synchronise). */
 int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream);
+
+/*
+ * Pinned, device-mapped, coherent host memory for the mirror ring (the one allocation the library makes
+ * on request; the caller owns it and frees it with xde_host_free).
+ */
+int xde_host_alloc(int64_t bytes, void** ptr_out);
+int xde_host_free(void* ptr);
+
+/*
+ * Host side of the mirror: spin (no HIP call) until the controller launch number `seq` has published
+ * its block, then copy it to host_out.  XDE_ETIMEOUT after timeout_ms; XDE_EBADARG if the slot was
+ * already overwritten by launch seq + XDE_MIRROR_SLOTS.
+ */
+int xde_ctrl_wait(const xde_ctrl_t* host_mirror, int64_t seq, double timeout_ms, xde_ctrl_t* host_out);
 
 /*
  * Dense output — replaces _interp_fit + interp_fit + interp_evaluate
@@ -226,8 +248,10 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
 
 /*
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
- * roofline figure).  When enabled every launch above is bracketed by an event pair;
- * xde_prof_collect() synchronises and returns, per kernel id, launch count and summed milliseconds.
+ * roofline figure).  xde_prof_enable(period): 0 = off; p >= 1 = every p-th launch of each kernel id is
+ * launched with a start/stop event pair stamped by the dispatch itself (hipExtLaunchKernelGGL), so the
+ * measured time is the kernel's own duration.  xde_prof_collect() synchronises and returns, per kernel
+ * id, the number of SAMPLED launches, their summed milliseconds and their summed algorithmic bytes.
  */
 #define XDE_KID_COMBINE 0
 #define XDE_KID_ERRNORM 1

@@ -8,10 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 
 import torch
 
-XDE_OK, XDE_EBADARG, XDE_EHIP = 0, 1, 2
+XDE_OK, XDE_EBADARG, XDE_EHIP, XDE_ETIMEOUT = 0, 1, 2, 3
+XDE_MIRROR_SLOTS = 4
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
 COMBINE_RK, COMBINE_FUSE, COMBINE_WFUSE = 0, 1, 2
@@ -35,6 +37,9 @@ SYMBOLS = (
     "xde_rk_control",
     "xde_ctrl_init",
     "xde_ctrl_read",
+    "xde_host_alloc",
+    "xde_host_free",
+    "xde_ctrl_wait",
     "xde_dense_eval",
     "xde_prof_enable",
     "xde_prof_collect",
@@ -68,7 +73,8 @@ class XdeCtrl(C.Structure):
         ("done", C.c_int32),
         ("next_step_index", C.c_int32),
         ("on_step_t", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("seq", C.c_int64),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -149,9 +155,15 @@ def load_library():
         lib.xde_norm_result.restype = i32
         lib.xde_norm_result.argtypes = [vp, dp, i32, i32, i32, vp, vp]
         lib.xde_rk_control.restype = i32
-        lib.xde_rk_control.argtypes = [vp, C.POINTER(XdeCtrlParams), vp, vp, vp, vp, vp, vp]
+        lib.xde_rk_control.argtypes = [vp, C.POINTER(XdeCtrlParams), vp, vp, vp, vp, vp, vp, vp]
         lib.xde_ctrl_init.restype = i32
-        lib.xde_ctrl_init.argtypes = [vp, C.POINTER(XdeCtrlParams), dbl, dbl, C.c_int32, vp, vp, vp, vp]
+        lib.xde_ctrl_init.argtypes = [vp, C.POINTER(XdeCtrlParams), dbl, dbl, C.c_int32, vp, vp, vp, i64, vp]
+        lib.xde_host_alloc.restype = i32
+        lib.xde_host_alloc.argtypes = [i64, C.POINTER(C.c_void_p)]
+        lib.xde_host_free.restype = i32
+        lib.xde_host_free.argtypes = [vp]
+        lib.xde_ctrl_wait.restype = i32
+        lib.xde_ctrl_wait.argtypes = [vp, i64, dbl, C.POINTER(XdeCtrl)]
         lib.xde_ctrl_read.restype = i32
         lib.xde_ctrl_read.argtypes = [vp, C.POINTER(XdeCtrl), vp]
         lib.xde_dense_eval.restype = i32
@@ -202,8 +214,31 @@ class HipBackend:
 
     name = "hip"
 
+    WAIT_TIMEOUT_MS = 600e3
+
     def __init__(self):
         self.lib = load_library()
+        self._mirror_pool = []  # pinned host mirror rings, reused across solver instances
+        self._mirrors = {}  # device ctrl pointer -> _Mirror
+
+    # -- host mirror ring of the control block (see xde_rk_control / xde_ctrl_wait) -------------
+    class _Mirror:
+        __slots__ = ("ptr", "seq", "seq0")
+
+        def __init__(self, ptr):
+            self.ptr, self.seq, self.seq0 = ptr, 0, 0
+
+    def _acquire_mirror(self):
+        if self._mirror_pool:
+            return self._mirror_pool.pop()
+        ptr = C.c_void_p()
+        self._check(self.lib.xde_host_alloc(XDE_MIRROR_SLOTS * C.sizeof(XdeCtrl), C.byref(ptr)), "xde_host_alloc")
+        return HipBackend._Mirror(ptr.value)
+
+    def _release_mirror(self, key):
+        m = self._mirrors.pop(key, None)
+        if m is not None:
+            self._mirror_pool.append(m)
 
     # -- helpers -------------------------------------------------------------------------
     def _check(self, rc, who):
@@ -227,7 +262,11 @@ class HipBackend:
 
     # -- allocation (torch is the allocator; the library never allocates) -------------------
     def new_ctrl(self, device):
-        return torch.zeros(C.sizeof(XdeCtrl), dtype=torch.uint8, device=device)
+        t = torch.zeros(C.sizeof(XdeCtrl), dtype=torch.uint8, device=device)
+        key = t.data_ptr()
+        self._mirrors[key] = self._acquire_mirror()
+        weakref.finalize(t, self._release_mirror, key)
+        return t
 
     def new_workspace(self, device):
         return torch.zeros(int(self.lib.xde_workspace_bytes()), dtype=torch.uint8, device=device)
@@ -276,35 +315,47 @@ class HipBackend:
 
     def rk_control(self, ctrl, params, ws, sums, t_span_dev, step_t_dev, t_stage):
         self._require_device(ctrl, t_span_dev, t_stage)
+        m = self._mirrors.get(ctrl.data_ptr())
         rc = self.lib.xde_rk_control(ctrl.data_ptr(), C.byref(params), _ptr(ws), _ptr(sums), t_span_dev.data_ptr(),
-                                     _ptr(step_t_dev), t_stage.data_ptr(), self._stream(ctrl))
+                                     _ptr(step_t_dev), t_stage.data_ptr(), m.ptr if m is not None else None,
+                                     self._stream(ctrl))
         self._check(rc, "xde_rk_control")
+        if m is not None:
+            m.seq += 1
 
     def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage):
         self._require_device(ctrl, t_span_dev, t_stage)
+        m = self._mirrors.get(ctrl.data_ptr())
+        seq0 = m.seq if m is not None else 0
         rc = self.lib.xde_ctrl_init(ctrl.data_ptr(), C.byref(params), float(t_start), float(first_step), int(n_out),
-                                    t_span_dev.data_ptr(), _ptr(step_t_dev), t_stage.data_ptr(), self._stream(ctrl))
+                                    t_span_dev.data_ptr(), _ptr(step_t_dev), t_stage.data_ptr(), seq0, self._stream(ctrl))
         self._check(rc, "xde_ctrl_init")
+        if m is not None:
+            m.seq0 = seq0
 
     def ctrl_read(self, ctrl) -> XdeCtrl:
+        """The newest control block.  With a host mirror: poll the pinned ring (no HIP call); else a blocking copy."""
         self._require_device(ctrl)
+        m = self._mirrors.get(ctrl.data_ptr())
+        if m is not None and m.seq > m.seq0:
+            return self.ctrl_wait((m, m.seq))
         host = XdeCtrl()
         self._check(self.lib.xde_ctrl_read(ctrl.data_ptr(), C.byref(host), self._stream(ctrl)), "xde_ctrl_read")
         return host
 
     def ctrl_read_async(self, ctrl):
-        """Enqueue a device->pinned-host copy of the control block; returns a handle for ctrl_wait()."""
+        """Handle for the control block of the newest controller launch; nothing is enqueued on the stream."""
         self._require_device(ctrl)
-        host = torch.empty(ctrl.numel(), dtype=torch.uint8, pin_memory=True)
-        host.copy_(ctrl, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(ctrl.device))
-        return (host, ev)
+        m = self._mirrors.get(ctrl.data_ptr())
+        if m is None or m.seq == m.seq0:
+            raise XdeError("ctrl_read_async needs a control block from new_ctrl() with at least one controller launch")
+        return (m, m.seq)
 
     def ctrl_wait(self, handle) -> XdeCtrl:
-        host, ev = handle
-        ev.synchronize()
-        return XdeCtrl.from_buffer_copy(host.numpy().tobytes())
+        m, seq = handle
+        host = XdeCtrl()
+        self._check(self.lib.xde_ctrl_wait(m.ptr, seq, self.WAIT_TIMEOUT_MS, C.byref(host)), "xde_ctrl_wait")
+        return host
 
     def dense_eval(self, out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype, *, y0_alt=None, k0_alt=None,
                    expect_step=-1):
@@ -319,8 +370,9 @@ class HipBackend:
         self._check(rc, "xde_dense_eval")
 
     # -- profiling ---------------------------------------------------------------------------
-    def prof_enable(self, on=True):
-        self._check(self.lib.xde_prof_enable(1 if on else 0), "xde_prof_enable")
+    def prof_enable(self, period=1):
+        """0/False: off; p >= 1: time every p-th launch of each kernel with dispatch-stamped HIP events."""
+        self._check(self.lib.xde_prof_enable(int(period)), "xde_prof_enable")
 
     def prof_collect(self):
         n = len(KID_NAMES)

@@ -11,10 +11,12 @@
 // order exactly; the kernels are memory bound, so FMA contraction would buy nothing.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -123,14 +125,20 @@ struct SegMap {
   int64_t seg_len[XDE_MAX_SEG];
 };
 
+struct alignas(16) Partial {
+  double val;   // sum of squares (RMS) or max |.| (LINF) of the block's elements
+  double nf;    // non-finite elements of y0 seen by the block
+  int32_t seg;  // segment the block worked on
+  int32_t pad[3];
+};
+static_assert(sizeof(Partial) == 32, "Partial is two 16-byte stores / loads");
+
 struct NormSlot {
   int32_t nblocks;
   int32_t n_seg;
   int32_t norm_kind;
   int32_t pad;
-  int32_t seg_of_block[XDE_MAX_PARTIALS];
-  double val[XDE_MAX_PARTIALS];
-  double nf[XDE_MAX_PARTIALS];
+  Partial p[XDE_MAX_PARTIALS];
 };
 
 struct ErrArgs {
@@ -344,9 +352,12 @@ __device__ void block_reduce_store(double val, double nf, NormSlot* slot, int se
       v = merge_<NORM>(v, s_val[w]);
       f += s_nf[w];
     }
-    slot->val[blockIdx.x] = v;
-    slot->nf[blockIdx.x] = f;
-    slot->seg_of_block[blockIdx.x] = seg;
+    Partial rec;
+    rec.val = v;
+    rec.nf = f;
+    rec.seg = seg;
+    rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+    slot->p[blockIdx.x] = rec;
   }
 }
 
@@ -566,35 +577,63 @@ __global__ __launch_bounds__(kBlock) void xde_scalednorm_kernel(ScaledArgs s) {
 // fixed-order reduction of block partials → per-segment sums (one workgroup)
 // ------------------------------------------------------------------------------------------
 __device__ void reduce_partials(const NormSlot* slot, double* seg_val, double* seg_nf) {
-  // called by all kBlock threads of ONE block; results valid in thread 0's view of seg_val/seg_nf
-  // (shared memory arrays of XDE_MAX_SEG)
-  __shared__ double r_val[kBlock];
-  __shared__ double r_nf[kBlock];
+  // Called by all kBlock threads of ONE block; results land in seg_val/seg_nf (shared, XDE_MAX_SEG each).
+  // Every thread first pulls its (up to) XDE_MAX_PARTIALS/kBlock records into registers with independent
+  // 32-byte loads (one memory round trip), then the per-segment reductions run on registers:
+  // strided per-thread order -> wave64 shuffle tree -> 4 wave results summed in order.  Fixed order, so
+  // the value is bit-reproducible from launch to launch and identical on every rank.
+  constexpr int kPer = XDE_MAX_PARTIALS / kBlock;
+  __shared__ double w_val[kWaves];
+  __shared__ double w_nf[kWaves];
   const int nblocks = slot->nblocks;
   const int n_seg = slot->n_seg;
   const bool rms = slot->norm_kind == XDE_NORM_RMS;
+  double rv[kPer], rf[kPer];
+  int rs[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int b = threadIdx.x + i * kBlock;
+    if (b < nblocks) {
+      Partial rec = slot->p[b];
+      rv[i] = rec.val;
+      rf[i] = rec.nf;
+      rs[i] = rec.seg;
+    } else {
+      rv[i] = 0.0;
+      rf[i] = 0.0;
+      rs[i] = -1;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int s = 0; s < n_seg; ++s) {
     double v = 0.0, f = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
-      if (slot->seg_of_block[b] == s) {
-        v = rms ? v + slot->val[b] : nanmax_(v, slot->val[b]);
-        f += slot->nf[b];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      if (rs[i] == s) {
+        v = rms ? v + rv[i] : nanmax_(v, rv[i]);
+        f += rf[i];
       }
     }
-    r_val[threadIdx.x] = v;
-    r_nf[threadIdx.x] = f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      double ov = __shfl_down(v, off, 64);
+      v = rms ? v + ov : nanmax_(v, ov);
+      f += __shfl_down(f, off, 64);
+    }
+    if (lane == 0) {
+      w_val[wave] = v;
+      w_nf[wave] = f;
+    }
     __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-      if (threadIdx.x < off) {
-        r_val[threadIdx.x] = rms ? r_val[threadIdx.x] + r_val[threadIdx.x + off]
-                                 : nanmax_(r_val[threadIdx.x], r_val[threadIdx.x + off]);
-        r_nf[threadIdx.x] += r_nf[threadIdx.x + off];
-      }
-      __syncthreads();
-    }
     if (threadIdx.x == 0) {
-      seg_val[s] = r_val[0];
-      seg_nf[s] = r_nf[0];
+      double tv = w_val[0], tf = w_nf[0];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) {
+        tv = rms ? tv + w_val[w] : nanmax_(tv, w_val[w]);
+        tf += w_nf[w];
+      }
+      seg_val[s] = tv;
+      seg_nf[s] = tf;
     }
     __syncthreads();
   }
@@ -780,9 +819,16 @@ __device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double r
 
 __global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const NormSlot* slot,
                                                              const double* sums, const double* t_span,
-                                                             const double* step_t, void* t_stage_out) {
+                                                             const double* step_t, void* t_stage_out,
+                                                             xde_ctrl_t* mirror) {
   __shared__ double seg_val[XDE_MAX_SEG];
   __shared__ double seg_nf[XDE_MAX_SEG];
+  __shared__ xde_ctrl_t zs;
+  constexpr int kWords = sizeof(xde_ctrl_t) / 8;
+  constexpr int kSeqWord = offsetof(xde_ctrl_t, seq) / 8;
+  // the control block is fetched by the first lanes while the partials are being reduced
+  if (threadIdx.x < kWords)
+    reinterpret_cast<uint64_t*>(&zs)[threadIdx.x] = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
   if (sums) {
     if (threadIdx.x < XDE_MAX_SEG) {
       seg_val[threadIdx.x] = sums[threadIdx.x];
@@ -797,19 +843,43 @@ __global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_
     __syncthreads();
     reduce_partials(slot, seg_val, seg_nf);
   }
-  if (threadIdx.x == 0 && !c->done) {  // a speculative attempt past the last output is a no-op
-    double ratio = norm_from_sums(seg_val, p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, c->ratio_seg);
-    double nf = 0.0;
-    for (int s = 0; s < p.n_seg; ++s) nf += seg_nf[s];
-    if (p.time_dtype == XDE_F32)
-      control_step<float>(c, p, ratio, nf, t_span, step_t, t_stage_out);
-    else
-      control_step<double>(c, p, ratio, nf, t_span, step_t, t_stage_out);
+  if (threadIdx.x == 0) {
+    xde_ctrl_t z = zs;  // all controller arithmetic runs on registers
+    z.seq += 1;
+    if (!z.done) {  // a speculative attempt past the last output is a no-op
+      double ratio = norm_from_sums(seg_val, p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, z.ratio_seg);
+      double nf = 0.0;
+      for (int s = 0; s < p.n_seg; ++s) nf += seg_nf[s];
+      if (p.time_dtype == XDE_F32)
+        control_step<float>(&z, p, ratio, nf, t_span, step_t, t_stage_out);
+      else
+        control_step<double>(&z, p, ratio, nf, t_span, step_t, t_stage_out);
+    }
+    zs = z;
+  }
+  __syncthreads();
+  // write-back: one wave instruction to the device block, one to the pinned host mirror slot
+  // (slot[seq % SLOTS]); the slot's seq word is stored last, after a system-scope release
+  if (threadIdx.x < kWords) {
+    const uint64_t word = reinterpret_cast<const uint64_t*>(&zs)[threadIdx.x];
+    reinterpret_cast<uint64_t*>(c)[threadIdx.x] = word;
+    if (mirror && threadIdx.x != kSeqWord) {
+      xde_ctrl_t* ms = mirror + (zs.seq % XDE_MIRROR_SLOTS);
+      __hip_atomic_store(reinterpret_cast<uint64_t*>(ms) + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (mirror && threadIdx.x < 64) {  // the wave that wrote the words releases them, then publishes seq
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+      xde_ctrl_t* ms = mirror + (zs.seq % XDE_MIRROR_SLOTS);
+      __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
 __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
-                                     int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out) {
+                                     int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
+                                     int64_t seq0) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   xde_ctrl_t z;
   memset(&z, 0, sizeof(z));
@@ -834,11 +904,12 @@ __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double 
     if (idx > p.n_step_t - 1) idx = p.n_step_t - 1;
   }
   z.next_step_index = idx;
-  *c = z;
+  z.seq = seq0;
   if (p.time_dtype == XDE_F32)
-    plan_next<float>(c, p, step_t, t_stage_out);
+    plan_next<float>(&z, p, step_t, t_stage_out);
   else
-    plan_next<double>(c, p, step_t, t_stage_out);
+    plan_next<double>(&z, p, step_t, t_stage_out);
+  *c = z;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -932,6 +1003,8 @@ struct ProfRec {
 };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+int g_prof_period = 1;
+int64_t g_prof_launches[XDE_KID_COUNT] = {0};
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_event_pool;
 double g_prof_bytes[XDE_KID_COUNT] = {0};
@@ -949,28 +1022,31 @@ hipEvent_t get_event() {
   return e;
 }
 
+// When profiling is on, the start/stop events are handed to hipExtLaunchKernelGGL, which stamps them with
+// the kernel dispatch's own begin/end timestamps (no extra marker packets on the stream).
 struct ProfScope {
   bool on;
   int kid;
-  hipStream_t st;
-  hipEvent_t start, stop;
-  ProfScope(int kid_, hipStream_t st_, double bytes) : on(g_prof_on), kid(kid_), st(st_) {
+  hipEvent_t start = nullptr, stop = nullptr;
+  ProfScope(int kid_, double bytes) : on(g_prof_on), kid(kid_) {
+    if (on) on = (g_prof_launches[kid]++ % g_prof_period) == 0;  // sample every period-th launch of this kernel
     if (on) {
       std::lock_guard<std::mutex> lk(g_prof_mu);
       start = get_event();
       stop = get_event();
       g_prof_bytes[kid] += bytes;
-      (void)hipEventRecord(start, st);
     }
   }
   ~ProfScope() {
     if (on) {
       std::lock_guard<std::mutex> lk(g_prof_mu);
-      (void)hipEventRecord(stop, st);
       g_prof_recs.push_back(ProfRec{kid, start, stop});
     }
   }
 };
+
+#define XDE_LAUNCH(kernel, grid, block, st, prof, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, 0, st, (prof).start, (prof).stop, 0, __VA_ARGS__)
 
 int build_segmap(const xde_segments_t* segs, int width, bool vec, SegMap* m, int* nblocks_out) {
   if (!segs || segs->n_seg < 1 || segs->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, "segments: n_seg out of range");
@@ -1060,14 +1136,14 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   if (blocks < 1) blocks = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double elt = dtype == XDE_F32 ? 4.0 : 8.0;
-  ProfScope prof(XDE_KID_COMBINE, st, double(nk + 2) * double(n) * elt);
+  ProfScope prof(XDE_KID_COMBINE, double(nk + 2) * double(n) * elt);
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
 #define LAUNCH_COMBINE(T, MODE)                                                     \
   do {                                                                              \
     if (vec)                                                                        \
-      hipLaunchKernelGGL((xde_combine_kernel<T, MODE, true>), g, b, 0, st, a);      \
+      XDE_LAUNCH((xde_combine_kernel<T, MODE, true>), g, b, st, prof, a);      \
     else                                                                            \
-      hipLaunchKernelGGL((xde_combine_kernel<T, MODE, false>), g, b, 0, st, a);     \
+      XDE_LAUNCH((xde_combine_kernel<T, MODE, false>), g, b, st, prof, a);     \
   } while (0)
   if (dtype == XDE_F32) {
     if (mode == XDE_COMBINE_RK) LAUNCH_COMBINE(float, XDE_COMBINE_RK);
@@ -1120,14 +1196,14 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   hipStream_t st = static_cast<hipStream_t>(stream);
   double total = 0;
   for (int s = 0; s < segs->n_seg; ++s) total += double(segs->seg_len[s]);
-  ProfScope prof(XDE_KID_ERRNORM, st, double(nk + 2) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
+  ProfScope prof(XDE_KID_ERRNORM, double(nk + 2) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
   dim3 g(nblocks), b(kBlock);
 #define LAUNCH_ERR(T, NORM)                                                       \
   do {                                                                            \
     if (vec)                                                                      \
-      hipLaunchKernelGGL((xde_errnorm_kernel<T, NORM, true>), g, b, 0, st, a);    \
+      XDE_LAUNCH((xde_errnorm_kernel<T, NORM, true>), g, b, st, prof, a);    \
     else                                                                          \
-      hipLaunchKernelGGL((xde_errnorm_kernel<T, NORM, false>), g, b, 0, st, a);   \
+      XDE_LAUNCH((xde_errnorm_kernel<T, NORM, false>), g, b, st, prof, a);   \
   } while (0)
   if (dtype == XDE_F32) {
     if (norm_kind == XDE_NORM_RMS) LAUNCH_ERR(float, XDE_NORM_RMS);
@@ -1163,14 +1239,14 @@ int xde_scaled_norm_partial(const void* av, const void* bv, const void* y0, doub
   hipStream_t st = static_cast<hipStream_t>(stream);
   double total = 0;
   for (int i = 0; i < segs->n_seg; ++i) total += double(segs->seg_len[i]);
-  ProfScope prof(XDE_KID_SCALEDNORM, st, (bv ? 3.0 : 2.0) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
+  ProfScope prof(XDE_KID_SCALEDNORM, (bv ? 3.0 : 2.0) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
   dim3 g(nblocks), b(kBlock);
 #define LAUNCH_SC(T, NORM, DIFF)                                                          \
   do {                                                                                    \
     if (vec)                                                                              \
-      hipLaunchKernelGGL((xde_scalednorm_kernel<T, NORM, true, DIFF>), g, b, 0, st, s);   \
+      XDE_LAUNCH((xde_scalednorm_kernel<T, NORM, true, DIFF>), g, b, st, prof, s);   \
     else                                                                                  \
-      hipLaunchKernelGGL((xde_scalednorm_kernel<T, NORM, false, DIFF>), g, b, 0, st, s);  \
+      XDE_LAUNCH((xde_scalednorm_kernel<T, NORM, false, DIFF>), g, b, st, prof, s);  \
   } while (0)
 #define LAUNCH_SC2(T, NORM)              \
   do {                                   \
@@ -1194,8 +1270,8 @@ int xde_norm_finalize(const void* ws, int slot, double* sums_out, void* stream) 
   if (!ws || !sums_out) return fail(XDE_EBADARG, "xde_norm_finalize: null pointer");
   if (slot < 0 || slot >= kSlots) return fail(XDE_EBADARG, "xde_norm_finalize: bad slot");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  ProfScope prof(XDE_KID_FINALIZE, st, 0.0);
-  hipLaunchKernelGGL(xde_finalize_kernel, dim3(1), dim3(kBlock), 0, st, slot_ptr(ws, slot), sums_out);
+  ProfScope prof(XDE_KID_FINALIZE, 0.0);
+  XDE_LAUNCH(xde_finalize_kernel, dim3(1), dim3(kBlock), st, prof, slot_ptr(ws, slot), sums_out);
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }
@@ -1225,22 +1301,23 @@ static int check_params(const xde_ctrl_params_t* p, const char* who) {
 }
 
 int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void* ws, const double* sums,
-                   const double* t_span_dev, const double* step_t_dev, void* t_stage_out, void* stream) {
+                   const double* t_span_dev, const double* step_t_dev, void* t_stage_out, xde_ctrl_t* host_mirror,
+                   void* stream) {
   if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_rk_control: null pointer");
   if (!ws && !sums) return fail(XDE_EBADARG, "xde_rk_control: need ws or sums");
   int rc = check_params(params, "xde_rk_control");
   if (rc != XDE_OK) return rc;
   if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_rk_control: n_step_t > 0 without step_t_dev");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  ProfScope prof(XDE_KID_CONTROL, st, 0.0);
-  hipLaunchKernelGGL(xde_control_kernel, dim3(1), dim3(kBlock), 0, st, ctrl, *params,
-                     ws ? slot_ptr(ws, 0) : nullptr, sums, t_span_dev, step_t_dev, t_stage_out);
+  ProfScope prof(XDE_KID_CONTROL, 0.0);
+  XDE_LAUNCH(xde_control_kernel, dim3(1), dim3(kBlock), st, prof, ctrl, *params, ws ? slot_ptr(ws, 0) : nullptr, sums,
+             t_span_dev, step_t_dev, t_stage_out, host_mirror);
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }
 
 int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_start, double first_step, int32_t n_out,
-                  const double* t_span_dev, const double* step_t_dev, void* t_stage_out, void* stream) {
+                  const double* t_span_dev, const double* step_t_dev, void* t_stage_out, int64_t seq0, void* stream) {
   if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_ctrl_init: null pointer");
   int rc = check_params(params, "xde_ctrl_init");
   if (rc != XDE_OK) return rc;
@@ -1248,7 +1325,7 @@ int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_st
   if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_ctrl_init: n_step_t > 0 without step_t_dev");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(xde_ctrl_init_kernel, dim3(1), dim3(64), 0, st, ctrl, *params, t_start, first_step, n_out,
-                     t_span_dev, step_t_dev, t_stage_out);
+                     t_span_dev, step_t_dev, t_stage_out, seq0);
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }
@@ -1258,6 +1335,45 @@ int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream
   hipStream_t st = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemcpyAsync(host_out, ctrl_dev, sizeof(xde_ctrl_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return XDE_OK;
+}
+
+int xde_host_alloc(int64_t bytes, void** ptr_out) {
+  if (bytes <= 0 || !ptr_out) return fail(XDE_EBADARG, "xde_host_alloc: bad argument");
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, size_t(bytes), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(p, 0, size_t(bytes));
+  *ptr_out = p;
+  return XDE_OK;
+}
+
+int xde_host_free(void* ptr) {
+  if (!ptr) return XDE_OK;
+  HIP_TRY(hipHostFree(ptr));
+  return XDE_OK;
+}
+
+int xde_ctrl_wait(const xde_ctrl_t* host_mirror, int64_t seq, double timeout_ms, xde_ctrl_t* host_out) {
+  if (!host_mirror || !host_out || seq < 0) return fail(XDE_EBADARG, "xde_ctrl_wait: bad argument");
+  const xde_ctrl_t* slot = host_mirror + (seq % XDE_MIRROR_SLOTS);
+  const auto t_begin = std::chrono::steady_clock::now();
+  uint64_t spins = 0;
+  for (;;) {
+    int64_t cur = __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE);
+    if (cur == seq) break;
+    if (cur > seq) return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot already overwritten by a later launch");
+    if ((++spins & 0x3ff) == 0) {
+      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+      if (ms > timeout_ms) return fail(XDE_ETIMEOUT, "xde_ctrl_wait: timed out waiting for the controller launch");
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  memcpy(host_out, slot, sizeof(xde_ctrl_t));
+  // the slot may have been overwritten while copying (only if the host lags >= SLOTS launches behind)
+  if (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != seq)
+    return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot overwritten while reading");
   return XDE_OK;
 }
 
@@ -1301,14 +1417,14 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
   if (blocks > grid_cap()) blocks = grid_cap();
   if (blocks < 1) blocks = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  ProfScope prof(XDE_KID_DENSE, st, double(nk + 4) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
+  ProfScope prof(XDE_KID_DENSE, double(nk + 4) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
 #define LAUNCH_DENSE(T, TT)                                                     \
   do {                                                                          \
     if (vec)                                                                    \
-      hipLaunchKernelGGL((xde_dense_kernel<T, TT, true>), g, b, 0, st, a);      \
+      XDE_LAUNCH((xde_dense_kernel<T, TT, true>), g, b, st, prof, a);      \
     else                                                                        \
-      hipLaunchKernelGGL((xde_dense_kernel<T, TT, false>), g, b, 0, st, a);     \
+      XDE_LAUNCH((xde_dense_kernel<T, TT, false>), g, b, st, prof, a);     \
   } while (0)
   if (dtype == XDE_F32) {
     if (time_dtype == XDE_F32) LAUNCH_DENSE(float, float);
@@ -1325,8 +1441,10 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
 int xde_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
+  g_prof_period = on > 1 ? on : 1;
   if (on) {
     for (int i = 0; i < XDE_KID_COUNT; ++i) {
+      g_prof_launches[i] = 0;
       g_prof_bytes[i] = 0;
       g_prof_counts[i] = 0;
       g_prof_ms[i] = 0;

@@ -214,6 +214,7 @@ class NumpyDoubleBackend:
     def rk_control(self, ctrl, params, ws, sums, t_span_dev, step_t_dev, t_stage):
         self.launches.append("control")
         c, p = self._c(ctrl), params
+        c.seq += 1
         if c.done:
             return
         if sums is not None:
