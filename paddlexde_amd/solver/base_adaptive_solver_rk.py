@@ -74,6 +74,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         controller="I",
         pi_beta=0.04,
         process_group=None,
+        record_trace=False,
         _xde_segments=None,
         **kwargs,
     ):
@@ -104,6 +105,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self.controller = controller
         self.pi_beta = float(pi_beta)
         self.process_group = process_group
+        self.record_trace = bool(record_trace)
+        self.trace = []  # (t0, dt, ratio, accept) per attempted step when record_trace is set
 
         self.backend = _hip.get_backend()
         self.nfe = 0
@@ -363,6 +366,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._n_attempts += 1
             done += 1
             c = be.ctrl_read(self._ctrl)  # the step's one host sync
+            if self.record_trace:
+                self.trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
             if c.accept:
                 if c.out_end > c.out_begin and self._solution is not None:
                     self._dense(self._solution, base, y1, ks)
@@ -375,6 +380,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
 
     def _resolve_pending(self):
         c = self.backend.ctrl_wait(self._pending[2])
+        if self.record_trace:
+            self.trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
         if c.accept:
             self._base = (self._pending[0], self._pending[1][-1])
         self._pending = None

@@ -56,6 +56,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
         self.backend = _hip.get_backend()
         self.nfe = 0
         self._dt = None  # host dt (numpy scalar of the time dtype) while integrate() drives step()
+        self._t0_host = None  # host t0 of the current step while integrate() drives step()
         self._row = None  # current row of the uploaded time table
         self._y1_out = None  # where the step's final combine should write (a slice of the output)
         self._tdev_cache = {}
@@ -140,6 +141,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
             for i in range(1, pred_len):
                 t0, t1 = t_dev[i - 1 : i], t_dev[i : i + 1]
                 self._dt = t_host[i] - t_host[i - 1]
+                self._t0_host = t_host[i - 1]
                 self._row = table[i - 1] if table is not None else None
                 dst = out.narrow(-2, i * L, L)
                 self._y1_out = dst.view(y0.shape) if (direct and dst.data_ptr() % 16 == 0) else None
@@ -148,6 +150,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
                     # base_fixed_solver.py:133-137: an extra step(t1, t1, y1) supplies dy1; the Hermite cubic
                     # evaluated at t == t1 is y1 itself (h00 = h10 = h11 = 0, h01 = 1), so only the NFE matter.
                     self._dt = t_host[i] - t_host[i]
+                    self._t0_host = t_host[i]
                     self._row = None
                     self._y1_out = None
                     self.step(t1, t1, y1)
@@ -157,6 +160,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
                 y0 = y1
         finally:
             self._dt = None
+            self._t0_host = None
             self._row = None
             self._y1_out = None
         return out
@@ -169,7 +173,8 @@ class FixedSolver(metaclass=abc.ABCMeta):
     def rk4_step_func(self, t0, t1, y0, f0=None):
         dt = self._host_dt(t0, t1)
         half_dt = dt * 0.5
-        dtt, hdt, t_half = self._tdev(dt, t0), self._tdev(half_dt, t0), self._tdev(float(t0.item()) + half_dt, t0)
+        t0h = self._t0_host if self._t0_host is not None else type(dt)(t0.item())
+        dtt, hdt, t_half = self._tdev(dt, t0), self._tdev(half_dt, t0), self._tdev(t0h + half_dt, t0)
         k1 = f0
         if k1 is None:
             k1 = self._f(t0, dtt, y0)

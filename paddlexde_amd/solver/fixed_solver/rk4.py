@@ -3,7 +3,16 @@ from ..base_fixed_solver import FixedSolver, _one_third, _two_thirds
 
 
 class RK4(FixedSolver):
+    """``options={"variant": "classic"}`` selects the textbook RK4 (``rk4_step_func``, base_fixed_solver.py:146-164,
+    which the reference defines but never uses); the default "alt" is what the reference's RK4 runs."""
+
     order = 4
+
+    def __init__(self, *args, variant="alt", **kwargs):
+        super().__init__(*args, **kwargs)
+        if variant not in ("alt", "classic"):
+            raise ValueError("variant must be 'alt' (reference) or 'classic'")
+        self.variant = variant
 
     @staticmethod
     def _time_values(dt):
@@ -24,4 +33,6 @@ class RK4(FixedSolver):
     def step(self, t0, t1, y0):
         dt = self._host_dt(t0, t1)
         f0 = self._f(t0, self._times(t0, dt)[0], y0)
+        if self.variant == "classic":
+            return self.rk4_step_func(t0, t1, y0, f0=f0), f0
         return self.rk4_alt_step_func(t0, t1, y0, f0=f0), f0

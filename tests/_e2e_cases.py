@@ -307,6 +307,64 @@ def test_tuple_state_vs_oracle(dev):
 
 
 # ----------------------------------------------------------------------------------------------
+# committed golden vectors (tests/golden/*.npz, generated from the oracle by tests/golden/make_golden.py)
+# ----------------------------------------------------------------------------------------------
+def _golden(name):
+    import os
+
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+
+
+def test_golden_spiral_rk4(dev):
+    z = _golden("spiral_rk4")
+    got = odeint(P.spiral_torch, torch.from_numpy(z["y0"]).to(dev), torch.from_numpy(z["t"]).to(dev), solver=RK4)
+    assert np.array_equal(got.cpu().numpy(), z["sol"])  # bit-exact: 999 steps x 4 combines
+
+
+def test_golden_fixed_small(dev):
+    z = _golden("spiral_fixed_small")
+    y0, t = torch.from_numpy(z["y0"]).to(dev), torch.from_numpy(z["t"]).to(dev)
+    for name, cls, opts in [("euler", Euler, {}), ("midpoint", Midpoint, {}), ("rk4", RK4, {}), ("rk4_classic", RK4, {"variant": "classic"})]:
+        got = odeint(P.spiral_torch, y0, t, solver=cls, options={"norm": _rms_norm, **opts})
+        assert np.array_equal(got.cpu().numpy(), z["sol_" + name]), name
+
+
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+def test_golden_linear_dopri5_trace(dev, pipeline):
+    """Step-for-step: (t0, dt, ratio, accept) of every attempted step against the oracle's trace."""
+    from paddlexde_amd.xde import BaseODE
+
+    z = _golden("linear_dopri5_f64")
+    A = torch.from_numpy(z["A"]).to(dev)
+    y0 = torch.from_numpy(z["y0"]).to(dev)
+    t = torch.from_numpy(z["t"])
+    xde = BaseODE(lambda t_, y: y @ A.T, y0=y0, t_span=t)
+    s = Dopri5(xde=xde, y0=y0, rtol=1e-7, atol=1e-9, norm=_rms_norm, dtype=torch.float64, pipeline=pipeline, record_trace=True)
+    got = s.integrate(t)
+    assert P.parity_ok(got.cpu().numpy(), z["sol"], rtol=1e-10, atol=1e-12)
+    tr = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
+    assert tr.shape == z["trace"].shape
+    assert np.array_equal(tr[:, 3], z["trace"][:, 3])  # identical accept/reject decisions
+    assert np.allclose(tr[:, :2], z["trace"][:, :2], rtol=1e-9, atol=0)  # t0, dt
+    assert np.allclose(tr[:, 2], z["trace"][:, 2], rtol=1e-6)  # error ratio (cancellation-limited)
+    assert s.stats["nfe"] == int(z["nfe"])
+
+
+def test_golden_vdp_counts(dev):
+    from paddlexde_amd.xde import BaseODE
+
+    z = _golden("vdp_dopri5_f64")
+    y0 = torch.from_numpy(z["y0"]).to(dev)
+    t = torch.from_numpy(z["t"])
+    xde = BaseODE(P.vdp_torch(float(z["mu"])), y0=y0, t_span=t)
+    s = Dopri5(xde=xde, y0=y0, rtol=1e-6, atol=1e-8, norm=_rms_norm, dtype=torch.float64, record_trace=True)
+    got = s.integrate(t)
+    assert [s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]] == list(z["counts"])
+    assert int(z["counts"][1]) > 0
+    assert P.parity_ok(got.cpu().numpy(), z["sol"], rtol=1e-8, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties (the oracle cannot run these in seconds)
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.gpu

@@ -1,0 +1,78 @@
+"""The C-ABI shared library loads on a box without a GPU and exports every symbol include/xde_hip.h declares;
+the ctypes mirrors of the ABI structs have the header's layout.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from paddlexde_amd import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "xde_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(xde_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_declares_what_python_binds():
+    assert _declared() == sorted(_hip.SYMBOLS)
+
+
+def test_library_loads_and_exports_every_symbol():
+    lib = _hip.load_library()
+    for sym in _declared():
+        assert hasattr(lib, sym), sym
+    assert lib.xde_abi_version() == 1
+
+
+def test_struct_layouts_match():
+    lib = _hip.load_library()
+    assert lib.xde_sizeof_ctrl() == C.sizeof(_hip.XdeCtrl) == 288
+    assert _hip.XdeCtrl.seq.offset % 8 == 0
+    assert lib.xde_workspace_bytes() > 0
+    # constants mirrored from the header
+    src = open(HEADER).read()
+    for name, val in [("XDE_MAX_K", _hip.XDE_MAX_K), ("XDE_MAX_SEG", _hip.XDE_MAX_SEG), ("XDE_MAX_STAGE", _hip.XDE_MAX_STAGE),
+                      ("XDE_MIRROR_SLOTS", _hip.XDE_MIRROR_SLOTS)]:
+        assert int(re.search(r"#define {}\s+(\d+)".format(name), src).group(1)) == val
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host before any HIP call (safe on a CPU-only box)."""
+    lib = _hip.load_library()
+    assert lib.xde_stage_combine(None, None, None, None, None, None, 1, 0, 1.0, 0.0, None, 8, 0, None) == _hip.XDE_EBADARG
+    assert b"null pointer" in lib.xde_last_error()
+    assert lib.xde_norm_finalize(None, 0, None, None) == _hip.XDE_EBADARG
+    assert lib.xde_ctrl_wait(None, 0, 1.0, None) == _hip.XDE_EBADARG
+
+
+def test_product_fails_loudly_without_gpu_or_library(monkeypatch):
+    import torch
+
+    from paddlexde_amd import Dopri5, RK4, odeint
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    y0 = torch.ones(4, 2)
+    t = torch.tensor([0.0, 1.0])
+    with pytest.raises(_hip.XdeError, match="no CPU path"):
+        odeint(lambda t_, y: -y, y0, t, solver=Dopri5)
+    with pytest.raises(_hip.XdeError, match="no CPU path"):
+        odeint(lambda t_, y: -y, y0, t, solver=RK4)
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libxde_hip.so")
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "_backend", None)
+    with pytest.raises(_hip.XdeError, match="is missing"):
+        _hip.get_backend()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "paddlexde_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("no oracle", ""), os.path.join(dirpath, f)

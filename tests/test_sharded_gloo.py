@@ -1,0 +1,87 @@
+"""N>1 path on CPU: world_size-2 `gloo` run of the batch-sharded Dopri5 (rows split across ranks, the ONLY
+data-path collective is the all-reduce of the error-norm partial sums per attempted step).  Uses the numpy test
+double for the kernels; checks that (i) both ranks take the identical step sequence, (ii) the sharded solution
+equals the unsharded one on the same rows, (iii) the initial step uses the global norm too."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from . import problems as P
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem(B, D):
+    A = P.skew_matrix(D)
+    y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(0))
+    # rows of very different magnitude: each shard alone would choose a different step size
+    y0[B // 2 :] *= 25.0
+    return A, y0
+
+
+def _solve(y0, A, pg, norm_name="rms", pipeline="sync"):
+    from paddlexde_amd import Dopri5
+    from paddlexde_amd.utils import _linf_norm, _rms_norm
+    from paddlexde_amd.xde import BaseODE
+
+    t = torch.linspace(0.0, 1.0, 4)
+    xde = BaseODE(lambda t_, y: y @ A.T, y0=y0, t_span=t)
+    s = Dopri5(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm if norm_name == "rms" else _linf_norm, process_group=pg,
+               record_trace=True, pipeline=pipeline)
+    return s.integrate(t), s
+
+
+def _worker(rank, world, port, out_dir, norm_name, pipeline):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from paddlexde_amd import _hip
+
+        from ._cpu_double import NumpyDoubleBackend
+
+        _hip._set_backend_for_testing(NumpyDoubleBackend())
+        torch.set_num_threads(1)
+        B, D = 64, 16
+        A, y0 = _problem(B, D)
+        rows = slice(rank * B // world, (rank + 1) * B // world)
+        sol, s = _solve(y0[rows].contiguous(), A, True, norm_name, pipeline)
+        np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), sol=sol.numpy(), trace=np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("norm_name,pipeline", [("rms", "sync"), ("rms", "lag"), ("linf", "sync")])
+def test_two_rank_sharded_equals_unsharded(tmp_path, cpu_double, norm_name, pipeline):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), norm_name, pipeline), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # (i) lock-step: identical (t0, dt, ratio, accept) on both ranks, bit for bit
+    assert np.array_equal(r0["trace"], r1["trace"])
+    # (ii) equals the single-process run over the whole batch
+    B, D = 64, 16
+    A, y0 = _problem(B, D)
+    full, s = _solve(y0, A, None, norm_name, pipeline)
+    full = full.numpy()
+    tr = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
+    assert tr.shape == r0["trace"].shape
+    assert np.array_equal(tr[:, 3], r0["trace"][:, 3])
+    assert np.allclose(tr[:, :3], r0["trace"][:, :3], rtol=1e-6)
+    got = np.concatenate([r0["sol"], r1["sol"]], axis=1)
+    assert P.rel_err(got, full) <= 1e-6
+    # (iii) the shards really are coupled: the small-magnitude shard alone would have taken different steps
+    alone, s_alone = _solve(y0[: B // 2].contiguous(), A, None, norm_name, pipeline)
+    assert len(s_alone.trace) != len(s.trace) or not np.allclose([x[1] for x in s_alone.trace], tr[:, 1])
