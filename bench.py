@@ -72,6 +72,90 @@ def cpu_baseline(D, budget_s=12.0):
     }
 
 
+def side_workload(args):
+    """Configs 3 and 5 of BASELINE.json: latency-bound (state of 16-64 KB), reported as time per step."""
+    import torch.nn as nn
+
+    from paddlexde_amd import Dopri5, odeint_adjoint
+    from paddlexde_amd.utils import _rms_norm
+    from paddlexde_amd.xde import BaseODE
+
+    dev = torch.device("cuda", 0)
+    if args.workload == "c5":
+        mu = 1000.0
+
+        def vdp(t, y):
+            x, v = y[..., 0], y[..., 1]
+            return torch.stack([v, mu * (1 - x * x) * v - x], dim=-1)
+
+        y0 = (torch.tensor([2.0, 0.0]) + 0.01 * torch.randn(4096, 2, generator=torch.Generator().manual_seed(0))).to(dev)
+        t = torch.tensor([0.0, 1.0])
+        res = {}
+        for dtype in (torch.float32, torch.float64):
+            y = y0.to(dtype)
+            for rep in range(2):  # first repetition warms allocator / kernels up
+                xde = BaseODE(vdp, y0=y, t_span=t)
+                s = Dopri5(xde=xde, y0=y, rtol=1e-5, atol=1e-7, norm=_rms_norm, max_num_steps=10**6, pipeline=args.pipeline,
+                           dtype=dtype)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sol = s.integrate(t)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            st = s.stats
+            res[str(dtype).split(".")[-1]] = {"n_accept": st["n_accept"], "n_reject": st["n_reject"], "nfe": st["nfe"],
+                                              "seconds": el, "us_per_attempted_step": 1e6 * el / max(st["n_steps"], 1),
+                                              "finite": bool(torch.isfinite(sol).all())}
+        print(json.dumps({"metric": "us per attempted dopri5 step (latency-bound)", "workload": "c5: Van der Pol mu=1000, batch 4096 x 2, "
+                          "t in [0,1], rtol 1e-5 atol 1e-7", "pipeline": args.pipeline, "results": res}))
+        return
+
+    class ODEFunc(nn.Module):  # example/ode_demo.py:17-33
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(42)
+            self.net = nn.Sequential(nn.Linear(2, 50), nn.Tanh(), nn.Linear(50, 2))
+            for m in self.net:
+                if isinstance(m, nn.Linear):
+                    with torch.no_grad():
+                        m.weight.copy_(0.1 * torch.randn(m.weight.shape, generator=g))
+                        m.bias.zero_()
+
+        def forward(self, t, y):
+            return self.net(y**3)
+
+    func = ODEFunc().to(dev)
+    y0 = (torch.rand(8192, 2, generator=torch.Generator().manual_seed(0)) * 4 - 2).to(dev)
+    t = torch.linspace(0.0, 25.0, 1000)[:32].to(dev)
+    A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], device=dev)
+    res = {}
+    from paddlexde_amd import RK4, odeint
+
+    with torch.no_grad():
+        y_true = odeint(lambda t_, y: (y**3) @ A, y0, t, solver=RK4)  # [8192*32... fixed layout: [T*B?]
+    for name, solver in (("dopri5", Dopri5), ("rk4", RK4)):
+        for rep in range(2):
+            for p in func.parameters():
+                p.grad = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opts = {"norm": _rms_norm}
+            if name == "dopri5":
+                opts["pipeline"] = args.pipeline
+            pred = odeint_adjoint(func, y0, t, solver=solver, rtol=1e-5, atol=1e-7, options=opts)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            target = y_true if name == "rk4" else pred.detach() * 0.0
+            loss = torch.mean(torch.abs(pred - target))
+            loss.backward()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+        gn = float(sum(p.grad.double().pow(2).sum() for p in func.parameters()).sqrt())
+        res[name] = {"forward_s": t1 - t0, "backward_s": t2 - t1, "grad_norm": gn, "n_params": sum(p.numel() for p in func.parameters())}
+    print(json.dumps({"metric": "seconds per forward / adjoint backward (latency-bound)", "workload": "c3: spiral neural-ODE (2-50-2 MLP on y^3), "
+                      "batch 8192, 32 output times, odeint_adjoint", "pipeline": args.pipeline, "results": res}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,13 +163,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=65536, help="rows per GPU")
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--pipeline", default="lag", choices=["sync", "lag"])
+    ap.add_argument("--pipeline", default="lag", choices=["sync", "lag", "graph"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+                    help="c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
+                         "batch 8192 (latency-bound, reports ms per fwd+bwd and per attempted step); c5: stiff Van der Pol "
+                         "mu=1000 batch 4096 (step-rejection stress, reports accepted/rejected and us per step)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--event-period", type=int, default=5,
                     help="time every p-th launch of each kernel inside the timed region (5 is coprime with the 6 "
                          "combines per step, so all stages are sampled evenly)")
     args = ap.parse_args()
+
+    if args.workload != "c2":
+        return side_workload(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

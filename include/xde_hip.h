@@ -247,6 +247,15 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
                    int dtype, int64_t expect_step, void* stream);
 
 /*
+ * Predicated commit for the hipGraph pipeline (operand addresses are baked into a captured graph, so the
+ * host cannot swap pointers): if ctrl->accept then y0_dst <- y1_src and f0_dst <- f1_src — the state update
+ * `(t, y, f) <- (t1, y1, f1)` of AdaptiveRKSolver._adaptive_step (solver/base_adaptive_solver_rk.py:258-277).
+ * Costs 4*N*s extra bytes on accepted steps; meant for launch-bound (small-state) problems.
+ */
+int xde_commit(const xde_ctrl_t* ctrl, void* y0_dst, const void* y1_src, void* f0_dst, const void* f1_src,
+               int64_t n, int dtype, void* stream);
+
+/*
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline figure).  xde_prof_enable(period): 0 = off; p >= 1 = every p-th launch of each kernel id is
  * launched with a start/stop event pair stamped by the dispatch itself (hipExtLaunchKernelGGL), so the
@@ -259,7 +268,8 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
 #define XDE_KID_DENSE 3
 #define XDE_KID_SCALEDNORM 4
 #define XDE_KID_FINALIZE 5
-#define XDE_KID_COUNT 6
+#define XDE_KID_COMMIT 6
+#define XDE_KID_COUNT 7
 int xde_prof_enable(int on);
 int xde_prof_collect(int64_t* counts_out, double* ms_out, double* bytes_out);
 

@@ -19,7 +19,7 @@ XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
 COMBINE_RK, COMBINE_FUSE, COMBINE_WFUSE = 0, 1, 2
 NORM_RMS, NORM_LINF = 0, 1
 STATUS_OK, STATUS_DT_UNDERFLOW, STATUS_NONFINITE, STATUS_MAX_STEPS = 0, 1, 2, 3
-KID_NAMES = ("combine", "errnorm", "control", "dense", "scalednorm", "finalize")
+KID_NAMES = ("combine", "errnorm", "control", "dense", "scalednorm", "finalize", "commit")
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libxde_hip.so")
 
@@ -41,6 +41,7 @@ SYMBOLS = (
     "xde_host_free",
     "xde_ctrl_wait",
     "xde_dense_eval",
+    "xde_commit",
     "xde_prof_enable",
     "xde_prof_collect",
 )
@@ -168,6 +169,8 @@ def load_library():
         lib.xde_ctrl_read.argtypes = [vp, C.POINTER(XdeCtrl), vp]
         lib.xde_dense_eval.restype = i32
         lib.xde_dense_eval.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i64, vp]
+        lib.xde_commit.restype = i32
+        lib.xde_commit.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
         lib.xde_prof_enable.restype = i32
         lib.xde_prof_enable.argtypes = [i32]
         lib.xde_prof_collect.restype = i32
@@ -220,6 +223,7 @@ class HipBackend:
         self.lib = load_library()
         self._mirror_pool = []  # pinned host mirror rings, reused across solver instances
         self._mirrors = {}  # device ctrl pointer -> _Mirror
+        self._capturing = False
 
     # -- host mirror ring of the control block (see xde_rk_control / xde_ctrl_wait) -------------
     class _Mirror:
@@ -320,7 +324,7 @@ class HipBackend:
                                      _ptr(step_t_dev), t_stage.data_ptr(), m.ptr if m is not None else None,
                                      self._stream(ctrl))
         self._check(rc, "xde_rk_control")
-        if m is not None:
+        if m is not None and not self._capturing:
             m.seq += 1
 
     def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage):
@@ -368,6 +372,34 @@ class HipBackend:
             dtype_code(y0.dtype), int(expect_step), self._stream(y0),
         )
         self._check(rc, "xde_dense_eval")
+
+    def commit(self, ctrl, y0_dst, y1_src, f0_dst, f1_src):
+        self._require_device(ctrl, y0_dst, y1_src, f0_dst, f1_src)
+        rc = self.lib.xde_commit(ctrl.data_ptr(), y0_dst.data_ptr(), y1_src.data_ptr(), f0_dst.data_ptr(), f1_src.data_ptr(),
+                                 y0_dst.numel(), dtype_code(y0_dst.dtype), self._stream(y0_dst))
+        self._check(rc, "xde_commit")
+
+    # -- hipGraph capture of one attempted step ---------------------------------------------------
+    class _Graph:
+        def __init__(self, backend, graph, ctrl):
+            self.backend, self.graph, self.ctrl = backend, graph, ctrl
+
+        def replay(self):
+            self.graph.replay()
+            m = self.backend._mirrors.get(self.ctrl.data_ptr())
+            if m is not None:
+                m.seq += 1  # one controller launch per replay
+
+    def capture(self, body, ctrl):
+        """Record ``body()`` (kernels of this library + the framework ops of the user's func) into a hipGraph."""
+        g = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g):
+                body()
+        finally:
+            self._capturing = False
+        return HipBackend._Graph(self, g, ctrl)
 
     # -- profiling ---------------------------------------------------------------------------
     def prof_enable(self, period=1):

@@ -846,7 +846,12 @@ __global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_
   if (threadIdx.x == 0) {
     xde_ctrl_t z = zs;  // all controller arithmetic runs on registers
     z.seq += 1;
-    if (!z.done) {  // a speculative attempt past the last output is a no-op
+    if (z.done) {
+      // an attempt enqueued past the last output (speculative / graph replay) is a no-op: nothing to commit,
+      // no rows to emit
+      z.accept = 0;
+      z.out_begin = z.out_end = z.next_out;
+    } else {
       double ratio = norm_from_sums(seg_val, p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, z.ratio_seg);
       double nf = 0.0;
       for (int s = 0; s < p.n_seg; ++s) nf += seg_nf[s];
@@ -993,6 +998,32 @@ __global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// predicated commit (hipGraph pipeline): (y0, f0) <- (y1, f1) when the step was accepted
+// ------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_commit_kernel(const xde_ctrl_t* c, T* __restrict__ y0, const T* __restrict__ y1,
+                                                            T* __restrict__ f0, const T* __restrict__ f1, int64_t n) {
+  if (!c->accept) return;
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const int64_t nvec = n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P a = P::load(y1, i);
+    P b = P::load(f1, i);
+    a.store(y0, i);
+    b.store(f0, i);
+  }
+  if (VEC) {
+    const int64_t i = nvec * W + threadIdx.x;
+    if (blockIdx.x == 0 && i < n) {
+      y0[i] = y1[i];
+      f0[i] = f1[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -1045,8 +1076,14 @@ struct ProfScope {
   }
 };
 
-#define XDE_LAUNCH(kernel, grid, block, st, prof, ...) \
-  hipExtLaunchKernelGGL(kernel, grid, block, 0, st, (prof).start, (prof).stop, 0, __VA_ARGS__)
+// plain launch unless this launch is being timed (the plain form is what stream capture records)
+#define XDE_LAUNCH(kernel, grid, block, st, prof, ...)                                                       \
+  do {                                                                                                       \
+    if ((prof).on)                                                                                           \
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, st, (prof).start, (prof).stop, 0, __VA_ARGS__);         \
+    else                                                                                                     \
+      hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                           \
+  } while (0)
 
 int build_segmap(const xde_segments_t* segs, int width, bool vec, SegMap* m, int* nblocks_out) {
   if (!segs || segs->n_seg < 1 || segs->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, "segments: n_seg out of range");
@@ -1434,6 +1471,39 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
     else LAUNCH_DENSE(double, double);
   }
 #undef LAUNCH_DENSE
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_commit(const xde_ctrl_t* ctrl, void* y0_dst, const void* y1_src, void* f0_dst, const void* f1_src, int64_t n,
+               int dtype, void* stream) {
+  if (!ctrl || !y0_dst || !y1_src || !f0_dst || !f1_src) return fail(XDE_EBADARG, "xde_commit: null pointer");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_commit: bad dtype");
+  if (n < 0) return fail(XDE_EBADARG, "xde_commit: negative n");
+  if (n == 0) return XDE_OK;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const bool vec = aligned16(y0_dst) && aligned16(y1_src) && aligned16(f0_dst) && aligned16(f1_src);
+  const int64_t work = vec ? (n + width - 1) / width : n;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_COMMIT, 4.0 * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+  if (dtype == XDE_F32) {
+    if (vec)
+      XDE_LAUNCH((xde_commit_kernel<float, true>), g, b, st, prof, ctrl, static_cast<float*>(y0_dst),
+                 static_cast<const float*>(y1_src), static_cast<float*>(f0_dst), static_cast<const float*>(f1_src), n);
+    else
+      XDE_LAUNCH((xde_commit_kernel<float, false>), g, b, st, prof, ctrl, static_cast<float*>(y0_dst),
+                 static_cast<const float*>(y1_src), static_cast<float*>(f0_dst), static_cast<const float*>(f1_src), n);
+  } else {
+    if (vec)
+      XDE_LAUNCH((xde_commit_kernel<double, true>), g, b, st, prof, ctrl, static_cast<double*>(y0_dst),
+                 static_cast<const double*>(y1_src), static_cast<double*>(f0_dst), static_cast<const double*>(f1_src), n);
+    else
+      XDE_LAUNCH((xde_commit_kernel<double, false>), g, b, st, prof, ctrl, static_cast<double*>(y0_dst),
+                 static_cast<const double*>(y1_src), static_cast<double*>(f0_dst), static_cast<const double*>(f1_src), n);
+  }
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

@@ -81,8 +81,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         super().__init__(xde=xde, dtype=dtype, y0=y0, **kwargs)
         if jump_t is not None:
             raise NotImplementedError("jump_t calls a non-existent self.func in the reference (SURVEY D7)")
-        if pipeline not in ("sync", "lag"):
-            raise ValueError("pipeline must be 'sync' or 'lag'")
+        if pipeline not in ("sync", "lag", "graph"):
+            raise ValueError("pipeline must be 'sync', 'lag' or 'graph'")
         if controller not in ("I", "PI"):
             raise ValueError("controller must be 'I' (reference) or 'PI' (opt-in)")
         if dtype not in (torch.float32, torch.float64):
@@ -175,11 +175,17 @@ class AdaptiveRKSolver(AdaptiveSolver):
         import torch.distributed as dist
 
         group = None if self.process_group is True else self.process_group
+        buf = sums
+        staged = sums.is_cuda and dist.get_backend(group) == "gloo"
+        if staged:  # rehearsal transport (several ranks on one GPU): gloo reduces on the host
+            buf = sums.cpu()
         if self._norm_kind == _hip.NORM_RMS:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         else:
-            dist.all_reduce(sums[: _hip.XDE_MAX_SEG], op=dist.ReduceOp.MAX, group=group)
-            dist.all_reduce(sums[_hip.XDE_MAX_SEG :], op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(buf[: _hip.XDE_MAX_SEG], op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(buf[_hip.XDE_MAX_SEG :], op=dist.ReduceOp.SUM, group=group)
+        if staged:
+            sums.copy_(buf)
 
     def _global_counts(self):
         counts = list(self._seg_count_local)
@@ -187,7 +193,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
             import torch.distributed as dist
 
             group = None if self.process_group is True else self.process_group
-            c = torch.tensor(counts, dtype=torch.float64, device=self.y0.device)
+            cdev = "cpu" if dist.get_backend(group) == "gloo" else self.y0.device
+            c = torch.tensor(counts, dtype=torch.float64, device=cdev)
             dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
             counts = c.tolist()
         return counts
@@ -335,8 +342,10 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._pending = None  # lag pipeline: (y1, ks, read handle) of the newest, unresolved attempt
         self._n_attempts = 0
         self._last = None
+        self._graph = None
         self.advance(None)
         self._solution = None
+        self._graph = None  # releases the captured graph and its private memory pool
 
     def advance(self, max_attempts=None):
         """Run attempted steps until every output is produced (``max_attempts=None``) or exactly
@@ -349,17 +358,22 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._pending = None
             self._n_attempts = 0
             self._last = None
+            self._graph = None
         if self.pipeline == "lag":
             c = self._advance_lag(max_attempts)
+        elif self.pipeline == "graph":
+            c = self._advance_graph(max_attempts)
         else:
             c = self._advance_sync(max_attempts)
         self._finish(c, self._base)
         return c
 
-    def _advance_sync(self, max_attempts):
+    def _advance_sync(self, max_attempts, stop_on_done=None):
         be = self.backend
         c = self._last
         done = 0
+        if stop_on_done is None:
+            stop_on_done = max_attempts is None
         while max_attempts is None or done < max_attempts:
             base = self._base
             y1, ks = self._attempt(base)
@@ -373,10 +387,63 @@ class AdaptiveRKSolver(AdaptiveSolver):
                     self._dense(self._solution, base, y1, ks)
                 self._base = (y1, ks[-1])
             self._raise_status(c)
-            if c.done and max_attempts is None:
+            if c.done and stop_on_done:
                 break
         self._last = c
         return c
+
+    GRAPH_WARMUP_ATTEMPTS = 2
+    GRAPH_LOOKAHEAD = 2  # replays in flight before the host waits (ring has XDE_MIRROR_SLOTS = 4 slots)
+
+    def _advance_graph(self, max_attempts):
+        be = self.backend
+        to_end = max_attempts is None
+        done = 0
+        if getattr(self, "_graph", None) is None:
+            # eager warm-up (also lets short integrations finish without paying for a capture)
+            n_warm = self.GRAPH_WARMUP_ATTEMPTS if to_end else min(self.GRAPH_WARMUP_ATTEMPTS, max_attempts)
+            c = self._advance_sync(n_warm, stop_on_done=to_end)
+            done += n_warm
+            if (to_end and c.done) or (not to_end and done >= max_attempts):
+                return c
+            y0, f0 = self._base
+            self._gbase = (y0.clone(), f0.clone())  # static operands of the captured step
+
+            def body():
+                nfe0 = self.nfe  # evaluations are accounted per resolved replay below, not while recording
+                base = self._gbase
+                y1, ks = self._attempt(base)
+                if self._solution is not None:
+                    self._dense(self._solution, base, y1, ks)
+                be.commit(self._ctrl, base[0], y1, base[1], ks[-1])
+                self.nfe = nfe0
+
+            self._graph = be.capture(body, self._ctrl)
+            self._base = self._gbase
+        pending = collections.deque()
+        issued = 0
+        finished = False
+        while True:
+            budget = to_end or (done + issued) < max_attempts
+            if not finished and budget and len(pending) < self.GRAPH_LOOKAHEAD:
+                self._graph.replay()
+                pending.append(be.ctrl_read_async(self._ctrl))
+                issued += 1
+                continue
+            if not pending:
+                break
+            c = be.ctrl_wait(pending.popleft())
+            if finished:
+                continue  # replays issued past the last output are device-side no-ops (controller `done` guard)
+            self._n_attempts += 1
+            self.nfe += self._n_stage
+            if self.record_trace:
+                self.trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
+            self._raise_status(c)
+            self._last = c
+            if c.done and to_end:
+                finished = True
+        return self._last
 
     def _resolve_pending(self):
         c = self.backend.ctrl_wait(self._pending[2])

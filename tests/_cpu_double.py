@@ -216,6 +216,8 @@ class NumpyDoubleBackend:
         c, p = self._c(ctrl), params
         c.seq += 1
         if c.done:
+            c.accept = 0
+            c.out_begin = c.out_end = c.next_out
             return
         if sums is not None:
             s = sums.numpy()
@@ -334,6 +336,23 @@ class NumpyDoubleBackend:
             xp = xp * x
             total = total + xp * ca
             out[r, :] = total
+
+    def commit(self, ctrl, y0_dst, y1_src, f0_dst, f1_src):
+        self.launches.append("commit")
+        if self._c(ctrl).accept:
+            y0_dst.copy_(y1_src)
+            f0_dst.copy_(f1_src)
+
+    class _Replayable:
+        def __init__(self, body):
+            self.body = body
+
+        def replay(self):
+            self.body()
+
+    def capture(self, body, ctrl):
+        # the double executes ops immediately: "capture" records the callable, each replay runs it
+        return NumpyDoubleBackend._Replayable(body)
 
     def prof_enable(self, on=True):
         pass

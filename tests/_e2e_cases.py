@@ -87,7 +87,7 @@ def _linear(B, D, dtype):
     return A, y0
 
 
-@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+@pytest.mark.parametrize("pipeline", ["sync", "lag", "graph"])
 @pytest.mark.parametrize("name", list(ADAPTIVE))
 def test_linear_adaptive_vs_oracle_fp64(dev, name, pipeline):
     """fp64 state and time: step decisions are robust, so the tight bar applies."""
@@ -130,6 +130,23 @@ def test_lag_pipeline_is_bitwise_equal_to_sync(dev):
     a = odeint(f, y0.to(dev), t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "pipeline": "sync"})
     b = odeint(f, y0.to(dev), t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "pipeline": "lag"})
     assert torch.equal(a, b)
+    c = odeint(f, y0.to(dev), t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "pipeline": "graph"})
+    assert torch.equal(a, c)
+
+
+def test_graph_pipeline_vdp_rejections(dev):
+    """hipGraph replay with rejected steps: the predicated commit must leave (y0, f0) untouched on reject."""
+    from paddlexde_amd.xde import BaseODE
+
+    z = _golden("vdp_dopri5_f64")
+    y0 = torch.from_numpy(z["y0"]).to(dev)
+    t = torch.from_numpy(z["t"])
+    xde = BaseODE(P.vdp_torch(float(z["mu"])), y0=y0, t_span=t)
+    s = Dopri5(xde=xde, y0=y0, rtol=1e-6, atol=1e-8, norm=_rms_norm, dtype=torch.float64, pipeline="graph", record_trace=True)
+    got = s.integrate(t)
+    assert [s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]] == list(z["counts"])
+    assert P.parity_ok(got.cpu().numpy(), z["sol"], rtol=1e-8, atol=1e-10)
+    assert len(s.trace) == len(z["trace"])
 
 
 def test_reverse_time_vs_oracle(dev):
@@ -329,7 +346,7 @@ def test_golden_fixed_small(dev):
         assert np.array_equal(got.cpu().numpy(), z["sol_" + name]), name
 
 
-@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+@pytest.mark.parametrize("pipeline", ["sync", "lag", "graph"])
 def test_golden_linear_dopri5_trace(dev, pipeline):
     """Step-for-step: (t0, dt, ratio, accept) of every attempted step against the oracle's trace."""
     from paddlexde_amd.xde import BaseODE

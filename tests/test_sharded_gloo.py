@@ -42,22 +42,24 @@ def _solve(y0, A, pg, norm_name="rms", pipeline="sync"):
     return s.integrate(t), s
 
 
-def _worker(rank, world, port, out_dir, norm_name, pipeline):
+def _worker(rank, world, port, out_dir, norm_name, pipeline, device="cpu"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from paddlexde_amd import _hip
 
-        from ._cpu_double import NumpyDoubleBackend
+        if device == "cpu":
+            from ._cpu_double import NumpyDoubleBackend
 
-        _hip._set_backend_for_testing(NumpyDoubleBackend())
+            _hip._set_backend_for_testing(NumpyDoubleBackend())
         torch.set_num_threads(1)
         B, D = 64, 16
         A, y0 = _problem(B, D)
         rows = slice(rank * B // world, (rank + 1) * B // world)
-        sol, s = _solve(y0[rows].contiguous(), A, True, norm_name, pipeline)
-        np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), sol=sol.numpy(), trace=np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace]))
+        sol, s = _solve(y0[rows].contiguous().to(device), A.to(device), True, norm_name, pipeline)
+        np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), sol=sol.cpu().numpy(),
+                 trace=np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace]))
     finally:
         dist.destroy_process_group()
 
@@ -85,3 +87,23 @@ def test_two_rank_sharded_equals_unsharded(tmp_path, cpu_double, norm_name, pipe
     # (iii) the shards really are coupled: the small-magnitude shard alone would have taken different steps
     alone, s_alone = _solve(y0[: B // 2].contiguous(), A, None, norm_name, pipeline)
     assert len(s_alone.trace) != len(s.trace) or not np.allclose([x[1] for x in s_alone.trace], tr[:, 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+def test_two_ranks_on_one_gpu_hip_kernels(tmp_path, pipeline):
+    """The same check with the HIP kernels: two processes share cuda:0, gloo carries the 32-double reduction
+    (RCCL refuses two ranks on one device; the 8-GPU run uses the nccl backend through the same code path)."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "rms", pipeline, "cuda:0"), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["trace"], r1["trace"])
+    B, D = 64, 16
+    A, y0 = _problem(B, D)
+    full, s = _solve(y0.to("cuda:0"), A.to("cuda:0"), None, "rms", pipeline)
+    tr = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
+    assert tr.shape == r0["trace"].shape and np.array_equal(tr[:, 3], r0["trace"][:, 3])
+    got = np.concatenate([r0["sol"], r1["sol"]], axis=1)
+    assert P.rel_err(got, full.cpu().numpy()) <= 1e-6
