@@ -159,6 +159,16 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
                            void* stream);
 
 /*
+ * Element-wise error ratio for user-supplied norm callables — the tensor `error_estimate / error_tol` of
+ * compute_error_ratio (utils/ode_utils.py:80-82) materialised once: out[i] = (sum_j k_j[i]*(dt*c_err_j)) /
+ * (atol + rtol*max(|y0[i]|,|y1[i]|)).  The caller applies its own norm to `out` with framework ops and hands the
+ * scalar to xde_rk_control through `sums` (norm_kind = XDE_NORM_LINF, n_seg = 1, sums[0] = value).
+ */
+int xde_error_ratio(void* out, const void* const* k, const double* c_err, int nk, const void* y0, const void* y1,
+                    double rtol, double atol, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype,
+                    void* stream);
+
+/*
  * Scaled norms for the initial-step heuristic — replaces `scale = atol + abs(y0) * rtol`,
  * `norm(a / scale)` of AdaptiveSolver.select_initial_step (solver/base_adaptive_solver.py:50-53,64).
  *   b == NULL: partials of norm(a / scale);  b != NULL: partials of norm((a - b) / scale).
@@ -245,6 +255,14 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
                    int nk, const void* y0, const void* y0_alt, const void* y1, const void* f1,
                    const xde_ctrl_t* ctrl, const double* t_span_dev, int time_dtype, int64_t n,
                    int dtype, int64_t expect_step, void* stream);
+
+/*
+ * Backward of xde_stage_combine for discretise-then-optimise training (the reference back-propagates through
+ * its eager ops, example/ode_demo.py:51-53): every input gradient of a combine is a scalar multiple of the
+ * output gradient, so one pass reads g once and writes outs[j] = g * factor_j * (dt_dev ? *dt_dev : 1).
+ */
+int xde_scale_fanout(void* const* outs, const void* g, const double* factors, int nout, const double* dt_dev,
+                     int64_t n, int dtype, void* stream);
 
 /*
  * Predicated commit for the hipGraph pipeline (operand addresses are baked into a captured graph, so the

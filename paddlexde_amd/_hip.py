@@ -31,6 +31,7 @@ SYMBOLS = (
     "xde_workspace_bytes",
     "xde_stage_combine",
     "xde_error_norm_partial",
+    "xde_error_ratio",
     "xde_scaled_norm_partial",
     "xde_norm_finalize",
     "xde_norm_result",
@@ -42,6 +43,7 @@ SYMBOLS = (
     "xde_ctrl_wait",
     "xde_dense_eval",
     "xde_commit",
+    "xde_scale_fanout",
     "xde_prof_enable",
     "xde_prof_collect",
 )
@@ -149,6 +151,8 @@ def load_library():
         lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp]
         lib.xde_error_norm_partial.restype = i32
         lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp]
+        lib.xde_error_ratio.restype = i32
+        lib.xde_error_ratio.argtypes = [vp, vpp, dp, i32, vp, vp, dbl, dbl, dbl, vp, i64, i32, vp]
         lib.xde_scaled_norm_partial.restype = i32
         lib.xde_scaled_norm_partial.argtypes = [vp, vp, vp, dbl, dbl, C.POINTER(XdeSegments), i32, i32, vp, i32, vp]
         lib.xde_norm_finalize.restype = i32
@@ -169,6 +173,8 @@ def load_library():
         lib.xde_ctrl_read.argtypes = [vp, C.POINTER(XdeCtrl), vp]
         lib.xde_dense_eval.restype = i32
         lib.xde_dense_eval.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i64, vp]
+        lib.xde_scale_fanout.restype = i32
+        lib.xde_scale_fanout.argtypes = [vpp, vp, dp, i32, vp, i64, i32, vp]
         lib.xde_commit.restype = i32
         lib.xde_commit.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
         lib.xde_prof_enable.restype = i32
@@ -299,6 +305,15 @@ class HipBackend:
         )
         self._check(rc, "xde_error_norm_partial")
 
+    def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None):
+        self._require_device(out, y0, y1, *ks)
+        if out.numel() == 0:
+            return
+        rc = self.lib.xde_error_ratio(out.data_ptr(), _ptr_array(ks), _dbl_array(c_err), len(ks), y0.data_ptr(), y1.data_ptr(),
+                                      float(rtol), float(atol), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype),
+                                      self._stream(out))
+        self._check(rc, "xde_error_ratio")
+
     def scaled_norm_partial(self, a, b, y0, rtol, atol, segs, norm_kind, ws, slot):
         self._require_device(a, b, y0, ws)
         rc = self.lib.xde_scaled_norm_partial(
@@ -372,6 +387,14 @@ class HipBackend:
             dtype_code(y0.dtype), int(expect_step), self._stream(y0),
         )
         self._check(rc, "xde_dense_eval")
+
+    def scale_fanout(self, outs, g, factors, dt_dev=None):
+        self._require_device(g, *outs)
+        if g.numel() == 0:
+            return
+        rc = self.lib.xde_scale_fanout(_ptr_array(outs), g.data_ptr(), _dbl_array(factors), len(outs), _ptr(dt_dev), g.numel(),
+                                       dtype_code(g.dtype), self._stream(g))
+        self._check(rc, "xde_scale_fanout")
 
     def commit(self, ctrl, y0_dst, y1_src, f0_dst, f1_src):
         self._require_device(ctrl, y0_dst, y1_src, f0_dst, f1_src)

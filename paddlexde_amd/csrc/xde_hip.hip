@@ -998,6 +998,86 @@ __global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// element-wise error ratio (materialised only for user-supplied norm callables)
+// ------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_ratio_kernel(ErrArgs a, T* __restrict__ out, int64_t n) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const T dt = a.ctrl ? T(a.ctrl->dt) : T(a.dt_host);
+  const T* __restrict__ y0 = static_cast<const T*>(a.y0[0]);
+  const T* __restrict__ y1 = static_cast<const T*>(a.y1);
+  const T rtol = T(a.rtol), atol = T(a.atol);
+  const int nk = a.nk;
+  const int64_t nvec = n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P y0v = P::load(y0, i);
+    P y1v = P::load(y1, i);
+    P e;
+    for (int j = 0; j < nk; ++j) {
+      P kk = P::load(static_cast<const T*>(a.k[j]), i);
+      T cj = dt * T(a.coef[j]);
+#pragma unroll
+      for (int w = 0; w < W; ++w) e.v[w] = (j == 0) ? kk.v[w] * cj : e.v[w] + kk.v[w] * cj;
+    }
+    P o;
+#pragma unroll
+    for (int w = 0; w < W; ++w) o.v[w] = e.v[w] / (atol + rtol * fmax_(abs_(y0v.v[w]), abs_(y1v.v[w])));
+    o.store(out, i);
+  }
+  if (VEC) {
+    const int64_t i = nvec * W + threadIdx.x;
+    if (blockIdx.x == 0 && i < n) {
+      T e = T(0);
+      for (int j = 0; j < nk; ++j) {
+        T term = static_cast<const T*>(a.k[j])[i] * (dt * T(a.coef[j]));
+        e = (j == 0) ? term : e + term;
+      }
+      out[i] = e / (atol + rtol * fmax_(abs_(y0[i]), abs_(y1[i])));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fan-out: outs[j] = g * factor_j  (backward of the combine)
+// ------------------------------------------------------------------------------------------
+struct FanoutArgs {
+  void* outs[XDE_MAX_K + 1];
+  double factor[XDE_MAX_K + 1];
+  const void* g;
+  const double* dt_dev;
+  int64_t n;
+  int nout;
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_fanout_kernel(FanoutArgs a) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const T* __restrict__ g = static_cast<const T*>(a.g);
+  const T dt = a.dt_dev ? T(*a.dt_dev) : T(1);
+  const int nout = a.nout;
+  const int64_t nvec = a.n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P gv = P::load(g, i);
+    for (int j = 0; j < nout; ++j) {
+      const T f = T(a.factor[j]) * dt;
+      P o;
+#pragma unroll
+      for (int w = 0; w < W; ++w) o.v[w] = gv.v[w] * f;
+      o.store(static_cast<T*>(a.outs[j]), i);
+    }
+  }
+  if (VEC) {
+    const int64_t i = nvec * W + threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n)
+      for (int j = 0; j < nout; ++j) static_cast<T*>(a.outs[j])[i] = g[i] * (T(a.factor[j]) * dt);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // predicated commit (hipGraph pipeline): (y0, f0) <- (y1, f1) when the step was accepted
 // ------------------------------------------------------------------------------------------
 template <typename T, bool VEC>
@@ -1254,6 +1334,48 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   return XDE_OK;
 }
 
+int xde_error_ratio(void* out, const void* const* k, const double* c_err, int nk, const void* y0, const void* y1,
+                    double rtol, double atol, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, void* stream) {
+  if (!out || !k || !c_err || !y0 || !y1) return fail(XDE_EBADARG, "xde_error_ratio: null pointer");
+  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_error_ratio: nk out of range");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_error_ratio: bad dtype");
+  if (n < 0) return fail(XDE_EBADARG, "xde_error_ratio: negative n");
+  if (n == 0) return XDE_OK;
+  ErrArgs a;
+  memset(&a, 0, sizeof(a));
+  a.y0[0] = a.y0[1] = y0;
+  a.y1 = y1;
+  bool vec = aligned16(out) && aligned16(y0) && aligned16(y1);
+  for (int j = 0; j < nk; ++j) {
+    if (!k[j]) return fail(XDE_EBADARG, "xde_error_ratio: null k[j]");
+    a.k[j] = k[j];
+    a.coef[j] = c_err[j];
+    vec = vec && aligned16(k[j]);
+  }
+  a.k0_alt = k[0];
+  a.rtol = rtol;
+  a.atol = atol;
+  a.dt_host = dt_host;
+  a.ctrl = ctrl;
+  a.nk = nk;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const int64_t work = vec ? (n + width - 1) / width : n;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_ERRNORM, double(nk + 3) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+  if (dtype == XDE_F32) {
+    if (vec) XDE_LAUNCH((xde_ratio_kernel<float, true>), g, b, st, prof, a, static_cast<float*>(out), n);
+    else XDE_LAUNCH((xde_ratio_kernel<float, false>), g, b, st, prof, a, static_cast<float*>(out), n);
+  } else {
+    if (vec) XDE_LAUNCH((xde_ratio_kernel<double, true>), g, b, st, prof, a, static_cast<double*>(out), n);
+    else XDE_LAUNCH((xde_ratio_kernel<double, false>), g, b, st, prof, a, static_cast<double*>(out), n);
+  }
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
 int xde_scaled_norm_partial(const void* av, const void* bv, const void* y0, double rtol, double atol,
                             const xde_segments_t* segs, int norm_kind, int dtype, void* ws, int slot, void* stream) {
   if (!av || !y0 || !ws || !segs) return fail(XDE_EBADARG, "xde_scaled_norm_partial: null pointer");
@@ -1471,6 +1593,44 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
     else LAUNCH_DENSE(double, double);
   }
 #undef LAUNCH_DENSE
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_scale_fanout(void* const* outs, const void* g, const double* factors, int nout, const double* dt_dev, int64_t n,
+                     int dtype, void* stream) {
+  if (!outs || !g || !factors) return fail(XDE_EBADARG, "xde_scale_fanout: null pointer");
+  if (nout < 1 || nout > XDE_MAX_K + 1) return fail(XDE_EBADARG, "xde_scale_fanout: nout out of range");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_scale_fanout: bad dtype");
+  if (n < 0) return fail(XDE_EBADARG, "xde_scale_fanout: negative n");
+  if (n == 0) return XDE_OK;
+  FanoutArgs a;
+  memset(&a, 0, sizeof(a));
+  bool vec = aligned16(g);
+  for (int j = 0; j < nout; ++j) {
+    if (!outs[j]) return fail(XDE_EBADARG, "xde_scale_fanout: null outs[j]");
+    a.outs[j] = outs[j];
+    a.factor[j] = factors[j];
+    vec = vec && aligned16(outs[j]);
+  }
+  a.g = g;
+  a.dt_dev = dt_dev;
+  a.n = n;
+  a.nout = nout;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const int64_t work = vec ? (n + width - 1) / width : n;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_COMBINE, double(nout + 1) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 gr(static_cast<unsigned>(blocks)), b(kBlock);
+  if (dtype == XDE_F32) {
+    if (vec) XDE_LAUNCH((xde_fanout_kernel<float, true>), gr, b, st, prof, a);
+    else XDE_LAUNCH((xde_fanout_kernel<float, false>), gr, b, st, prof, a);
+  } else {
+    if (vec) XDE_LAUNCH((xde_fanout_kernel<double, true>), gr, b, st, prof, a);
+    else XDE_LAUNCH((xde_fanout_kernel<double, false>), gr, b, st, prof, a);
+  }
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

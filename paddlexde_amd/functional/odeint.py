@@ -87,6 +87,7 @@ def _odeint_tuple(func, y0, t_span, solver, *, rtol, atol, options):
         y_in = flat0
         opts = dict(options)
         opts["_xde_segments"] = segs
+        opts["_xde_segment_shapes"] = shapes
 
     xde = BaseODE(flat_func, y0=y_in, t_span=t_span)
     s = solver(xde=xde, y0=xde.y0, rtol=rtol, atol=atol, **opts)

@@ -6,6 +6,7 @@ Reference: paddlexde/solver/base_adaptive_solver.py:6-72.  ``integrate`` keeps t
 xde_scaled_norm_partial launches, the Euler probe ``y0 + h0*f0`` (:59) is one xde_stage_combine.
 """
 import abc
+import warnings
 
 import numpy as np
 import torch
@@ -41,6 +42,15 @@ class AdaptiveSolver(metaclass=abc.ABCMeta):
         driven by the device controller (ctrl.next_out) inside ``_run``."""
         y0 = self.y0
         self.backend.require_device(y0)
+        if torch.is_grad_enabled():
+            func = getattr(self.xde, "func", None)
+            trainable = isinstance(func, torch.nn.Module) and any(p.requires_grad for p in func.parameters())
+            if y0.requires_grad or trainable:
+                warnings.warn(
+                    "paddlexde_amd: adaptive solvers do not record an autograd graph (the step kernels read dt from device "
+                    "memory); the result is detached. Use odeint_adjoint for gradients, or torch.no_grad() to silence this.",
+                    stacklevel=3,
+                )
         self.y0 = y0 = as_operand(y0.detach())
         t_host = t_span_to_host(t_span, np_dtype(self.dtype))  # t_span.astype(self.dtype)
         solution = torch.empty((len(t_host),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)

@@ -76,6 +76,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         process_group=None,
         record_trace=False,
         _xde_segments=None,
+        _xde_segment_shapes=None,
         **kwargs,
     ):
         super().__init__(xde=xde, dtype=dtype, y0=y0, **kwargs)
@@ -128,12 +129,20 @@ class AdaptiveRKSolver(AdaptiveSolver):
         n = self.y0.numel()
         segs = [(0, n)] if _xde_segments is None else [(int(s), int(l)) for s, l in _xde_segments]
         spec = native_norm_spec(self.norm)
+        self._custom_norm = spec is None
+        self._segs = segs
+        self._seg_shapes = _xde_segment_shapes
         if spec is None:
-            raise NotImplementedError(
-                "custom norm callables are not mapped onto the native norm kernels yet; use _rms_norm, _linf_norm "
-                "or the adjoint's default/'seminorm' norms"
-            )
-        if spec[0] in ("rms", "linf"):
+            # an arbitrary callable: err/tol is materialised by one kernel (xde_error_ratio), the user's norm runs
+            # as framework ops on it and its scalar feeds the device controller (as a 1-segment "linf" value)
+            if not callable(self.norm):
+                raise TypeError("options['norm'] must be callable")
+            if pipeline != "sync":
+                raise NotImplementedError("custom norm callables run with pipeline='sync' only")
+            self._norm_kind = _hip.NORM_LINF
+            self._norm_segs = [(0, n)]
+            self._seg_count_local = [1.0]
+        elif spec[0] in ("rms", "linf"):
             self._norm_kind = _hip.NORM_RMS if spec[0] == "rms" else _hip.NORM_LINF
             # a plain norm over a (padded) tuple state: pads are zero, so one segment over the whole
             # buffer with the true element count gives the same value
@@ -156,7 +165,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
     def _eval(self, t, y, live=()):
         """``xde.move`` -> func(t, y); returns a kernel-ready tensor that aliases nothing we still need."""
         self.nfe += 1
-        f = self.move(t, None, y)
+        with torch.no_grad():  # the adaptive path is forward-only; gradients come from odeint_adjoint
+            f = self.move(t, None, y)
         f = as_operand(f, like=y)
         sp = storage_ptr(f)
         if sp == storage_ptr(y) or any(sp == storage_ptr(x) for x in live):
@@ -199,8 +209,22 @@ class AdaptiveRKSolver(AdaptiveSolver):
             counts = c.tolist()
         return counts
 
+    def _user_norm(self, flat):
+        """Apply a user-supplied norm callable to a flat state-like tensor (tuple state: to the tuple of views)."""
+        if self._seg_shapes is not None:
+            arg = tuple(flat[s : s + l].view(shape) for (s, l), shape in zip(self._segs, self._seg_shapes))
+        else:
+            arg = flat.view(self.y0.shape)
+        v = self.norm(arg)
+        v = v if torch.is_tensor(v) else torch.as_tensor(float(v))
+        return v.detach().abs().to(device=flat.device, dtype=torch.float64).reshape(())
+
     def _scaled_norms(self, pairs, y0, rtol, atol):
         """norm(a / scale) or norm((a - b) / scale) for each (a, b) pair; one host read for all of them."""
+        if self._custom_norm:
+            scale = float(atol) + y0.abs() * float(rtol)
+            vals = [self._user_norm(((a - b) if b is not None else a) / scale) for a, b in pairs]
+            return torch.stack(vals).tolist()
         be = self.backend
         res = torch.empty(len(pairs), dtype=torch.float64, device=y0.device)
         sdt = _hip.dtype_code(y0.dtype)
@@ -298,6 +322,14 @@ class AdaptiveRKSolver(AdaptiveSolver):
             y1 = torch.empty_like(y0)
             be.stage_combine(y1, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
         idx, coef = self._err_plan
+        if self._custom_norm:
+            r = torch.empty_like(y0)
+            be.error_ratio(r, [ks[j] for j in idx], coef, y0, y1, float(self.rtol), float(self.atol), ctrl=ctrl)
+            self._sums.zero_()
+            self._sums[0] = self._user_norm(r)
+            self._sums[_hip.XDE_MAX_SEG] = (~torch.isfinite(y0)).sum()
+            be.rk_control(ctrl, self._params, None, self._sums, self._t_span_dev, self._step_t_dev, self._t_stage)
+            return y1, ks
         be.error_norm_partial([ks[j] for j in idx], coef, y0, y1, float(self.rtol), float(self.atol), self._xsegs,
                               self._norm_kind, self._ws, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
         if self.process_group is None:

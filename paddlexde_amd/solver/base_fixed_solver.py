@@ -16,6 +16,7 @@ import torch
 
 from .. import _hip
 from ..xde.base_ode import BaseODE
+from ._autograd import CombineFn
 from ._common import as_operand, np_dtype, storage_ptr, t_span_to_host
 
 _one_third = 1 / 3
@@ -71,6 +72,9 @@ class FixedSolver(metaclass=abc.ABCMeta):
         return f
 
     def _combine(self, y0, ks, coef, mode, dt, scale=1.0, out=None):
+        if torch.is_grad_enabled() and (y0.requires_grad or any(k.requires_grad for k in ks)):
+            # discretise-then-optimise: keep the autograd graph through the combine
+            return CombineFn.apply(self.backend, list(coef), mode, scale, float(dt), y0, *ks)
         if out is None:
             out = torch.empty_like(y0)
         self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, dt_host=float(dt))
@@ -130,7 +134,8 @@ class FixedSolver(metaclass=abc.ABCMeta):
         if rows and len(rows[0]):
             table = torch.from_numpy(np.asarray(rows, dtype=np_dtype(t_dtype))).to(y0.device)
 
-        y0 = as_operand(y0.detach())
+        tracking = torch.is_grad_enabled() and y0.requires_grad
+        y0 = as_operand(y0 if tracking else y0.detach())
         L, D = y0.shape[-2], y0.shape[-1]
         lead = y0.shape[:-2]
         out = torch.empty(*lead, pred_len * L, D, dtype=y0.dtype, device=y0.device)
@@ -155,7 +160,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
                     self._y1_out = None
                     self.step(t1, t1, y1)
                 # "linear": linear_interp returns y1 when t == t1 (interp_fn.py:7-8); any other value: raw y1
-                if y1.data_ptr() != dst.data_ptr():
+                if y1.data_ptr() != dst.data_ptr():  # (differentiable copy when y1 carries an autograd graph)
                     dst.copy_(y1)
                 y0 = y1
         finally:

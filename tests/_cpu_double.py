@@ -118,6 +118,19 @@ class NumpyDoubleBackend:
             r = e / tol
         self._slots[0] = self._seg_reduce(r, y0v, segs, norm_kind) + (norm_kind, segs.n_seg)
 
+    def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None):
+        self.launches.append("ratio")
+        T = _NP[y0.dtype]
+        dt = T(self._c(ctrl).dt) if ctrl is not None else T(dt_host)
+        y0v, y1v = _np(y0).reshape(-1), _np(y1).reshape(-1)
+        kk = [_np(k).reshape(-1) for k in ks]
+        with np.errstate(all="ignore"):
+            cs = [dt * T(c_) for c_ in c_err]
+            e = kk[0] * cs[0]
+            for j in range(1, len(kk)):
+                e = e + kk[j] * cs[j]
+            _np(out).reshape(-1)[...] = e / (T(atol) + T(rtol) * np.fmax(np.abs(y0v), np.abs(y1v)))
+
     def scaled_norm_partial(self, a, b, y0, rtol, atol, segs, norm_kind, ws, slot):
         self.launches.append("scalednorm")
         T = _NP[y0.dtype]
@@ -336,6 +349,14 @@ class NumpyDoubleBackend:
             xp = xp * x
             total = total + xp * ca
             out[r, :] = total
+
+    def scale_fanout(self, outs, g, factors, dt_dev=None):
+        self.launches.append("fanout")
+        T = _NP[g.dtype]
+        dt = T(dt_dev.item()) if dt_dev is not None else T(1)
+        gv = _np(g).reshape(-1)
+        for o, f in zip(outs, factors):
+            _np(o).reshape(-1)[...] = gv * (T(f) * dt)
 
     def commit(self, ctrl, y0_dst, y1_src, f0_dst, f1_src):
         self.launches.append("commit")

@@ -173,6 +173,29 @@ def test_linf_norm_and_options(dev):
     assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
 
 
+def test_custom_norm_callable(dev):
+    """A user-supplied norm: err/tol is materialised by xde_error_ratio and the callable runs on it."""
+    A, y0 = _linear(64, 32, torch.float64)
+    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64)
+    An = A.numpy()
+    ref, so = O.odeint(lambda t_, y: y @ An.T, y0.numpy(), t.numpy(), "dopri5", rtol=1e-6, atol=1e-8,
+                       options={"norm": lambda x: 0.5 * np.abs(x).max() + 0.5 * np.sqrt(np.mean(x * x)), "dtype": np.float64},
+                       return_solver=True)
+    Ad = A.to(dev)
+    calls = []
+
+    def my_norm(x):
+        calls.append(tuple(x.shape))
+        return 0.5 * x.abs().max() + 0.5 * x.pow(2).mean().sqrt()
+
+    got = odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, rtol=1e-6, atol=1e-8, options={"norm": my_norm, "dtype": torch.float64})
+    assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
+    assert calls and all(c == (64, 32) for c in calls)
+    assert len(calls) == 3 + so.n_accept + so.n_reject  # 3 in select_initial_step + one per attempted step
+    with pytest.raises(NotImplementedError):
+        odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, options={"norm": my_norm, "pipeline": "lag"})
+
+
 def test_step_t_option(dev):
     A, y0 = _linear(16, 8, torch.float64)
     t = torch.linspace(0.0, 1.0, 3, dtype=torch.float64)
@@ -290,6 +313,48 @@ def test_adjoint_gradients_vs_oracle(dev, solver, dtype):
     assert P.rel_err(y0g.grad.cpu().numpy(), gy0) <= bar, P.rel_err(y0g.grad.cpu().numpy(), gy0)
     for p_, g_ in zip(m.parameters(), gps):
         assert P.rel_err(p_.grad.cpu().numpy(), g_) <= bar, P.rel_err(p_.grad.cpu().numpy(), g_)
+
+
+@pytest.mark.parametrize("solver", ["euler", "midpoint", "rk4"])
+def test_fixed_step_backprop_through_odeint(dev, solver):
+    """Discretise-then-optimise, as example/ode_demo.py:51-53 trains: gradients through the combine kernels equal
+    the gradients of the same discretisation written with plain framework ops."""
+    dtype = torch.float64
+    m = ODEFunc(dtype).to(dev)
+    y0 = (torch.rand(32, 2, generator=torch.Generator().manual_seed(0), dtype=dtype) * 2 - 1).to(dev).requires_grad_(True)
+    t = torch.linspace(0.0, 1.0, 6, dtype=dtype).to(dev)
+    sol = odeint(m, y0, t, solver=FIXED[solver])
+    loss = (sol * sol).mean()
+    loss.backward()
+    got = [y0.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+    y0.grad = None
+    for p in m.parameters():
+        p.grad = None
+
+    # the same scheme in eager framework ops (op order of base_fixed_solver.py / fixed_solver/*.py)
+    def step(t0, t1, y):
+        dt = t1 - t0
+        if solver == "euler":
+            return m(t0, y) * dt + y
+        if solver == "midpoint":
+            yh = m(t0, y) * (0.5 * dt) + y
+            return m(t0 + 0.5 * dt, yh) * dt + y
+        k1 = m(t0, y)
+        k2 = m(t0 + dt / 3, k1 * (dt / 3) + y)
+        k3 = m(t0 + dt * 2 / 3, (k1 - k2 / 3) * dt + y)
+        k4 = m(t1, (k1 - k2 + k3) * dt + y)
+        return ((k1 * dt + y) + 3 * (k2 * dt + y) + 3 * (k3 * dt + y) + (k4 * dt + y)) * 0.125
+
+    ys, y = [y0], y0
+    for i in range(1, len(t)):
+        y = step(t[i - 1], t[i], y)
+        ys.append(y)
+    ref_sol = torch.cat(ys, dim=-2)
+    assert torch.allclose(sol, ref_sol, rtol=1e-12, atol=1e-14)
+    ((ref_sol * ref_sol).mean()).backward()
+    ref = [y0.grad] + [p.grad for p in m.parameters()]
+    for a, b in zip(got, ref):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-13), float((a - b).abs().max())
 
 
 def test_adjoint_argument_validation(dev):
