@@ -142,7 +142,10 @@ def side_workload(args):
             opts = {"norm": _rms_norm}
             if name == "dopri5":
                 opts["pipeline"] = args.pipeline
-            pred = odeint_adjoint(func, y0, t, solver=solver, rtol=1e-5, atol=1e-7, options=opts)
+            aopts = {k: v for k, v in opts.items() if k != "norm"}
+            if args.graph_func:
+                aopts["graph_func"] = True
+            pred = odeint_adjoint(func, y0, t, solver=solver, rtol=1e-5, atol=1e-7, options=opts, adjoint_options=aopts)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             target = y_true if name == "rk4" else pred.detach() * 0.0
@@ -153,7 +156,8 @@ def side_workload(args):
         gn = float(sum(p.grad.double().pow(2).sum() for p in func.parameters()).sqrt())
         res[name] = {"forward_s": t1 - t0, "backward_s": t2 - t1, "grad_norm": gn, "n_params": sum(p.numel() for p in func.parameters())}
     print(json.dumps({"metric": "seconds per forward / adjoint backward (latency-bound)", "workload": "c3: spiral neural-ODE (2-50-2 MLP on y^3), "
-                      "batch 8192, 32 output times, odeint_adjoint", "pipeline": args.pipeline, "results": res}))
+                      "batch 8192, 32 output times, odeint_adjoint", "pipeline": args.pipeline, "graph_func": bool(args.graph_func),
+                      "results": res}))
 
 
 def main():
@@ -165,6 +169,7 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--pipeline", default="lag", choices=["sync", "lag", "graph"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-func", action="store_true", help="c3: replay the augmented dynamics from a captured HIP graph")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
                     help="c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
                          "batch 8192 (latency-bound, reports ms per fwd+bwd and per attempted step); c5: stiff Van der Pol "

@@ -11,6 +11,7 @@ Deviations, all documented in SURVEY.md:
   D6  the gradient w.r.t. ``y0`` (``adj_y``) is returned instead of ``None`` (superset).
 """
 import warnings
+import weakref
 
 import torch
 import torch.nn as nn
@@ -30,6 +31,80 @@ def _time_first(x, y0_shape, T, fixed):
         return x
     lead, L, D = tuple(y0_shape[:-2]), y0_shape[-2], y0_shape[-1]
     return x.reshape(lead + (T, L, D)).movedim(len(lead), 0)
+
+
+def _make_augmented_dynamics(func, adjoint_params, t_requires_grad):
+    """odeint_adjoint.py:89-124: dynamics of the original system augmented with the adjoint wrt y and an integrator
+    wrt t and the parameters.  ``y_aug = (adj_t, y, adj_y, *adj_params)``; only y and adj_y are read."""
+
+    def augmented_dynamics(t, y_aug):
+        y = y_aug[1]
+        adj_y = y_aug[2]
+        with torch.enable_grad():
+            t_ = t.detach()
+            t = t_.clone().requires_grad_(True)
+            y = y.detach().clone().requires_grad_(True)
+            # If using an adaptive solver we don't want to waste time resolving dL/dt unless we need it
+            func_eval = func(t if t_requires_grad else t_, y)
+            vjp_t, vjp_y, *vjp_params = torch.autograd.grad(
+                func_eval, (t, y) + adjoint_params, -adj_y, allow_unused=True, retain_graph=True
+            )
+        # autograd.grad returns None if no gradient, set to zero.
+        vjp_t = torch.zeros_like(t) if vjp_t is None else vjp_t
+        vjp_y = torch.zeros_like(y) if vjp_y is None else vjp_y
+        vjp_params = [
+            torch.zeros_like(param) if vjp_param is None else vjp_param for param, vjp_param in zip(adjoint_params, vjp_params)
+        ]
+        return (vjp_t, func_eval.detach(), vjp_y, *vjp_params)
+
+    return augmented_dynamics
+
+
+def _make_functional_dynamics(func, adjoint_params, t_requires_grad):
+    """The augmented dynamics for HIP-graph capture: identical arithmetic, but the vjp is taken w.r.t. fresh detached
+    aliases of the parameters (substituted with torch.func.functional_call) instead of the parameter leaves
+    themselves.  After a user's loss.backward() the real leaves own AccumulateGrad nodes bound to the default
+    stream, and differentiating w.r.t. them inside a later stream capture makes the engine synchronise with the
+    default stream — which crashes the capture.  Needs ``func`` to be an nn.Module whose parameters are the
+    adjoint parameters."""
+    names = {id(p): n for n, p in func.named_parameters()}
+    try:
+        order = [names[id(p)] for p in adjoint_params]
+    except KeyError:
+        raise NotImplementedError(
+            "adjoint_options['graph_func'] needs func to be an nn.Module and adjoint_params to be (a subset of) its parameters"
+        )
+
+    def augmented_dynamics(t, y_aug):
+        y = y_aug[1]
+        adj_y = y_aug[2]
+        with torch.enable_grad():
+            t_ = t.detach()
+            t = t_.clone().requires_grad_(True)
+            y = y.detach().clone().requires_grad_(True)
+            ps = tuple(p.detach().requires_grad_(True) for p in adjoint_params)  # aliases, no copy
+            func_eval = torch.func.functional_call(func, dict(zip(order, ps)), (t if t_requires_grad else t_, y))
+            vjp_t, vjp_y, *vjp_params = torch.autograd.grad(func_eval, (t, y) + ps, -adj_y, allow_unused=True)
+        vjp_t = torch.zeros_like(t) if vjp_t is None else vjp_t
+        vjp_y = torch.zeros_like(y) if vjp_y is None else vjp_y
+        vjp_params = [torch.zeros_like(p) if v is None else v for p, v in zip(adjoint_params, vjp_params)]
+        return (vjp_t, func_eval.detach(), vjp_y, *vjp_params)
+
+    return augmented_dynamics
+
+
+_GRAPH_CACHE = weakref.WeakKeyDictionary()  # func module -> {signature: GraphedFunc}; captures are reused across calls
+
+
+def _graph_time_examples(adjoint_method, adjoint_options, t_span, y0):
+    """The time arguments (shape, dtype) the adjoint solver will hand to func, for pre-capturing its HIP graph."""
+    dev = y0.device
+    if _is_fixed(adjoint_method):
+        tt = t_span.dtype if t_span.dtype in (torch.float32, torch.float64) else torch.float32
+        return [torch.zeros(1, dtype=tt, device=dev)]
+    time_dtype = adjoint_options.get("dtype", torch.float32)
+    dtypes = {time_dtype, y0.dtype, torch.promote_types(time_dtype, y0.dtype)}
+    return [torch.zeros((), dtype=d, device=dev) for d in dtypes]
 
 
 class OdeintAdjointMethod(torch.autograd.Function):
@@ -63,6 +138,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
         with torch.no_grad():
             ans = odeint(func, y0, t_span, solver=method, rtol=rtol, atol=atol, options=options)
             ctx.save_for_backward(t_span, ans, *adjoint_params)
+
         return ans
 
     @staticmethod
@@ -91,25 +167,14 @@ class OdeintAdjointMethod(torch.autograd.Function):
             ##################################
             #    Set up backward ODE func    #
             ##################################
-            def augmented_dynamics(t, y_aug):
-                # odeint_adjoint.py:89-124
-                y = y_aug[1]
-                adj_y = y_aug[2]
-                with torch.enable_grad():
-                    t_ = t.detach()
-                    t = t_.clone().requires_grad_(True)
-                    y = y.detach().clone().requires_grad_(True)
-                    func_eval = func(t if t_requires_grad else t_, y)
-                    vjp_t, vjp_y, *vjp_params = torch.autograd.grad(
-                        func_eval, (t, y) + adjoint_params, -adj_y, allow_unused=True, retain_graph=True
-                    )
-                vjp_t = torch.zeros_like(t) if vjp_t is None else vjp_t
-                vjp_y = torch.zeros_like(y) if vjp_y is None else vjp_y
-                vjp_params = [
-                    torch.zeros_like(param) if vjp_param is None else vjp_param
-                    for param, vjp_param in zip(adjoint_params, vjp_params)
-                ]
-                return (vjp_t, func_eval.detach(), vjp_y, *vjp_params)
+            augmented_dynamics = _make_augmented_dynamics(func, adjoint_params, t_requires_grad)
+            graphed = adjoint_options.get("_graphed")
+            if graphed is not None:
+
+                def augmented_dynamics(t, y_aug):  # noqa: F811  outputs are consumed at once by the tuple packer
+                    return graphed(t, (y_aug[1], y_aug[2]))
+
+            solver_options = {k: v for k, v in adjoint_options.items() if k not in ("graph_func", "_graphed")}
 
             ##################################
             #       Solve adjoint ODE        #
@@ -133,7 +198,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
                     solver=adjoint_method,
                     rtol=adjoint_rtol,
                     atol=adjoint_atol,
-                    options=adjoint_options,
+                    options=solver_options,
                 )
                 aug_state = [a[1] for a in aug]  # extract just the t[i - 1] value
                 aug_state[1] = y_ans[i - 1]  # use our forward-pass estimate of the state
@@ -209,6 +274,33 @@ def odeint_adjoint(
 
     if not torch.is_tensor(t_span):
         t_span = torch.as_tensor(t_span)
+
+    # opt-in adjoint_options["graph_func"] (True, or a dict that caches captures across calls): the augmented dynamics
+    # (func forward + autograd vjp, ~30 eager launches) is captured into one HIP graph per time-argument signature.
+    # It has to happen HERE — on the calling thread and outside the autograd Function: capturing from the engine's
+    # worker thread (where backward runs), or inside Function.forward while the parameters are its inputs, crashes
+    # the runtime.
+    if adjoint_options.get("graph_func", False) and y0.is_cuda:
+        from ..utils.graphed import GraphedFunc
+
+        if not isinstance(func, nn.Module):
+            raise NotImplementedError("adjoint_options['graph_func'] needs func to be an nn.Module")
+        if isinstance(adjoint_options["graph_func"], dict):
+            cache = adjoint_options["graph_func"]
+        else:
+            cache = _GRAPH_CACHE.setdefault(func, {})
+        t_rg = bool(t_span.requires_grad)
+        key = ("aug", tuple(y0.shape), y0.dtype, str(y0.device), t_rg, tuple(id(p) for p in adjoint_params))
+        graphed = cache.get(key)
+        if graphed is None:
+            dyn = _make_functional_dynamics(func, adjoint_params, t_rg)
+            graphed = GraphedFunc(lambda t, ya: dyn(t, (None, ya[0], ya[1])), clone_outputs=False)
+            cache[key] = graphed
+        y_ex = y0.detach()
+        for t_ex in _graph_time_examples(adjoint_solver, adjoint_options, t_span, y0):
+            graphed.prepare(t_ex, (y_ex, torch.zeros_like(y_ex)))
+        adjoint_options["_graphed"] = graphed
+
     solution = OdeintAdjointMethod.apply(
         func,
         y0,
