@@ -188,13 +188,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    # rehearsal on a one-GPU box (XDE_BENCH_REHEARSAL=1): all ranks share cuda:0 and gloo carries the collectives
+    # (RCCL refuses several ranks on one device); the driver's real runs use one GPU per rank over nccl (= RCCL)
+    rehearsal = os.environ.get("XDE_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from paddlexde_amd import Dopri5, _hip
     from paddlexde_amd.utils import _rms_norm
@@ -233,7 +241,7 @@ def main():
         be.prof_enable(False)
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

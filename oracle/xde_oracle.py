@@ -140,12 +140,19 @@ ADAPTIVE_HEUN_TABLEAU = ButcherTableau(
 )
 ADAPTIVE_HEUN_MID = _f64([0.5, 0.0])
 
+# dopri8.py:5-252 (coefficients in oracle/dopri8_data.py)
+from . import dopri8_data as _d8  # noqa: E402
+
+DOPRI8_TABLEAU = ButcherTableau(alpha=_f64(_d8.ALPHA), beta=[_f64(b) for b in _d8.BETA], c_sol=_f64(_d8.C_SOL), c_error=_f64(_d8.C_ERR))
+DOPRI8_MID = _f64(_d8.C_MID)
+
 ADAPTIVE = {
     # name: (order, tableau, mid)                       class attrs in each solver file
     "dopri5": (5, DOPRI5_TABLEAU, DOPRI5_MID),  # dopri5.py:58-61
     "bosh3": (3, BOSH3_TABLEAU, BOSH3_MID),  # bosh3.py:21-24
     "fehlberg2": (2, FEHLBERG2_TABLEAU, FEHLBERG2_MID),  # fehlberg2.py:18-21
     "adaptive_heun": (2, ADAPTIVE_HEUN_TABLEAU, ADAPTIVE_HEUN_MID),  # adaptive_heun.py:23-26
+    "dopri8": (8, DOPRI8_TABLEAU, DOPRI8_MID),  # dopri8.py:249-252
 }
 FIXED = ("euler", "midpoint", "rk4", "rk4_classic")
 
@@ -323,6 +330,16 @@ class FixedSolver:
 #           (paddlexde/solver/base_adaptive_solver.py, base_adaptive_solver_rk.py)
 # --------------------------------------------------------------------------------------
 
+def _sum_last(x):
+    """``paddle.sum(x, axis=-1)`` over the stage axis.  Paddle's reduction order over these <= 14 terms is not
+    specified; left-to-right is used (numpy's own ``sum`` is left-to-right below 8 terms and 8-way unrolled
+    pairwise from 8 on, which would make Dopri8's noise-level first error estimate depend on numpy internals)."""
+    acc = x[..., 0].copy()
+    for j in range(1, x.shape[-1]):
+        acc = acc + x[..., j]
+    return acc
+
+
 RKState = collections.namedtuple("RKState", "y1 f1 t0 t1 dt interp_coeff")
 StepRecord = collections.namedtuple("StepRecord", "t0 dt ratio accept")
 
@@ -462,14 +479,14 @@ class AdaptiveRKSolver:
                 ti = t1
             else:
                 ti = t0 + alpha_i * dt
-            yi = y0 + np.sum(k[..., : i + 1] * (beta_i * dt), axis=-1).reshape(y0.shape)
+            yi = y0 + _sum_last(k[..., : i + 1] * (beta_i * dt)).reshape(y0.shape)
             f = self.move(ti, dt, yi)
             k[..., i + 1] = f
         if not (tableau.c_sol[-1] == 0 and (tableau.c_sol[:-1] == tableau.beta[-1]).all()):
-            yi = y0 + np.sum(k * (dt * tableau.c_sol), axis=-1).reshape(y0.shape)
+            yi = y0 + _sum_last(k * (dt * tableau.c_sol)).reshape(y0.shape)
         y1 = yi
         f1 = k[..., -1]
-        y1_error = np.sum(k * (dt * tableau.c_error), axis=-1)
+        y1_error = _sum_last(k * (dt * tableau.c_error))
         return y1, f1, y1_error, k
 
     # base_adaptive_solver_rk.py:183-284
@@ -518,7 +535,7 @@ class AdaptiveRKSolver:
     # base_adaptive_solver_rk.py:286-292
     def _interp_fit(self, y0, y1, k, dt):
         dt = y0.dtype.type(dt)
-        y_mid = y0 + np.sum(k * (dt * self.mid), axis=-1).reshape(y0.shape)
+        y_mid = y0 + _sum_last(k * (dt * self.mid)).reshape(y0.shape)
         f0 = k[..., 0]
         f1 = k[..., -1]
         return interp_fit(y0, y1, y_mid, f0, f1, dt)

