@@ -50,6 +50,15 @@ int env_int(const char* name, int dflt) {
   return x > 0 ? x : dflt;
 }
 
+// XDE_NT: bit 0 = stream the dead operands of the error-norm kernel with non-temporal loads (default on)
+int nt_policy() {
+  static int v = [] {
+    const char* e = getenv("XDE_NT");
+    return (e && *e) ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 int grid_cap() {
   static int cap = env_int("XDE_GRID_BLOCKS", 2048);
   return cap > XDE_MAX_PARTIALS ? XDE_MAX_PARTIALS : cap;
@@ -63,11 +72,19 @@ template <> struct VecOf<float> { using type = float4; static constexpr int W = 
 template <> struct VecOf<double> { using type = double2; static constexpr int W = 2; };
 
 template <typename T, bool VEC> struct Pack;
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
 template <> struct Pack<float, true> {
   static constexpr int W = 4;
   float v[4];
   __device__ static Pack load(const float* p, int64_t i) {
     float4 x = reinterpret_cast<const float4*>(p)[i];
+    return Pack{{x.x, x.y, x.z, x.w}};
+  }
+  // streaming load (global_load_dwordx4 ... nt): for operands this kernel reads for the last time
+  __device__ static Pack load_nt(const float* p, int64_t i) {
+    v4f_t x = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p) + i);
     return Pack{{x.x, x.y, x.z, x.w}};
   }
   __device__ void store(float* p, int64_t i) const {
@@ -81,6 +98,10 @@ template <> struct Pack<double, true> {
     double2 x = reinterpret_cast<const double2*>(p)[i];
     return Pack{{x.x, x.y}};
   }
+  __device__ static Pack load_nt(const double* p, int64_t i) {
+    v2d_t x = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p) + i);
+    return Pack{{x.x, x.y}};
+  }
   __device__ void store(double* p, int64_t i) const {
     reinterpret_cast<double2*>(p)[i] = make_double2(v[0], v[1]);
   }
@@ -89,6 +110,7 @@ template <typename T> struct Pack<T, false> {
   static constexpr int W = 1;
   T v[1];
   __device__ static Pack load(const T* p, int64_t i) { return Pack{{p[i]}}; }
+  __device__ static Pack load_nt(const T* p, int64_t i) { return Pack{{__builtin_nontemporal_load(p + i)}}; }
   __device__ void store(T* p, int64_t i) const { p[i] = v[0]; }
 };
 
@@ -153,6 +175,7 @@ struct ErrArgs {
   SegMap map;
   int nk;
   int use_sel;
+  int nt;
 };
 
 struct ScaledArgs {
@@ -370,7 +393,7 @@ __device__ __forceinline__ int find_segment(const SegMap& m, int b) {
 // ------------------------------------------------------------------------------------------
 // K2: fused error combine + tolerance scaling + norm partials (+ non-finite count of y0)
 // ------------------------------------------------------------------------------------------
-template <typename T, int NK, int NORM, bool VEC>
+template <typename T, int NK, int NORM, bool VEC, bool NT>
 __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0,
                                              T dt, int seg, int lb, int nb, T& acc_out, int& nf_out) {
   using P = Pack<T, VEC>;
@@ -404,11 +427,14 @@ __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restri
     nf += finite_(y0v) ? 0 : 1;
   };
   for (int64_t i = int64_t(lb) * kBlock + threadIdx.x; i < nvec; i += stride) {
-    P y0v = P::load(y0, vbase + i);
+    // NT: y0 and k_0..k_{NK-2} are read here for the last time when the step is accepted (the common case) and
+    // are streamed; y1 and the last operand (f1) become the next step's (y0, f0), which all its stage combines
+    // re-read, so they keep the default policy and stay in the Infinity Cache
+    P y0v = NT ? P::load_nt(y0, vbase + i) : P::load(y0, vbase + i);
     P y1v = P::load(y1, vbase + i);
     P kk[NK];
 #pragma unroll
-    for (int j = 0; j < NK; ++j) kk[j] = P::load(kp[j], vbase + i);
+    for (int j = 0; j < NK; ++j) kk[j] = (NT && j < NK - 1) ? P::load_nt(kp[j], vbase + i) : P::load(kp[j], vbase + i);
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       T e = kk[0].v[w] * c[0];
@@ -503,14 +529,14 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
   T acc = T(0);
   int nf = 0;
   switch (a.nk) {
-    case 1: errnorm_body<T, 1, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 2: errnorm_body<T, 2, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 3: errnorm_body<T, 3, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 4: errnorm_body<T, 4, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 5: errnorm_body<T, 5, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 6: errnorm_body<T, 6, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 7: errnorm_body<T, 7, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 8: errnorm_body<T, 8, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 1: if (a.nt) errnorm_body<T, 1, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 1, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 2: if (a.nt) errnorm_body<T, 2, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 2, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 3: if (a.nt) errnorm_body<T, 3, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 3, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 4: if (a.nt) errnorm_body<T, 4, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 4, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 5: if (a.nt) errnorm_body<T, 5, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 5, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 6: if (a.nt) errnorm_body<T, 6, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 6, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 7: if (a.nt) errnorm_body<T, 7, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 7, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 8: if (a.nt) errnorm_body<T, 8, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 8, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
     default: errnorm_generic<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1307,6 +1333,7 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   a.ctrl = ctrl;
   a.slot = slot_ptr(ws, 0);
   a.nk = nk;
+  a.nt = nt_policy() & 1;
   int nblocks = 0;
   int rc = build_segmap(segs, vec ? width : 1, vec, &a.map, &nblocks);
   if (rc != XDE_OK) return rc;

@@ -58,7 +58,15 @@ class AdaptiveSolver(metaclass=abc.ABCMeta):
         if len(t_host) < 2:
             return solution
         self._before_integrate(t_host)
-        self._run(solution)
+        # rows whose time equals the start time need no step (`while next_t > rk_state.t1` is false at once,
+        # base_adaptive_solver_rk.py:119); the device controller starts its row counter after them
+        d = -1 if t_host[1] < t_host[0] else 1
+        e = 1
+        while e < len(t_host) and d * t_host[e] <= d * t_host[0]:
+            solution[e] = y0
+            e += 1
+        if e < len(t_host):
+            self._run(solution)
         return solution
 
     # base_adaptive_solver.py:33-72

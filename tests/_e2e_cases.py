@@ -196,6 +196,20 @@ def test_custom_norm_callable(dev):
         odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, options={"norm": my_norm, "pipeline": "lag"})
 
 
+def test_repeated_start_time_rows(dev):
+    """t_span = [t0, t0, t1]: the reference's loop takes no step for the second row; it must equal y0."""
+    A, y0 = _linear(8, 4, torch.float64)
+    Ad = A.to(dev)
+    t = torch.tensor([0.0, 0.0, 0.5], dtype=torch.float64)
+    got = odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, rtol=1e-8, atol=1e-10, options={"norm": _rms_norm, "dtype": torch.float64})
+    ref = O.odeint(lambda t_, y: y @ A.numpy().T, y0.numpy(), np.array([0.0, 0.5]), "dopri5", rtol=1e-8, atol=1e-10,
+                   options={"norm": O._rms_norm, "dtype": np.float64})
+    assert torch.equal(got[0].cpu(), y0) and torch.equal(got[1].cpu(), y0)
+    assert P.parity_ok(got[2].cpu().numpy(), ref[1], 1e-9, 1e-11)
+    same = odeint(lambda t_, y: y @ Ad.T, y0.to(dev), torch.zeros(3, dtype=torch.float64), solver=Dopri5, options={"norm": _rms_norm})
+    assert all(torch.equal(same[i].cpu(), y0) for i in range(3))
+
+
 def test_step_t_option(dev):
     A, y0 = _linear(16, 8, torch.float64)
     t = torch.linspace(0.0, 1.0, 3, dtype=torch.float64)
