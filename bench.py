@@ -43,39 +43,41 @@ def make_problem(B, D, rank, device):
 
 
 def cpu_baseline(D, budget_s=12.0):
-    """The oracle ("port") on a bounded sample: batch 8192 x dim D, attempted Dopri5 steps for ~budget_s."""
+    """The oracle ("port") on a bounded sample: batch 8192 x dim D, attempted Dopri5 steps for ~budget_s, on every
+    host core (oracle/xde_oracle_torch.py: the reference's eager op sequence on torch-CPU tensors, checked against the
+    numpy oracle by tests/test_oracle_pinning.py).  The first step size comes from the numpy oracle's heuristic."""
     from oracle import xde_oracle as O
+    from oracle import xde_oracle_torch as OT
 
     B = 8192
     g = torch.Generator().manual_seed(1)
     U = 0.1 * torch.randn(D, D, generator=g)
-    A = (U - U.T).numpy()
-    y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(0)).numpy()
-    AT = np.ascontiguousarray(A.T)
-    s = O.AdaptiveRKSolver(lambda t, y: y @ AT, y0, 1e-5, 1e-7, method="dopri5", norm=O._rms_norm)
+    A = (U - U.T).contiguous()
+    y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(0))
+    AT = A.T.contiguous()
+    ATn = AT.numpy()
+    s = O.AdaptiveRKSolver(lambda t, y: y @ ATn, y0.numpy(), 1e-5, 1e-7, method="dopri5", norm=O._rms_norm)
     s._before_integrate(np.asarray([0.0, 1e9], dtype=np.float32))
-    s.rk_state = s._adaptive_step(s.rk_state)  # warm-up
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tw = OT.TorchAdaptiveStepper(lambda t, y: y @ AT, y0, 1e-5, 1e-7)
+    tw.start(0.0, float(s.rk_state.dt))
+    for _ in range(3):
+        tw.step()  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        s.rk_state = s._adaptive_step(s.rk_state)
+        tw.step()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
+        if el > budget_s or n >= 2000:
             break
-    blas_threads = 1
-    try:
-        from threadpoolctl import threadpool_info
-
-        blas_threads = max([int(p.get("num_threads", 1)) for p in threadpool_info()] + [1])
-    except Exception:
-        pass
     return {
         "value": B * D * n / el,
         "unit": "states/s",
-        "cores": blas_threads,
+        "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": "numpy oracle, {} attempted dopri5 steps, batch {} x dim {} fp32, {:.1f} s; element-wise ops run on 1 thread, "
-                  "the func matmul on {} BLAS threads".format(n, B, D, el, blas_threads),
+        "sample": "torch-CPU twin of the oracle (reference's eager op sequence), {} attempted dopri5 steps, batch {} x dim {} fp32, "
+                  "{:.1f} s, {} threads".format(n, B, D, el, torch.get_num_threads()),
     }
 
 

@@ -475,6 +475,51 @@ def test_tuple_state_vs_oracle(dev):
 
 
 # ----------------------------------------------------------------------------------------------
+# BASELINE.json configs 3 and 5 at their FULL sizes against the oracle (it finishes these in seconds)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pipeline", ["sync", "graph"])
+def test_config5_full_size_vs_oracle(dev, pipeline):
+    """Stiff Van der Pol mu=1000, batch 4096 x 2, t in [0, 1], rtol 1e-5 / atol 1e-7 (fp64 state and time so that the
+    ~1200 accept/reject decisions are reproducible): identical step counts, solution to 1e-8."""
+    from paddlexde_amd.xde import BaseODE
+
+    mu = 1000.0
+    y0 = np.array([2.0, 0.0]) + 0.01 * torch.randn(4096, 2, generator=torch.Generator().manual_seed(0)).double().numpy()
+    t = np.array([0.0, 1.0])
+    ref, so = O.odeint(P.vdp_np(mu), y0, t, "dopri5", rtol=1e-5, atol=1e-7, options={"norm": O._rms_norm, "dtype": np.float64,
+                                                                                      "max_num_steps": 10**6}, return_solver=True)
+    y0t = torch.from_numpy(y0).to(dev)
+    xde = BaseODE(P.vdp_torch(mu), y0=y0t, t_span=torch.from_numpy(t))
+    s = Dopri5(xde=xde, y0=y0t, rtol=1e-5, atol=1e-7, norm=_rms_norm, dtype=torch.float64, max_num_steps=10**6, pipeline=pipeline)
+    got = s.integrate(torch.from_numpy(t))
+    assert so.n_reject > 100 and so.n_accept > 500
+    assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == (so.n_accept, so.n_reject, so.nfe)
+    assert P.rel_err(got.cpu().numpy(), ref) <= 1e-8, P.rel_err(got.cpu().numpy(), ref)
+
+
+def test_config3_full_size_gradients_vs_oracle(dev):
+    """Spiral neural-ODE, batch 8192, 32 output times, odeint_adjoint with Dopri5 (fp64): 252 parameter gradients and
+    dL/dy0 against the oracle's adjoint."""
+    dtype = torch.float64
+    m = ODEFunc(dtype)
+    fn, vjp, params = _mlp_numpy(m)
+    m = m.to(dev)
+    y0 = torch.rand(8192, 2, generator=torch.Generator().manual_seed(0), dtype=dtype) * 4 - 2
+    t = torch.linspace(0.0, 25.0, 1000, dtype=dtype)[:32]
+    tol = dict(rtol=1e-7, atol=1e-9)
+    y0g = y0.clone().to(dev).requires_grad_(True)
+    sol = odeint_adjoint(m, y0g, t.to(dev), solver=Dopri5, options={"norm": _rms_norm, "dtype": dtype}, **tol)
+    sol.abs().mean().backward()
+    ans, bw = O.odeint_adjoint(fn, vjp, params, y0.numpy(), t.numpy(), "dopri5", options={"norm": O._rms_norm, "dtype": np.float64}, **tol)
+    gy0, gps = bw(np.sign(ans) / ans.size)
+    assert sum(p_.numel() for p_ in m.parameters()) == 252
+    assert P.rel_err(sol.detach().cpu().numpy(), ans) <= 1e-9
+    assert P.rel_err(y0g.grad.cpu().numpy(), gy0) <= 1e-7, P.rel_err(y0g.grad.cpu().numpy(), gy0)
+    for p_, g_ in zip(m.parameters(), gps):
+        assert P.rel_err(p_.grad.cpu().numpy(), g_) <= 1e-7, P.rel_err(p_.grad.cpu().numpy(), g_)
+
+
+# ----------------------------------------------------------------------------------------------
 # committed golden vectors (tests/golden/*.npz, generated from the oracle by tests/golden/make_golden.py)
 # ----------------------------------------------------------------------------------------------
 def _golden(name):
@@ -535,6 +580,24 @@ def test_golden_vdp_counts(dev):
 # ----------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties (the oracle cannot run these in seconds)
 # ----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_config4_shard_size_properties(dev):
+    """Config 4's per-GPU shard (65536 x 64): exact-solution rows and norm conservation (the 8-GPU coupling itself is
+    covered by tests/test_sharded_gloo.py)."""
+    import scipy.linalg
+
+    B, D = 65536, 64
+    A = P.skew_matrix(D)
+    y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(3))
+    Ad, y0d = A.to(dev), y0.to(dev)
+    sol = odeint(lambda t_, y: y @ Ad.T, y0d, torch.tensor([0.0, 1.0], device=dev), solver=Dopri5, rtol=1e-5, atol=1e-7,
+                 options={"norm": _rms_norm, "pipeline": "lag"})
+    rows = [0, 77, 40000, 65535]
+    exact = y0[rows].double().numpy() @ scipy.linalg.expm(A.double().numpy()).T
+    assert np.allclose(sol[1][rows].cpu().numpy(), exact, rtol=1e-4, atol=2e-5)
+    assert torch.allclose(y0d.double().norm(dim=1), sol[1].double().norm(dim=1), rtol=2e-5)
+
+
 @pytest.mark.gpu
 def test_config2_full_size_properties(dev):
     """batch=65536 x dim=128 Dopri5: (i) rows checked against the exact solution expm(tA) y0, (ii) the flow
