@@ -42,6 +42,30 @@ def make_problem(B, D, rank, device):
     return A.to(device), y0.to(device)
 
 
+def _cpu_share():
+    """Host threads this process may really use: scheduler affinity, capped by the cgroup CPU quota (a GPU box
+    exposes all 256 host CPUs but grants a share of ~16 per GPU) and by 32."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(-(-int(txt[0]) // int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, -(-q // per)))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, int(os.environ.get("XDE_BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(D, budget_s=12.0):
     """The oracle ("port") on a bounded sample: batch 8192 x dim D, attempted Dopri5 steps for ~budget_s, on every
     host core (oracle/xde_oracle_torch.py: the reference's eager op sequence on torch-CPU tensors, checked against the
@@ -58,7 +82,7 @@ def cpu_baseline(D, budget_s=12.0):
     ATn = AT.numpy()
     s = O.AdaptiveRKSolver(lambda t, y: y @ ATn, y0.numpy(), 1e-5, 1e-7, method="dopri5", norm=O._rms_norm)
     s._before_integrate(np.asarray([0.0, 1e9], dtype=np.float32))
-    cores = os.cpu_count() or 1
+    cores = _cpu_share()
     torch.set_num_threads(cores)
     tw = OT.TorchAdaptiveStepper(lambda t, y: y @ AT, y0, 1e-5, 1e-7)
     tw.start(0.0, float(s.rk_state.dt))
@@ -305,7 +329,7 @@ def main():
                 traffic = None
         out["roofline"] = {
             "bound": "hbm",
-            "kernel": "xde_combine_kernel<float, RK, vec> (6 launches per step, 32*N*4 B per step)",
+            "kernel": "xde_combine_kernel<float, RK, vec> (6 launches per step; the last one also emits the partial error sum)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

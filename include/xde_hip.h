@@ -140,10 +140,15 @@ int64_t xde_workspace_bytes(void);
  *   else dt_host.  If y0_alt/k0_alt != NULL and ctrl != NULL the kernel uses (y0_alt, k0_alt) in
  *   place of (y0, k[0]) when ctrl->accept != 0 (speculative enqueue: the host does not yet know
  *   whether the previous step was accepted).
+ *   out2/coef2 (optional, RK mode): a second output out2 = sum_j k_j * (dt * coef2_j) formed from the SAME loaded
+ *   operands.  The last stage of an FSAL pair loads exactly the operands the error estimate needs, so it emits the
+ *   partial error sum there (`y1_error` minus its last term, base_adaptive_solver_rk.py:180) and the error-norm
+ *   kernel reads 4 arrays instead of 8 (xde_error_norm_partial, e_pre).
  */
 int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k,
                       const void* k0_alt, const double* coef, int nk, int mode, double scale,
-                      double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, void* stream);
+                      double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, void* out2,
+                      const double* coef2, void* stream);
 
 /*
  * Error-norm partials — replaces `y1_error = sum(k * (dt * c_error), -1)` (base_adaptive_solver_rk.py:180),
@@ -151,12 +156,14 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
  * :4-9), and the `isfinite(y0).all()` pass (base_adaptive_solver_rk.py:201).
  * Writes per-block partial sums of (err/tol)^2 (or max |err/tol| for LINF) and the count of
  * non-finite y0 elements to `ws`; xde_norm_finalize / xde_rk_control reduce them in a fixed order.
+ *   e_pre (optional): partial error sum written by the last stage's combine (out2); then nk must be 1 and the
+ *   estimate is e_pre + k[0] * (dt * c_err[0]) — the same left-to-right association as the unfused sum.
  */
 int xde_error_norm_partial(const void* const* k, const void* k0_alt, const double* c_err, int nk,
                            const void* y0, const void* y0_alt, const void* y1, double rtol,
                            double atol, double dt_host, const xde_ctrl_t* ctrl,
                            const xde_segments_t* segs, int norm_kind, int dtype, void* ws,
-                           void* stream);
+                           const void* e_pre, void* stream);
 
 /*
  * Element-wise error ratio for user-supplied norm callables — the tensor `error_estimate / error_tol` of

@@ -148,9 +148,9 @@ def load_library():
         lib.xde_sizeof_ctrl.restype = i64
         lib.xde_workspace_bytes.restype = i64
         lib.xde_stage_combine.restype = i32
-        lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp]
+        lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, vp]
         lib.xde_error_norm_partial.restype = i32
-        lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp]
+        lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp, vp]
         lib.xde_error_ratio.restype = i32
         lib.xde_error_ratio.argtypes = [vp, vpp, dp, i32, vp, vp, dbl, dbl, dbl, vp, i64, i32, vp]
         lib.xde_scaled_norm_partial.restype = i32
@@ -285,23 +285,25 @@ class HipBackend:
         return torch.zeros(2 * XDE_MAX_SEG, dtype=torch.float64, device=device)
 
     # -- kernels ---------------------------------------------------------------------------
-    def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None):
-        self._require_device(out, y0, *ks)
+    def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None,
+                      out2=None, coef2=None):
+        self._require_device(out, y0, out2, *ks)
         if out.numel() == 0:
             return
         rc = self.lib.xde_stage_combine(
             out.data_ptr(), y0.data_ptr(), _ptr(y0_alt), _ptr_array(ks), _ptr(k0_alt), _dbl_array(coef), len(ks),
-            mode, float(scale), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype), self._stream(out),
+            mode, float(scale), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype), _ptr(out2),
+            _dbl_array(coef2) if coef2 is not None else None, self._stream(out),
         )
         self._check(rc, "xde_stage_combine")
 
     def error_norm_partial(self, ks, c_err, y0, y1, rtol, atol, segs, norm_kind, ws, *, dt_host=0.0, ctrl=None,
-                           y0_alt=None, k0_alt=None):
-        self._require_device(y0, y1, ws, *ks)
+                           y0_alt=None, k0_alt=None, e_pre=None):
+        self._require_device(y0, y1, ws, e_pre, *ks)
         rc = self.lib.xde_error_norm_partial(
             _ptr_array(ks), _ptr(k0_alt), _dbl_array(c_err), len(ks), y0.data_ptr(), _ptr(y0_alt), y1.data_ptr(),
             float(rtol), float(atol), float(dt_host), _ptr(ctrl), C.byref(segs), norm_kind, dtype_code(y0.dtype),
-            ws.data_ptr(), self._stream(y0),
+            ws.data_ptr(), _ptr(e_pre), self._stream(y0),
         )
         self._check(rc, "xde_error_norm_partial")
 

@@ -128,6 +128,8 @@ __device__ inline double nanmax_(double a, double b) { return (a != a) ? a : ((b
 // ------------------------------------------------------------------------------------------
 struct CombineArgs {
   void* out;
+  void* out2;  // optional second output (RK mode): sum_j k_j * (dt * coef2_j), no y0 — the partial error estimate
+  double coef2[XDE_MAX_K];
   const void* y0[2];
   const void* k[XDE_MAX_K];
   const void* k0_alt;
@@ -173,6 +175,7 @@ struct ErrArgs {
   const xde_ctrl_t* ctrl;
   NormSlot* slot;
   SegMap map;
+  const void* e_pre;  // optional pre-accumulated partial error (second output of the last stage's combine)
   int nk;
   int use_sel;
   int nt;
@@ -207,14 +210,16 @@ struct DenseArgs {
 // ------------------------------------------------------------------------------------------
 // K1: stage combine
 // ------------------------------------------------------------------------------------------
-template <typename T, int MODE, int NK, bool VEC>
+template <typename T, int MODE, int NK, bool VEC, bool OUT2>
 __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __restrict__ y0,
                                              const T* __restrict__ k0, T dt) {
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
   T* __restrict__ out = static_cast<T*>(a.out);
+  T* __restrict__ out2 = static_cast<T*>(a.out2);
   const T* kp[NK];
   T c[NK];
+  T c2[NK];
   kp[0] = k0;
 #pragma unroll
   for (int j = 1; j < NK; ++j) kp[j] = static_cast<const T*>(a.k[j]);
@@ -222,6 +227,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
   for (int j = 0; j < NK; ++j) {
     // reference: tableau cast to the state dtype, then `beta_i * dt` (RK) — or used as is (FUSE/WFUSE)
     c[j] = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+    c2[j] = OUT2 ? dt * T(a.coef2[j]) : T(0);  // `dt * tableau.c_error`
   }
   const T scale = T(a.scale);
   const int64_t nvec = a.n / W;
@@ -232,6 +238,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
 #pragma unroll
     for (int j = 0; j < NK; ++j) kk[j] = P::load(kp[j], i);
     P o;
+    P o2;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       if (MODE == XDE_COMBINE_RK) {
@@ -239,6 +246,12 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
 #pragma unroll
         for (int j = 1; j < NK; ++j) acc = acc + kk[j].v[w] * c[j];
         o.v[w] = y.v[w] + acc;
+        if (OUT2) {
+          T e = kk[0].v[w] * c2[0];
+#pragma unroll
+          for (int j = 1; j < NK; ++j) e = e + kk[j].v[w] * c2[j];
+          o2.v[w] = e;
+        }
       } else if (MODE == XDE_COMBINE_FUSE) {
         T acc = kk[0].v[w] * c[0];
 #pragma unroll
@@ -252,6 +265,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
       }
     }
     o.store(out, i);
+    if (OUT2) o2.store(out2, i);
   }
   if (VEC) {
     // scalar tail (n % W elements), done by the first threads of block 0
@@ -260,6 +274,11 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
     if (blockIdx.x == 0 && i < a.n) {
       T yv = y0[i];
       T acc;
+      if (OUT2) {
+        T e = kp[0][i] * c2[0];
+        for (int j = 1; j < NK; ++j) e = e + kp[j][i] * c2[j];
+        out2[i] = e;
+      }
       if (MODE == XDE_COMBINE_WFUSE) {
         acc = (kp[0][i] * dt + yv) * c[0];
         for (int j = 1; j < NK; ++j) acc = acc + (kp[j][i] * dt + yv) * c[j];
@@ -274,7 +293,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
 }
 
 // generic operand count (> 8: Dopri8) — runtime loop, same arithmetic order
-template <typename T, int MODE, bool VEC>
+template <typename T, int MODE, bool VEC, bool OUT2>
 __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt) {
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
@@ -286,16 +305,21 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
     P y = P::load(y0, i);
     P acc;
+    P e2;
+    constexpr bool has2 = OUT2;
     for (int j = 0; j < nk; ++j) {
       const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
       P kk = P::load(kj, i);
       T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+      T c2j = has2 ? dt * T(a.coef2[j]) : T(0);
 #pragma unroll
       for (int w = 0; w < W; ++w) {
         T term = (MODE == XDE_COMBINE_WFUSE) ? (kk.v[w] * dt + y.v[w]) * cj : kk.v[w] * cj;
         acc.v[w] = (j == 0) ? term : acc.v[w] + term;
+        if (has2) e2.v[w] = (j == 0) ? kk.v[w] * c2j : e2.v[w] + kk.v[w] * c2j;
       }
     }
+    if (has2) e2.store(static_cast<T*>(a.out2), i);
     P o;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -310,18 +334,24 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
     if (blockIdx.x == 0 && i < a.n) {
       T yv = y0[i];
       T acc = T(0);
+      T e2 = T(0);
+      constexpr bool has2 = OUT2;
       for (int j = 0; j < nk; ++j) {
         const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
         T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
         T term = (MODE == XDE_COMBINE_WFUSE) ? (kj[i] * dt + yv) * cj : kj[i] * cj;
         acc = (j == 0) ? term : acc + term;
+        if (has2) e2 = (j == 0) ? kj[i] * (dt * T(a.coef2[j])) : e2 + kj[i] * (dt * T(a.coef2[j]));
       }
+      if (has2) static_cast<T*>(a.out2)[i] = e2;
       out[i] = (MODE == XDE_COMBINE_RK) ? yv + acc : (MODE == XDE_COMBINE_FUSE) ? acc * dt + yv : acc * scale;
     }
   }
 }
 
-template <typename T, int MODE, bool VEC>
+// OUT2 (second output, RK mode only) is a separate instantiation: its two accumulators per element would
+// otherwise raise the register budget of EVERY stage launch (62 -> 112 VGPRs, occupancy 8 -> 4 waves/SIMD)
+template <typename T, int MODE, bool VEC, bool OUT2>
 __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
   int sel = 0;
   T dt;
@@ -334,14 +364,14 @@ __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
   const T* y0 = static_cast<const T*>(a.y0[sel]);
   const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
   switch (a.nk) {
-    case 1: combine_body<T, MODE, 1, VEC>(a, y0, k0, dt); break;
-    case 2: combine_body<T, MODE, 2, VEC>(a, y0, k0, dt); break;
-    case 3: combine_body<T, MODE, 3, VEC>(a, y0, k0, dt); break;
-    case 4: combine_body<T, MODE, 4, VEC>(a, y0, k0, dt); break;
-    case 5: combine_body<T, MODE, 5, VEC>(a, y0, k0, dt); break;
-    case 6: combine_body<T, MODE, 6, VEC>(a, y0, k0, dt); break;
-    case 7: combine_body<T, MODE, 7, VEC>(a, y0, k0, dt); break;
-    default: combine_generic<T, MODE, VEC>(a, y0, k0, dt); break;
+    case 1: combine_body<T, MODE, 1, VEC, OUT2>(a, y0, k0, dt); break;
+    case 2: combine_body<T, MODE, 2, VEC, OUT2>(a, y0, k0, dt); break;
+    case 3: combine_body<T, MODE, 3, VEC, OUT2>(a, y0, k0, dt); break;
+    case 4: combine_body<T, MODE, 4, VEC, OUT2>(a, y0, k0, dt); break;
+    case 5: combine_body<T, MODE, 5, VEC, OUT2>(a, y0, k0, dt); break;
+    case 6: combine_body<T, MODE, 6, VEC, OUT2>(a, y0, k0, dt); break;
+    case 7: combine_body<T, MODE, 7, VEC, OUT2>(a, y0, k0, dt); break;
+    default: combine_generic<T, MODE, VEC, OUT2>(a, y0, k0, dt); break;
   }
 }
 
@@ -393,9 +423,10 @@ __device__ __forceinline__ int find_segment(const SegMap& m, int b) {
 // ------------------------------------------------------------------------------------------
 // K2: fused error combine + tolerance scaling + norm partials (+ non-finite count of y0)
 // ------------------------------------------------------------------------------------------
-template <typename T, int NK, int NORM, bool VEC, bool NT>
+template <typename T, int NK, int NORM, bool VEC, bool NT, bool PRE = false>
 __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0,
                                              T dt, int seg, int lb, int nb, T& acc_out, int& nf_out) {
+  const T* __restrict__ epre = static_cast<const T*>(a.e_pre);
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
   const T* kp[NK];
@@ -435,9 +466,11 @@ __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restri
     P kk[NK];
 #pragma unroll
     for (int j = 0; j < NK; ++j) kk[j] = (NT && j < NK - 1) ? P::load_nt(kp[j], vbase + i) : P::load(kp[j], vbase + i);
+    P ep;
+    if (PRE) ep = NT ? P::load_nt(epre, vbase + i) : P::load(epre, vbase + i);
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-      T e = kk[0].v[w] * c[0];
+      T e = PRE ? ep.v[w] + kk[0].v[w] * c[0] : kk[0].v[w] * c[0];
 #pragma unroll
       for (int j = 1; j < NK; ++j) e = e + kk[j].v[w] * c[j];
       one(e, y0v.v[w], y1v.v[w]);
@@ -446,7 +479,7 @@ __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restri
   if (VEC && lb == 0) {
     const int64_t i = start + nvec * W + threadIdx.x;
     if (i < start + len) {
-      T e = kp[0][i] * c[0];
+      T e = PRE ? epre[i] + kp[0][i] * c[0] : kp[0][i] * c[0];
       for (int j = 1; j < NK; ++j) e = e + kp[j][i] * c[j];
       one(e, y0[i], y1[i]);
     }
@@ -528,6 +561,10 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
   const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
   T acc = T(0);
   int nf = 0;
+  if (a.e_pre) {  // host guarantees nk == 1 in this mode: e = e_pre + k_last * (dt * c_last)
+    if (a.nt) errnorm_body<T, 1, NORM, VEC, true, true>(a, y0, k0, dt, seg, lb, nb, acc, nf);
+    else errnorm_body<T, 1, NORM, VEC, false, true>(a, y0, k0, dt, seg, lb, nb, acc, nf);
+  } else
   switch (a.nk) {
     case 1: if (a.nt) errnorm_body<T, 1, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 1, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
     case 2: if (a.nt) errnorm_body<T, 2, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 2, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
@@ -1244,7 +1281,7 @@ int64_t xde_workspace_bytes(void) { return int64_t(sizeof(NormSlot)) * kSlots; }
 
 int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
                       const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
-                      int64_t n, int dtype, void* stream) {
+                      int64_t n, int dtype, void* out2, const double* coef2, void* stream) {
   if (!out || !y0 || !k || !coef) return fail(XDE_EBADARG, "xde_stage_combine: null pointer");
   if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_stage_combine: nk out of range");
   if (n < 0) return fail(XDE_EBADARG, "xde_stage_combine: negative n");
@@ -1252,10 +1289,13 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_stage_combine: bad dtype");
   if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: y0_alt/k0_alt must come together");
   if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_stage_combine: operand select needs ctrl");
+  if ((out2 == nullptr) != (coef2 == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: out2/coef2 must come together");
+  if (out2 && mode != XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: second output needs mode RK");
   if (n == 0) return XDE_OK;
   CombineArgs a;
   memset(&a, 0, sizeof(a));
   a.out = out;
+  a.out2 = out2;
   a.y0[0] = y0;
   a.y0[1] = y0_alt ? y0_alt : y0;
   a.k0_alt = k0_alt ? k0_alt : k[0];
@@ -1265,8 +1305,10 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
     if (!k[j]) return fail(XDE_EBADARG, "xde_stage_combine: null k[j]");
     a.k[j] = k[j];
     a.coef[j] = coef[j];
+    if (coef2) a.coef2[j] = coef2[j];
     vec = vec && aligned16(k[j]);
   }
+  if (out2) vec = vec && aligned16(out2);
   a.scale = scale;
   a.dt_host = dt_host;
   a.ctrl = ctrl;
@@ -1279,16 +1321,26 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   if (blocks < 1) blocks = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double elt = dtype == XDE_F32 ? 4.0 : 8.0;
-  ProfScope prof(XDE_KID_COMBINE, double(nk + 2) * double(n) * elt);
+  ProfScope prof(XDE_KID_COMBINE, double(nk + 2 + (out2 ? 1 : 0)) * double(n) * elt);
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
 #define LAUNCH_COMBINE(T, MODE)                                                     \
   do {                                                                              \
     if (vec)                                                                        \
-      XDE_LAUNCH((xde_combine_kernel<T, MODE, true>), g, b, st, prof, a);      \
+      XDE_LAUNCH((xde_combine_kernel<T, MODE, true, false>), g, b, st, prof, a);    \
     else                                                                            \
-      XDE_LAUNCH((xde_combine_kernel<T, MODE, false>), g, b, st, prof, a);     \
+      XDE_LAUNCH((xde_combine_kernel<T, MODE, false, false>), g, b, st, prof, a);   \
   } while (0)
-  if (dtype == XDE_F32) {
+#define LAUNCH_COMBINE2(T)                                                                   \
+  do {                                                                                       \
+    if (vec)                                                                                 \
+      XDE_LAUNCH((xde_combine_kernel<T, XDE_COMBINE_RK, true, true>), g, b, st, prof, a);    \
+    else                                                                                     \
+      XDE_LAUNCH((xde_combine_kernel<T, XDE_COMBINE_RK, false, true>), g, b, st, prof, a);   \
+  } while (0)
+  if (out2) {
+    if (dtype == XDE_F32) LAUNCH_COMBINE2(float);
+    else LAUNCH_COMBINE2(double);
+  } else if (dtype == XDE_F32) {
     if (mode == XDE_COMBINE_RK) LAUNCH_COMBINE(float, XDE_COMBINE_RK);
     else if (mode == XDE_COMBINE_FUSE) LAUNCH_COMBINE(float, XDE_COMBINE_FUSE);
     else LAUNCH_COMBINE(float, XDE_COMBINE_WFUSE);
@@ -1298,6 +1350,7 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
     else LAUNCH_COMBINE(double, XDE_COMBINE_WFUSE);
   }
 #undef LAUNCH_COMBINE
+#undef LAUNCH_COMBINE2
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }
@@ -1305,12 +1358,14 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
 int xde_error_norm_partial(const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
                            const void* y0_alt, const void* y1, double rtol, double atol, double dt_host,
                            const xde_ctrl_t* ctrl, const xde_segments_t* segs, int norm_kind, int dtype, void* ws,
-                           void* stream) {
+                           const void* e_pre, void* stream) {
   if (!k || !c_err || !y0 || !y1 || !ws || !segs) return fail(XDE_EBADARG, "xde_error_norm_partial: null pointer");
+  if (e_pre && nk != 1) return fail(XDE_EBADARG, "xde_error_norm_partial: e_pre takes exactly one remaining operand");
   if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_error_norm_partial: nk out of range");
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_error_norm_partial: bad dtype");
   if (norm_kind != XDE_NORM_RMS && norm_kind != XDE_NORM_LINF) return fail(XDE_EBADARG, "xde_error_norm_partial: bad norm");
-  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_error_norm_partial: y0_alt/k0_alt must come together");
+  if (!e_pre && (y0_alt == nullptr) != (k0_alt == nullptr))
+    return fail(XDE_EBADARG, "xde_error_norm_partial: y0_alt/k0_alt must come together");
   if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_error_norm_partial: operand select needs ctrl");
   ErrArgs a;
   memset(&a, 0, sizeof(a));
@@ -1333,6 +1388,8 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   a.ctrl = ctrl;
   a.slot = slot_ptr(ws, 0);
   a.nk = nk;
+  a.e_pre = e_pre;
+  if (e_pre) vec = vec && aligned16(e_pre);
   a.nt = nt_policy() & 1;
   int nblocks = 0;
   int rc = build_segmap(segs, vec ? width : 1, vec, &a.map, &nblocks);
@@ -1340,7 +1397,7 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   hipStream_t st = static_cast<hipStream_t>(stream);
   double total = 0;
   for (int s = 0; s < segs->n_seg; ++s) total += double(segs->seg_len[s]);
-  ProfScope prof(XDE_KID_ERRNORM, double(nk + 2) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
+  ProfScope prof(XDE_KID_ERRNORM, double(nk + 2 + (e_pre ? 1 : 0)) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
   dim3 g(nblocks), b(kBlock);
 #define LAUNCH_ERR(T, NORM)                                                       \
   do {                                                                            \

@@ -126,6 +126,17 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._sol_plan = _nz_plan(c_sol)
         self._err_plan = _nz_plan(tab.c_error)
         self._mid_plan = _nz_plan(self.mid)
+        # Error-estimate fusion: if the last stage (whose output is y1, FSAL) loads every operand the error estimate
+        # needs except the last derivative, it emits the partial sum as a second output and the error-norm kernel
+        # reads {e_partial, k_last, y0, y1} instead of all the k's (Dopri5: 8N -> 4N + 1N written).
+        last_idx = self._stage_plan[-1][0]
+        err_idx = self._err_plan[0]
+        S = self._n_stage
+        self._fuse_err = (
+            self._fsal and err_idx[-1] == S and set(err_idx[:-1]) <= set(last_idx) and float(tab.c_error[S]) != 0.0
+        )
+        if self._fuse_err:
+            self._err2_coef = [float(tab.c_error[j]) for j in last_idx]
 
         # -- segments / norm ---------------------------------------------------------------------
         n = self.y0.numel()
@@ -254,6 +265,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._sums = be.new_sums(dev)
         self._seg_count = self._global_counts()
         self._scratch = torch.empty_like(y0)
+        self._ebuf = torch.empty_like(y0) if self._fuse_err else None
 
         # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
         f0 = self._eval(self._scalar_t(t_span[0], self.dtype), y0)
@@ -311,10 +323,15 @@ class AdaptiveRKSolver(AdaptiveSolver):
         S = self._n_stage
         y_stage = None
         keep = [y0, f0] + ([y0_alt, k0_alt] if alt is not None else [])
+        fuse = self._fuse_err and not self._custom_norm
         for i in range(S):
             idx, coef = self._stage_plan[i]
             out = torch.empty_like(y0) if (i == S - 1 and self._fsal) else self._scratch
-            be.stage_combine(out, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
+            if i == S - 1 and fuse:
+                be.stage_combine(out, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt,
+                                 out2=self._ebuf, coef2=self._err2_coef)
+            else:
+                be.stage_combine(out, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
             ks.append(self._eval(self._t_stage[i], out, live=ks + keep))
             y_stage = out
         if self._fsal:
@@ -332,8 +349,12 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._sums[_hip.XDE_MAX_SEG] = (~torch.isfinite(y0)).sum()
             be.rk_control(ctrl, self._params, None, self._sums, self._t_span_dev, self._step_t_dev, self._t_stage)
             return y1, ks
-        be.error_norm_partial([ks[j] for j in idx], coef, y0, y1, float(self.rtol), float(self.atol), self._xsegs,
-                              self._norm_kind, self._ws, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
+        if fuse:
+            be.error_norm_partial([ks[-1]], [coef[-1]], y0, y1, float(self.rtol), float(self.atol), self._xsegs,
+                                  self._norm_kind, self._ws, ctrl=ctrl, y0_alt=y0_alt, e_pre=self._ebuf)
+        else:
+            be.error_norm_partial([ks[j] for j in idx], coef, y0, y1, float(self.rtol), float(self.atol), self._xsegs,
+                                  self._norm_kind, self._ws, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
         if self.process_group is None:
             be.rk_control(ctrl, self._params, self._ws, None, self._t_span_dev, self._step_t_dev, self._t_stage)
         else:

@@ -46,7 +46,8 @@ class NumpyDoubleBackend:
         return XdeCtrl.from_buffer(ctrl.numpy())
 
     # -- K1 -------------------------------------------------------------------------------------
-    def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None):
+    def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None,
+                      out2=None, coef2=None):
         self.launches.append("combine")
         T = _NP[out.dtype]
         sel = 0
@@ -66,6 +67,12 @@ class NumpyDoubleBackend:
                 acc = kk[0] * cs[0]
                 for j in range(1, len(kk)):
                     acc = acc + kk[j] * cs[j]
+                if out2 is not None:
+                    c2 = [dt * T(c_) for c_ in coef2]
+                    e = kk[0] * c2[0]
+                    for j in range(1, len(kk)):
+                        e = e + kk[j] * c2[j]
+                    _np(out2).reshape(-1)[...] = e
                 o[...] = y + acc
             elif mode == _hip.COMBINE_FUSE:
                 cs = [T(c_) for c_ in coef]
@@ -95,7 +102,7 @@ class NumpyDoubleBackend:
         return vals, nfs
 
     def error_norm_partial(self, ks, c_err, y0, y1, rtol, atol, segs, norm_kind, ws, *, dt_host=0.0, ctrl=None,
-                           y0_alt=None, k0_alt=None):
+                           y0_alt=None, k0_alt=None, e_pre=None):
         self.launches.append("errnorm")
         T = _NP[y0.dtype]
         sel = 0
@@ -108,10 +115,11 @@ class NumpyDoubleBackend:
             dt = T(dt_host)
         y0v = _np(y0_alt if sel else y0).reshape(-1)
         y1v = _np(y1).reshape(-1)
-        kk = [_np(k0_alt if sel else ks[0]).reshape(-1)] + [_np(k).reshape(-1) for k in ks[1:]]
+        k_first = ks[0] if (e_pre is not None or not sel) else k0_alt
+        kk = [_np(k_first).reshape(-1)] + [_np(k).reshape(-1) for k in ks[1:]]
         with np.errstate(all="ignore"):
             cs = [dt * T(c_) for c_ in c_err]
-            e = kk[0] * cs[0]
+            e = kk[0] * cs[0] if e_pre is None else _np(e_pre).reshape(-1) + kk[0] * cs[0]
             for j in range(1, len(kk)):
                 e = e + kk[j] * cs[j]
             tol = T(atol) + T(rtol) * np.fmax(np.abs(y0v), np.abs(y1v))

@@ -74,6 +74,38 @@ def test_stage_combine_misaligned_and_select(be, dbl, dtype):
         assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("nk", [1, 5, 7, 10])
+@pytest.mark.parametrize("n", [3, 4096 + 5, 1 << 20])
+def test_stage_combine_second_output_and_fused_error(be, dbl, dtype, nk, n):
+    """out2 = sum_j k_j (dt c2_j) from the same loaded operands is bit-exact, and the error norm taken from
+    (e_pre = out2, last k) equals the unfused one bit for bit (same association, same reduction tree)."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    y0 = _rand(n, dt, 1, dev)
+    ks = [_rand(n, dt, 10 + j, dev) for j in range(nk)]
+    klast = _rand(n, dt, 99, dev)
+    coef = list(np.linspace(-1.3, 2.1, nk))
+    coef2 = list(np.linspace(0.7, -0.2, nk) * 1e-3)
+    out, out2 = torch.empty_like(y0), torch.empty_like(y0)
+    be.stage_combine(out, y0, ks, coef, _hip.COMBINE_RK, dt_host=0.0371, out2=out2, coef2=coef2)
+    ref, ref2 = torch.empty(n, dtype=dt), torch.empty(n, dtype=dt)
+    dbl.stage_combine(ref, y0.cpu(), [k.cpu() for k in ks], coef, _hip.COMBINE_RK, dt_host=0.0371, out2=ref2, coef2=coef2)
+    assert torch.equal(out.cpu(), ref) and torch.equal(out2.cpu(), ref2)
+    plain = torch.empty_like(y0)
+    be.stage_combine(plain, y0, ks, coef, _hip.COMBINE_RK, dt_host=0.0371)
+    assert torch.equal(plain, out)  # the first output does not depend on the presence of the second
+    # fused vs unfused error norm
+    segs = _hip.make_segments([(0, n)])
+    ws, sums_a, sums_b = be.new_workspace(dev), be.new_sums(dev), be.new_sums(dev)
+    c_last = -1.0 / 60.0
+    be.error_norm_partial(ks + [klast], coef2 + [c_last], y0, out, 1e-3, 1e-5, segs, _hip.NORM_RMS, ws, dt_host=0.0371)
+    be.norm_finalize(ws, 0, sums_a)
+    be.error_norm_partial([klast], [c_last], y0, out, 1e-3, 1e-5, segs, _hip.NORM_RMS, ws, dt_host=0.0371, e_pre=out2)
+    be.norm_finalize(ws, 0, sums_b)
+    assert torch.equal(sums_a, sums_b)
+
+
 def test_bad_arguments_fail_loudly(be):
     dev = torch.device("cuda:0")
     y = torch.zeros(8, device=dev)
