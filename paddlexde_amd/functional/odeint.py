@@ -69,6 +69,10 @@ def _odeint_tuple(func, y0, t_span, solver, *, rtol, atol, options):
     device = y0[0].device
     flat0 = _pack(y0, segs, total, dtype, device)
     fixed = isinstance(solver, type) and issubclass(solver, FixedSolver)
+    options = dict(options)
+    # private hook (odeint_adjoint): a ready-made dynamics on the FLAT state with this exact layout, e.g. a
+    # HIP-graph-captured one; it replaces the unpack -> func -> pack wrapper below
+    ready_flat = options.pop("_xde_flat_func", None)
 
     def unpack(flat):
         return tuple(flat[s : s + n].view(shape) for (s, n), shape in zip(segs, shapes))
@@ -85,9 +89,11 @@ def _odeint_tuple(func, y0, t_span, solver, *, rtol, atol, options):
             return _pack(func(t, unpack(y)), segs, total, dtype, device)
 
         y_in = flat0
-        opts = dict(options)
+        opts = options
         opts["_xde_segments"] = segs
         opts["_xde_segment_shapes"] = shapes
+    if ready_flat is not None:
+        flat_func = ready_flat
 
     xde = BaseODE(flat_func, y0=y_in, t_span=t_span)
     s = solver(xde=xde, y0=xde.y0, rtol=rtol, atol=atol, **opts)

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ..solver.base_fixed_solver import FixedSolver
 from ..utils.ode_utils import _mixed_norm, _rms_norm, native_norm_spec
-from .odeint import odeint
+from .odeint import _pack, _segment_layout, odeint
 
 
 def _is_fixed(solver):
@@ -168,13 +168,11 @@ class OdeintAdjointMethod(torch.autograd.Function):
             #    Set up backward ODE func    #
             ##################################
             augmented_dynamics = _make_augmented_dynamics(func, adjoint_params, t_requires_grad)
-            graphed = adjoint_options.get("_graphed")
-            if graphed is not None:
-
-                def augmented_dynamics(t, y_aug):  # noqa: F811  outputs are consumed at once by the tuple packer
-                    return graphed(t, (y_aug[1], y_aug[2]))
-
             solver_options = {k: v for k, v in adjoint_options.items() if k not in ("graph_func", "_graphed")}
+            if adjoint_options.get("_graphed") is not None:
+                # the captured FLAT dynamics (same segment layout as odeint's tuple flattening) replaces the
+                # unpack -> dynamics -> pack wrapper: 2 input copies + 1 replay + 1 clone per evaluation
+                solver_options["_xde_flat_func"] = adjoint_options["_graphed"]
 
             ##################################
             #       Solve adjoint ODE        #
@@ -280,7 +278,7 @@ def odeint_adjoint(
     # It has to happen HERE — on the calling thread and outside the autograd Function: capturing from the engine's
     # worker thread (where backward runs), or inside Function.forward while the parameters are its inputs, crashes
     # the runtime.
-    if adjoint_options.get("graph_func", False) and y0.is_cuda:
+    if adjoint_options.get("graph_func", False):
         from ..utils.graphed import GraphedFunc
 
         if not isinstance(func, nn.Module):
@@ -290,15 +288,32 @@ def odeint_adjoint(
         else:
             cache = _GRAPH_CACHE.setdefault(func, {})
         t_rg = bool(t_span.requires_grad)
-        key = ("aug", tuple(y0.shape), y0.dtype, str(y0.device), t_rg, tuple(id(p) for p in adjoint_params))
+        fixed = _is_fixed(adjoint_solver)
+        key = ("aug-flat", tuple(y0.shape), y0.dtype, str(y0.device), t_rg, fixed, tuple(id(p) for p in adjoint_params))
         graphed = cache.get(key)
+        # the augmented state (adj_t, y, adj_y, *adj_params) in the flat, 16-byte-segment layout odeint() will use
+        aug_example = [torch.zeros([], dtype=y0.dtype, device=y0.device), y0.detach(), torch.zeros_like(y0)]
+        aug_example += [torch.zeros_like(p) for p in adjoint_params]
+        adt, segs, total = _segment_layout(aug_example)
         if graphed is None:
             dyn = _make_functional_dynamics(func, adjoint_params, t_rg)
-            graphed = GraphedFunc(lambda t, ya: dyn(t, (None, ya[0], ya[1])), clone_outputs=False)
+            (s1, n1), (s2, n2) = segs[1], segs[2]
+            yshape = tuple(y0.shape)
+            dev = y0.device
+
+            def flat_dynamics(t, yf):
+                # unpack views -> func + vjp -> pack, all inside ONE captured graph
+                v = yf[0] if fixed else yf
+                outs = dyn(t, (None, v[s1 : s1 + n1].view(yshape), v[s2 : s2 + n2].view(yshape)))
+                k = _pack(outs, segs, total, adt, dev)
+                return k[None, :] if fixed else k
+
+            graphed = GraphedFunc(flat_dynamics, clone_outputs=True)
             cache[key] = graphed
-        y_ex = y0.detach()
+        flat_ex = _pack(aug_example, segs, total, adt, y0.device)
+        flat_ex = flat_ex[None, :] if fixed else flat_ex
         for t_ex in _graph_time_examples(adjoint_solver, adjoint_options, t_span, y0):
-            graphed.prepare(t_ex, (y_ex, torch.zeros_like(y_ex)))
+            graphed.prepare(t_ex, flat_ex)
         adjoint_options["_graphed"] = graphed
 
     solution = OdeintAdjointMethod.apply(

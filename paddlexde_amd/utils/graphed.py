@@ -45,6 +45,9 @@ class GraphedFunc:
 
     def prepare(self, t, y):
         """Capture the graph for this input signature now (call from the main thread)."""
+        first = y[0] if isinstance(y, (tuple, list)) else y
+        if not first.is_cuda:
+            return None  # host tensors (test double): __call__ evaluates func directly
         key = self._signature(t, y)
         if key in self._captures:
             return self._captures[key]

@@ -196,6 +196,28 @@ def test_custom_norm_callable(dev):
         odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, options={"norm": my_norm, "pipeline": "lag"})
 
 
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+def test_mixed_precision_fp32_state_fp64_time(dev, pipeline):
+    """State in float32, time-like scalars in float64 (options["dtype"], base_adaptive_solver_rk.py:47-69): the
+    controller runs in double while stage times and the ratio are rounded to the state dtype."""
+    A, y0 = _linear(256, 32, torch.float32)
+    t = torch.linspace(0.0, 2.0, 9, dtype=torch.float64)
+    An = A.numpy()
+    ref, so = O.odeint(lambda t_, y: y @ An.T, y0.numpy(), t.numpy(), "dopri5", rtol=1e-4, atol=1e-6,
+                       options={"norm": O._rms_norm, "dtype": np.float64}, return_solver=True)
+    Ad = A.to(dev)
+    from paddlexde_amd.xde import BaseODE
+
+    xde = BaseODE(lambda t_, y: y @ Ad.T, y0=y0.to(dev), t_span=t)
+    s = Dopri5(xde=xde, y0=xde.y0, rtol=1e-4, atol=1e-6, norm=_rms_norm, dtype=torch.float64, pipeline=pipeline, record_trace=True)
+    got = s.integrate(t)
+    assert got.dtype == torch.float32 and ref.dtype == np.float32
+    assert P.rel_err(got.cpu().numpy(), ref) <= 1e-5
+    assert (s.stats["n_accept"], s.stats["n_reject"]) == (so.n_accept, so.n_reject)
+    # dt is a genuine double (not float32-representable) from the second step on
+    assert any(float(np.float32(d)) != d for _, d, _, _ in s.trace[1:])
+
+
 def test_repeated_start_time_rows(dev):
     """t_span = [t0, t0, t1]: the reference's loop takes no step for the second row; it must equal y0."""
     A, y0 = _linear(8, 4, torch.float64)
