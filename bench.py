@@ -176,6 +176,8 @@ def side_workload(args):
             if name == "dopri5":
                 opts["pipeline"] = args.pipeline
             aopts = {k: v for k, v in opts.items() if k != "norm"}
+            if "pipeline" in aopts:
+                aopts["pipeline"] = "sync"  # adjoint intervals are 1-3 steps long: speculation would waste an attempt each
             if args.graph_func:
                 aopts["graph_func"] = True
             pred = odeint_adjoint(func, y0, t, solver=solver, rtol=1e-5, atol=1e-7, options=opts, adjoint_options=aopts)

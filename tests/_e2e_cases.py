@@ -218,6 +218,31 @@ def test_mixed_precision_fp32_state_fp64_time(dev, pipeline):
     assert any(float(np.float32(d)) != d for _, d, _, _ in s.trace[1:])
 
 
+def test_pi_controller_is_opt_in(dev):
+    """north_star mentions a PI controller; the reference has a plain I-controller (SURVEY D9).  Default = reference;
+    controller="PI" (Hairer's dopri5 form) changes the step sequence and still meets the tolerance."""
+    import scipy.linalg
+
+    from paddlexde_amd.xde import BaseODE
+
+    mu = 5.0
+    y0 = torch.tensor([[2.0, 0.0]], dtype=torch.float64).repeat(16, 1).to(dev)
+    t = torch.tensor([0.0, 6.0], dtype=torch.float64)
+    runs = {}
+    for ctl in ("I", "PI"):
+        xde = BaseODE(P.vdp_torch(mu), y0=y0, t_span=t)
+        s = Dopri5(xde=xde, y0=y0, rtol=1e-7, atol=1e-9, norm=_rms_norm, dtype=torch.float64, controller=ctl, record_trace=True)
+        runs[ctl] = (s.integrate(t), s)
+    assert Dopri5(xde=BaseODE(P.vdp_torch(mu), y0=y0, t_span=t), y0=y0, rtol=1e-7, atol=1e-9, norm=_rms_norm).controller == "I"
+    ref = O.odeint(P.vdp_np(mu), y0.cpu().numpy(), t.numpy(), "dopri5", rtol=1e-10, atol=1e-12, options={"norm": O._rms_norm, "dtype": np.float64})
+    for ctl in ("I", "PI"):
+        assert P.rel_err(runs[ctl][0].cpu().numpy(), ref) <= 1e-5, ctl
+    dts_i = [d for _, d, _, _ in runs["I"][1].trace]
+    dts_pi = [d for _, d, _, _ in runs["PI"][1].trace]
+    assert dts_i != dts_pi  # the PI law really is active
+    assert runs["PI"][1].stats["n_reject"] <= runs["I"][1].stats["n_reject"]  # smoother step-size sequence
+
+
 def test_repeated_start_time_rows(dev):
     """t_span = [t0, t0, t1]: the reference's loop takes no step for the second row; it must equal y0."""
     A, y0 = _linear(8, 4, torch.float64)
