@@ -154,7 +154,7 @@ ADAPTIVE = {
     "adaptive_heun": (2, ADAPTIVE_HEUN_TABLEAU, ADAPTIVE_HEUN_MID),  # adaptive_heun.py:23-26
     "dopri8": (8, DOPRI8_TABLEAU, DOPRI8_MID),  # dopri8.py:249-252
 }
-FIXED = ("euler", "midpoint", "rk4", "rk4_classic")
+FIXED = ("euler", "midpoint", "rk4", "rk4_classic", "adams", "adams_implicit")
 
 
 # --------------------------------------------------------------------------------------
@@ -235,6 +235,34 @@ def cubic_hermite_interp(t0, y0, dy0, t1, y1, dy1, t):
     return h00 * y0 + h10 * dt * dy0 + h01 * y1 + h11 * dt * dy1
 
 
+def _lagrange_integrals(nodes):
+    """int_0^1 of the Lagrange basis polynomials for ``nodes`` (exact rationals) — the definition of the Adams
+    coefficients the reference tabulates (fixed_solver/adams.py:9-438)."""
+    from fractions import Fraction
+
+    out = []
+    for j, xj in enumerate(nodes):
+        poly = [Fraction(1)]
+        for i, xi in enumerate(nodes):
+            if i != j:
+                a, b = Fraction(-xi) / (xj - xi), Fraction(1) / (xj - xi)
+                nxt = [Fraction(0)] * (len(poly) + 1)
+                for d, c in enumerate(poly):
+                    nxt[d] += c * a
+                    nxt[d + 1] += c * b
+                poly = nxt
+        out.append(sum(c / (d + 1) for d, c in enumerate(poly)))
+    return out
+
+
+def _adams_bashforth(k):
+    return _lagrange_integrals([-i for i in range(k)])
+
+
+def _adams_moulton(k):
+    return _lagrange_integrals([1 - i for i in range(k)])
+
+
 class FixedSolver:
     """base_fixed_solver.py:14-197 with the default grid (``grid_constructor = lambda y0, t: t``)."""
 
@@ -250,6 +278,11 @@ class FixedSolver:
         if step_size is not None or grid_constructor is not None:
             raise NotImplementedError("step_size / grid_constructor sub-stepping is broken in the reference (D7)")
         self.nfe = 0
+        # AdamsBashforthMoulton state (fixed_solver/adams.py:457-498)
+        self.max_order = int(kwargs.get("max_order", 12))
+        self.max_iters = int(kwargs.get("max_iters", 4))
+        self.prev_f = collections.deque(maxlen=self.max_order - 1)
+        self.warned_not_converged = 0
 
     # BaseODE.move / fuse                                         xde/base_ode.py:47-58
     def move(self, t0, dt, y0):
@@ -279,7 +312,46 @@ class FixedSolver:
         if self.method == "rk4_classic":  # base_fixed_solver.py:146-164 (unused by the reference's RK4)
             f0 = self.move(t0, t1 - t0, y0)
             return self.rk4_step_func(t0, t1, y0, f0=f0), f0
+        if self.method in ("adams", "adams_implicit"):
+            return self._adams_step(t0, t1, y0)
         raise ValueError(self.method)
+
+    def _adams_step(self, t0, t1, y0):
+        """fixed_solver/adams.py:507-547.  The history is a newest-first list of derivatives; ``dy`` is the linear
+        combination the coefficient tables define (the reference's concat-on-batch-axis + paddle.dot cannot run as
+        written).  Sums run left to right."""
+        dt = t1 - t0
+        f0 = self.move(t0, dt, y0)
+        self.prev_f.appendleft(f0)
+        order = min(len(self.prev_f), self.max_order - 1)
+        if order < 3:
+            return self.rk4_alt_step_func(t0, t1, y0, f0=f0), f0
+        hist = list(self.prev_f)[:order]
+        yt = y0.dtype.type
+        b = [yt(float(c)) for c in _adams_bashforth(order)]
+        dy = hist[0] * b[0]
+        for j in range(1, order):
+            dy = dy + hist[j] * b[j]
+        if self.method == "adams_implicit":
+            m = [yt(float(c)) for c in _adams_moulton(order + 1)]
+            converged = False
+            f = None
+            for _ in range(self.max_iters):
+                dy_old = dy
+                f = self.move(t1, dt, self.fuse(dy, dt, y0))
+                ops = [f] + hist
+                dy = ops[0] * m[0]
+                for j in range(1, order + 1):
+                    dy = dy + ops[j] * m[j]
+                ratio = compute_error_ratio(np.abs(dy_old - dy), yt(self.rtol), yt(self.atol), dy_old, dy, _linf_norm)
+                converged = bool(ratio < 1)
+                if converged:
+                    break
+            if not converged:
+                self.warned_not_converged += 1
+                self.prev_f.pop()
+            self.prev_f.appendleft(f)
+        return self.fuse(dy, dt, y0), f0
 
     def rk4_step_func(self, t0, t1, y0, f0=None):
         """base_fixed_solver.py:146-164"""

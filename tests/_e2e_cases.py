@@ -11,13 +11,13 @@ import torch
 import torch.nn as nn
 
 from oracle import xde_oracle as O
-from paddlexde_amd import RK4, AdaptiveHeun, Bosh3, Dopri5, Dopri8, Euler, Fehlberg2, Midpoint, _hip, odeint, odeint_adjoint
+from paddlexde_amd import RK4, AdamsBashforthMoulton, AdaptiveHeun, Bosh3, Dopri5, Dopri8, Euler, Fehlberg2, Midpoint, _hip, odeint, odeint_adjoint
 from paddlexde_amd.utils import _linf_norm, _rms_norm
 
 from . import problems as P
 
 
-FIXED = {"euler": Euler, "midpoint": Midpoint, "rk4": RK4}
+FIXED = {"euler": Euler, "midpoint": Midpoint, "rk4": RK4, "adams": AdamsBashforthMoulton}
 ADAPTIVE = {"dopri5": Dopri5, "bosh3": Bosh3, "fehlberg2": Fehlberg2, "adaptive_heun": AdaptiveHeun, "dopri8": Dopri8}
 
 
@@ -54,7 +54,7 @@ def test_reference_adaptive(dev, name, ode):
 # ----------------------------------------------------------------------------------------------
 # config 1: the spiral demo, RK4 (reference variant), batch=1, dim=2 — against the oracle
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", list(FIXED) )
+@pytest.mark.parametrize("name", ["euler", "midpoint", "rk4"])  # (Adams: test_adams_bashforth_moulton_vs_oracle)
 def test_spiral_fixed_vs_oracle(dev, name):
     y0 = np.array([[2.0, 0.0]], dtype=np.float32)
     t = np.linspace(0.0, 25.0, 1000).astype(np.float32)
@@ -65,6 +65,23 @@ def test_spiral_fixed_vs_oracle(dev, name):
     assert got.shape == ref.shape == (len(t), 2)
     # every kernel is bit-exact and func uses only +,-,*: the whole trajectory is bit-exact
     assert np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("implicit", [False, True])
+def test_adams_bashforth_moulton_vs_oracle(dev, implicit):
+    """AdamsBashforthMoulton (fixed_solver/adams.py:457-547): RK4-variant bootstrap, then the explicit predictor of the
+    highest available order (<= max_order - 1), optionally the Adams-Moulton corrector iterations — bit-exact."""
+    rng = np.random.RandomState(5)
+    y0 = rng.uniform(-1.0, 1.0, size=(3, 2)).astype(np.float32)
+    t = np.linspace(0.0, 0.2, 41).astype(np.float32)
+    name = "adams_implicit" if implicit else "adams"
+    for max_order in (4, 6, 12):
+        ref = O.odeint(P.spiral_np, y0, t, name, rtol=1e-3, atol=1e-4, options={"norm": O._rms_norm, "max_order": max_order})
+        got = odeint(P.spiral_torch, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), solver=AdamsBashforthMoulton,
+                     rtol=1e-3, atol=1e-4, options={"norm": _rms_norm, "implicit": implicit, "max_order": max_order})
+        assert got.shape == ref.shape == (41 * 3, 2)
+        assert np.isfinite(ref).all()
+        assert np.array_equal(got.cpu().numpy(), ref), (implicit, max_order, float(np.abs(got.cpu().numpy() - ref).max()))
 
 
 def test_fixed_layout_batched(dev):
