@@ -144,11 +144,13 @@ int64_t xde_workspace_bytes(void);
  *   operands.  The last stage of an FSAL pair loads exactly the operands the error estimate needs, so it emits the
  *   partial error sum there (`y1_error` minus its last term, base_adaptive_solver_rk.py:180) and the error-norm
  *   kernel reads 4 arrays instead of 8 (xde_error_norm_partial, e_pre).
+ *   damping (FUSE/WFUSE): lambda of the delay-equation wrapper's fuse, `y = dy*dt + y0; (dy - lambda*y)*dt + y0`
+ *   (xde/base_dde.py:55-58; the reference uses 0.001); 0 selects BaseODE.fuse.
  */
 int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k,
                       const void* k0_alt, const double* coef, int nk, int mode, double scale,
                       double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, void* out2,
-                      const double* coef2, void* stream);
+                      const double* coef2, double damping, void* stream);
 
 /*
  * Error-norm partials — replaces `y1_error = sum(k * (dt * c_error), -1)` (base_adaptive_solver_rk.py:180),
@@ -270,6 +272,17 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
  */
 int xde_scale_fanout(void* const* outs, const void* g, const double* factors, int nout, const double* dt_dev,
                      int64_t n, int dtype, void* stream);
+
+/*
+ * Delay-equation history gather — replaces HistoryIndex.forward (xde/base_dde.py:82-121): the cubic-Hermite
+ * spline of the history `his[outer, T, D]` sampled at `his_t[T]` is evaluated at the L learned lags, together with
+ * its time derivative (needed by HistoryIndex.backward for d loss / d lags), in ONE pass:
+ * CubicHermiteSpline.evaluate / .derivative (interpolation/interpolate_base.py:50-107,
+ * interpolation/interpolate.py:100-204), including its conventions (index = clip(bucketize(t)-1, 0, T-1),
+ * one-sided differences as node derivatives, the last interval repeated).  val_out, der_out: [outer, L, D].
+ */
+int xde_hermite_gather(void* val_out, void* der_out, const void* his, const void* his_t, const void* lags,
+                       int64_t outer, int T, int D, int L, int dtype, void* stream);
 
 /*
  * Predicated commit for the hipGraph pipeline (operand addresses are baked into a captured graph, so the

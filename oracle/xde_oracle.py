@@ -787,3 +787,118 @@ def odeint_adjoint(func, vjp, params, y0, t_span, solver, *, rtol=1e-7, atol=1e-
         return aug_state[2], list(aug_state[3:])
 
     return ans, backward
+
+
+# --------------------------------------------------------------------------------------
+# delay equations: history spline + ddeint
+#   (paddlexde/interpolation/interpolate_base.py, interpolation/interpolate.py:100-204,
+#    paddlexde/xde/base_dde.py, paddlexde/functional/ddeint.py)
+# --------------------------------------------------------------------------------------
+
+_HERMITE_H = np.array([[2.0, -2.0, 1.0, 1.0], [-3.0, 3.0, -2.0, -1.0], [0.0, 0.0, 1.0, 0.0], [1.0, 0.0, 0.0, 0.0]])
+
+
+class CubicHermiteSpline:
+    """interpolation/interpolate.py:100-204 on interpolation/interpolate_base.py:7-107, as written: series [..., T, D],
+    node derivatives = one-sided differences (the last one repeated twice), ``ps = [p_i/scale1_i, p_{i+1}/scale2_i,
+    d_i, d_{i+1}]``, ``evaluate = ([s^3,s^2,s,1] @ H @ ps) * scale1_i``, ``derivative = [3s^2,2s,1,0] @ H @ ps``."""
+
+    def __init__(self, series, t=None, dtype=np.float32):
+        series = np.asarray(series).astype(dtype)
+        if t is None:
+            t = np.linspace(0, series.shape[-2], series.shape[-2] + 1)
+        t = np.asarray(t).astype(dtype)
+        self._t = t
+        self._series = series
+        self.dtype = dtype
+        # _make_series :136-160
+        scale = t[1:] - t[:-1]
+        scale1 = np.concatenate([scale, scale[-1:]])
+        scale2 = np.concatenate([scale[:1], scale1[:-1]])
+        series2 = np.concatenate([series[..., 1:, :], series[..., -1:, :]], axis=-2)
+        self._series_arr = np.stack([series / scale1[:, None], series2 / scale2[:, None]], axis=-2)  # [..., T, 2, D]
+        self._scale_t = scale1
+        # _make_derivative :162-183
+        diffs_t1 = np.concatenate([scale, scale[-1:]])
+        diffs = series[..., 1:, :] - series[..., :-1, :]
+        diffs = np.concatenate([diffs, diffs[..., -1:, :]], axis=-2)
+        derivs = diffs / diffs_t1[:, None]
+        self._derivs = np.concatenate([derivs, derivs[..., -1:, :]], axis=-2)  # T + 1 entries
+        self._h = _HERMITE_H.astype(dtype)
+
+    def _interpolate(self, t, der):
+        t = np.atleast_1d(np.asarray(t).astype(self.dtype))
+        maxlen = self._series.shape[-2] - 1
+        index = np.clip(np.searchsorted(self._t, t, side="left") - 1, 0, maxlen)  # paddle.bucketize(t, self._t) - 1
+        norm_t = (t - self._t[index]) / self._scale_t[index]
+        one, zero = np.ones_like(norm_t), np.zeros_like(norm_t)
+        if not der:
+            ts = np.stack([norm_t**3, norm_t**2, norm_t, one], axis=-1)[:, None, :]  # [L, 1, 4]
+        else:
+            ts = np.stack([3 * norm_t**2, 2 * norm_t, one, zero], axis=-1)[:, None, :]
+        ps = np.stack(
+            [
+                np.take(self._series_arr[..., 0, :], index, axis=-2),
+                np.take(self._series_arr[..., 1, :], index, axis=-2),
+                np.take(self._derivs, index, axis=-2),
+                np.take(self._derivs, index + 1, axis=-2),
+            ],
+            axis=-2,
+        )  # [..., L, 4, D]
+        return ts.astype(self.dtype), ps.astype(self.dtype), index
+
+    def evaluate(self, t):
+        ts, ps, index = self._interpolate(t, der=False)
+        result = ((ts @ self._h) @ ps).squeeze(-2)
+        return result * self._scale_t[index][:, None]
+
+    def derivative(self, t):
+        ts, ps, index = self._interpolate(t, der=True)
+        return ((ts @ self._h) @ ps).squeeze(-2)
+
+
+def history_index(lags, his, his_span, dtype=np.float32):
+    """HistoryIndex.forward / backward (xde/base_dde.py:82-127): returns (y_lags, grad_fn) with
+    ``grad_fn(grad_y) = sum over every axis but the lag axis of grad_y * derivative``."""
+    interp = CubicHermiteSpline(his, his_span, dtype=dtype)
+    y_lags = interp.evaluate(lags)
+    der = interp.derivative(lags)
+
+    def grad_lags(grad_y):
+        g = np.asarray(grad_y) * der
+        axes = tuple(a for a in range(g.ndim) if a != g.ndim - 2)
+        return g.sum(axis=axes)
+
+    return y_lags, grad_lags
+
+
+_DDE_LAMBDA = 0.001
+
+
+class DDEFixedSolver(FixedSolver):
+    """FixedSolver driven by BaseDDE (xde/base_dde.py:47-58): ``move = func(y_lags, y0)``, damped ``fuse``."""
+
+    def __init__(self, func, y0, y_lags, **kw):
+        super().__init__(func, y0, **kw)
+        self.y_lags = y_lags
+
+    def move(self, t0, dt, y0):
+        self.nfe += 1
+        return np.asarray(self.func(self.y_lags, y0))
+
+    @staticmethod
+    def fuse(dy, dt, y0):
+        y = dy * dt + y0
+        return (dy - _DDE_LAMBDA * y) * dt + y0
+
+
+def ddeint(func, y0, t_span, lags, his, his_span, solver, his_processed=False, rtol=1e-7, atol=1e-9, options=None,
+           fixed_solver_interp="linear"):
+    """functional/ddeint.py:9-47 — returns (solution, y_lags)."""
+    options = dict({"norm": _rms_norm} if options is None else options)
+    if not his_processed:
+        y_lags, _ = history_index(lags, his, his_span, dtype=np.asarray(his).dtype if np.asarray(his).dtype in (np.float32, np.float64) else np.float32)
+    else:
+        y_lags = np.asarray(his)
+    s = DDEFixedSolver(func, np.asarray(y0), y_lags, method=solver, rtol=rtol, atol=atol, interp=fixed_solver_interp, **options)
+    return s.integrate(np.asarray(t_span)), y_lags

@@ -43,6 +43,7 @@ SYMBOLS = (
     "xde_ctrl_wait",
     "xde_dense_eval",
     "xde_commit",
+    "xde_hermite_gather",
     "xde_scale_fanout",
     "xde_prof_enable",
     "xde_prof_collect",
@@ -148,7 +149,7 @@ def load_library():
         lib.xde_sizeof_ctrl.restype = i64
         lib.xde_workspace_bytes.restype = i64
         lib.xde_stage_combine.restype = i32
-        lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, vp]
+        lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, vp]
         lib.xde_error_norm_partial.restype = i32
         lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp, vp]
         lib.xde_error_ratio.restype = i32
@@ -175,6 +176,8 @@ def load_library():
         lib.xde_dense_eval.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i64, vp]
         lib.xde_scale_fanout.restype = i32
         lib.xde_scale_fanout.argtypes = [vpp, vp, dp, i32, vp, i64, i32, vp]
+        lib.xde_hermite_gather.restype = i32
+        lib.xde_hermite_gather.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         lib.xde_commit.restype = i32
         lib.xde_commit.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
         lib.xde_prof_enable.restype = i32
@@ -286,14 +289,14 @@ class HipBackend:
 
     # -- kernels ---------------------------------------------------------------------------
     def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None,
-                      out2=None, coef2=None):
+                      out2=None, coef2=None, damping=0.0):
         self._require_device(out, y0, out2, *ks)
         if out.numel() == 0:
             return
         rc = self.lib.xde_stage_combine(
             out.data_ptr(), y0.data_ptr(), _ptr(y0_alt), _ptr_array(ks), _ptr(k0_alt), _dbl_array(coef), len(ks),
             mode, float(scale), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype), _ptr(out2),
-            _dbl_array(coef2) if coef2 is not None else None, self._stream(out),
+            _dbl_array(coef2) if coef2 is not None else None, float(damping), self._stream(out),
         )
         self._check(rc, "xde_stage_combine")
 
@@ -397,6 +400,15 @@ class HipBackend:
         rc = self.lib.xde_scale_fanout(_ptr_array(outs), g.data_ptr(), _dbl_array(factors), len(outs), _ptr(dt_dev), g.numel(),
                                        dtype_code(g.dtype), self._stream(g))
         self._check(rc, "xde_scale_fanout")
+
+    def hermite_gather(self, val, der, his, his_t, lags):
+        """his [..., T, D] (contiguous), his_t [T], lags [L]  ->  val, der [..., L, D]."""
+        self._require_device(val, der, his, his_t, lags)
+        T, D = his.shape[-2], his.shape[-1]
+        outer = his.numel() // (T * D) if T * D else 0
+        rc = self.lib.xde_hermite_gather(val.data_ptr(), der.data_ptr(), his.data_ptr(), his_t.data_ptr(), lags.data_ptr(), outer,
+                                         T, D, lags.numel(), dtype_code(his.dtype), self._stream(his))
+        self._check(rc, "xde_hermite_gather")
 
     def commit(self, ctrl, y0_dst, y1_src, f0_dst, f1_src):
         self._require_device(ctrl, y0_dst, y1_src, f0_dst, f1_src)

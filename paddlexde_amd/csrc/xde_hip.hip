@@ -136,6 +136,7 @@ struct CombineArgs {
   double coef[XDE_MAX_K];
   double scale;
   double dt_host;
+  double damp;  // BaseDDE.fuse: (dy - damp * (dy*dt + y0)) * dt + y0   (0 = BaseODE.fuse)
   const xde_ctrl_t* ctrl;
   int64_t n;
   int nk;
@@ -207,6 +208,15 @@ struct DenseArgs {
   int64_t expect_step;
 };
 
+// fuse(dy, dt, y0): BaseODE `dy*dt + y0` (xde/base_ode.py:58) or, with damping, BaseDDE
+// `y = dy*dt + y0; (dy - lambda*y)*dt + y0` (xde/base_dde.py:55-58), same op order
+template <typename T>
+__device__ __forceinline__ T fuse_(T dy, T dt, T y0, T lam) {
+  if (lam == T(0)) return dy * dt + y0;
+  T y = dy * dt + y0;
+  return (dy - lam * y) * dt + y0;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: stage combine
 // ------------------------------------------------------------------------------------------
@@ -230,6 +240,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
     c2[j] = OUT2 ? dt * T(a.coef2[j]) : T(0);  // `dt * tableau.c_error`
   }
   const T scale = T(a.scale);
+  const T lam = T(a.damp);
   const int64_t nvec = a.n / W;
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
@@ -256,11 +267,11 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
         T acc = kk[0].v[w] * c[0];
 #pragma unroll
         for (int j = 1; j < NK; ++j) acc = acc + kk[j].v[w] * c[j];
-        o.v[w] = acc * dt + y.v[w];
+        o.v[w] = fuse_(acc, dt, y.v[w], lam);
       } else {
-        T acc = (kk[0].v[w] * dt + y.v[w]) * c[0];
+        T acc = fuse_(kk[0].v[w], dt, y.v[w], lam) * c[0];
 #pragma unroll
-        for (int j = 1; j < NK; ++j) acc = acc + (kk[j].v[w] * dt + y.v[w]) * c[j];
+        for (int j = 1; j < NK; ++j) acc = acc + fuse_(kk[j].v[w], dt, y.v[w], lam) * c[j];
         o.v[w] = acc * scale;
       }
     }
@@ -280,13 +291,13 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
         out2[i] = e;
       }
       if (MODE == XDE_COMBINE_WFUSE) {
-        acc = (kp[0][i] * dt + yv) * c[0];
-        for (int j = 1; j < NK; ++j) acc = acc + (kp[j][i] * dt + yv) * c[j];
+        acc = fuse_(kp[0][i], dt, yv, lam) * c[0];
+        for (int j = 1; j < NK; ++j) acc = acc + fuse_(kp[j][i], dt, yv, lam) * c[j];
         out[i] = acc * scale;
       } else {
         acc = kp[0][i] * c[0];
         for (int j = 1; j < NK; ++j) acc = acc + kp[j][i] * c[j];
-        out[i] = (MODE == XDE_COMBINE_RK) ? (yv + acc) : (acc * dt + yv);
+        out[i] = (MODE == XDE_COMBINE_RK) ? (yv + acc) : fuse_(acc, dt, yv, lam);
       }
     }
   }
@@ -300,6 +311,7 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
   T* __restrict__ out = static_cast<T*>(a.out);
   const int nk = a.nk;
   const T scale = T(a.scale);
+  const T lam = T(a.damp);
   const int64_t nvec = a.n / W;
   const int64_t stride = int64_t(gridDim.x) * kBlock;
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
@@ -314,7 +326,7 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
       T c2j = has2 ? dt * T(a.coef2[j]) : T(0);
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        T term = (MODE == XDE_COMBINE_WFUSE) ? (kk.v[w] * dt + y.v[w]) * cj : kk.v[w] * cj;
+        T term = (MODE == XDE_COMBINE_WFUSE) ? fuse_(kk.v[w], dt, y.v[w], lam) * cj : kk.v[w] * cj;
         acc.v[w] = (j == 0) ? term : acc.v[w] + term;
         if (has2) e2.v[w] = (j == 0) ? kk.v[w] * c2j : e2.v[w] + kk.v[w] * c2j;
       }
@@ -324,7 +336,7 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       o.v[w] = (MODE == XDE_COMBINE_RK) ? y.v[w] + acc.v[w]
-               : (MODE == XDE_COMBINE_FUSE) ? acc.v[w] * dt + y.v[w]
+               : (MODE == XDE_COMBINE_FUSE) ? fuse_(acc.v[w], dt, y.v[w], lam)
                                             : acc.v[w] * scale;
     }
     o.store(out, i);
@@ -339,12 +351,12 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
       for (int j = 0; j < nk; ++j) {
         const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
         T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
-        T term = (MODE == XDE_COMBINE_WFUSE) ? (kj[i] * dt + yv) * cj : kj[i] * cj;
+        T term = (MODE == XDE_COMBINE_WFUSE) ? fuse_(kj[i], dt, yv, lam) * cj : kj[i] * cj;
         acc = (j == 0) ? term : acc + term;
         if (has2) e2 = (j == 0) ? kj[i] * (dt * T(a.coef2[j])) : e2 + kj[i] * (dt * T(a.coef2[j]));
       }
       if (has2) static_cast<T*>(a.out2)[i] = e2;
-      out[i] = (MODE == XDE_COMBINE_RK) ? yv + acc : (MODE == XDE_COMBINE_FUSE) ? acc * dt + yv : acc * scale;
+      out[i] = (MODE == XDE_COMBINE_RK) ? yv + acc : (MODE == XDE_COMBINE_FUSE) ? fuse_(acc, dt, yv, lam) : acc * scale;
     }
   }
 }
@@ -1141,6 +1153,52 @@ __global__ __launch_bounds__(kBlock) void xde_fanout_kernel(FanoutArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// DDE history gather: cubic-Hermite value and derivative of a [outer, T, D] series at L query times
+// (interpolation/interpolate_base.py:50-107 + interpolation/interpolate.py:100-204), one pass
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void xde_hermite_kernel(T* __restrict__ val, T* __restrict__ der,
+                                                             const T* __restrict__ his, const T* __restrict__ ts,
+                                                             const T* __restrict__ lags, int64_t outer, int Tn, int D, int L) {
+  const int64_t total = outer * int64_t(L) * D;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x; e < total; e += stride) {
+    const int d = int(e % D);
+    const int l = int((e / D) % L);
+    const int64_t o = e / (int64_t(D) * L);
+    const T tau = lags[l];
+    // index = clip(bucketize(tau, t) - 1, 0, T-1); bucketize (right=False) = #{ t_i < tau }
+    int lo = 0, hi = Tn;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (ts[mid] < tau) lo = mid + 1; else hi = mid;
+    }
+    int i = lo - 1;
+    i = i < 0 ? 0 : (i > Tn - 1 ? Tn - 1 : i);
+    auto h_at = [&](int j) -> T {  // scale1[j] = t[j+1]-t[j], last one repeated
+      int jj = j < Tn - 1 ? j : Tn - 2;
+      return ts[jj + 1] - ts[jj];
+    };
+    const T h1 = h_at(i);                 // scale1[i]
+    const T h2 = i == 0 ? h_at(0) : h_at(i - 1);  // scale2[i] = concat(scale[:1], scale1[:-1])[i]
+    const T s = (tau - ts[i]) / h1;
+    const T* row = his + o * int64_t(Tn) * D + d;
+    auto ser = [&](int j) -> T { return row[int64_t(j < Tn ? j : Tn - 1) * D]; };
+    auto drv = [&](int j) -> T {  // derivs has T+1 entries: finite differences, the last two repeat the last one
+      int jj = j < Tn - 1 ? j : Tn - 2;
+      return (ser(jj + 1) - ser(jj)) / h_at(jj);
+    };
+    const T p0 = ser(i) / h1, p1 = ser(i + 1) / h2, d0 = drv(i), d1 = drv(i + 1);
+    // [s^3, s^2, s, 1] @ H  and  [3s^2, 2s, 1, 0] @ H  with H = [[2,-2,1,1],[-3,3,-2,-1],[0,0,1,0],[1,0,0,0]]
+    const T s2 = s * s, s3 = s2 * s;
+    const T c0 = T(2) * s3 - T(3) * s2 + T(1), c1 = T(-2) * s3 + T(3) * s2, c2 = s3 - T(2) * s2 + s, c3 = s3 - s2;
+    const T g0 = T(6) * s2 - T(6) * s, g1 = T(-6) * s2 + T(6) * s, g2 = T(3) * s2 - T(4) * s + T(1), g3 = T(3) * s2 - T(2) * s;
+    val[e] = (((c0 * p0 + c1 * p1) + c2 * d0) + c3 * d1) * h1;  // evaluate(): result *= scale
+    der[e] = ((g0 * p0 + g1 * p1) + g2 * d0) + g3 * d1;         // derivative(): no scale factor
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // predicated commit (hipGraph pipeline): (y0, f0) <- (y1, f1) when the step was accepted
 // ------------------------------------------------------------------------------------------
 template <typename T, bool VEC>
@@ -1281,7 +1339,7 @@ int64_t xde_workspace_bytes(void) { return int64_t(sizeof(NormSlot)) * kSlots; }
 
 int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
                       const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
-                      int64_t n, int dtype, void* out2, const double* coef2, void* stream) {
+                      int64_t n, int dtype, void* out2, const double* coef2, double damping, void* stream) {
   if (!out || !y0 || !k || !coef) return fail(XDE_EBADARG, "xde_stage_combine: null pointer");
   if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_stage_combine: nk out of range");
   if (n < 0) return fail(XDE_EBADARG, "xde_stage_combine: negative n");
@@ -1309,6 +1367,8 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
     vec = vec && aligned16(k[j]);
   }
   if (out2) vec = vec && aligned16(out2);
+  if (damping != 0.0 && mode == XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: damping applies to FUSE/WFUSE");
+  a.damp = damping;
   a.scale = scale;
   a.dt_host = dt_host;
   a.ctrl = ctrl;
@@ -1715,6 +1775,28 @@ int xde_scale_fanout(void* const* outs, const void* g, const double* factors, in
     if (vec) XDE_LAUNCH((xde_fanout_kernel<double, true>), gr, b, st, prof, a);
     else XDE_LAUNCH((xde_fanout_kernel<double, false>), gr, b, st, prof, a);
   }
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_hermite_gather(void* val_out, void* der_out, const void* his, const void* his_t, const void* lags, int64_t outer,
+                       int T, int D, int L, int dtype, void* stream) {
+  if (!val_out || !der_out || !his || !his_t || !lags) return fail(XDE_EBADARG, "xde_hermite_gather: null pointer");
+  if (outer < 0 || T < 2 || D < 1 || L < 0) return fail(XDE_EBADARG, "xde_hermite_gather: bad sizes (need T >= 2)");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_hermite_gather: bad dtype");
+  const int64_t total = outer * int64_t(L) * D;
+  if (total == 0) return XDE_OK;
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_DENSE, 0.0);
+  dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+  if (dtype == XDE_F32)
+    XDE_LAUNCH(xde_hermite_kernel<float>, g, b, st, prof, static_cast<float*>(val_out), static_cast<float*>(der_out),
+               static_cast<const float*>(his), static_cast<const float*>(his_t), static_cast<const float*>(lags), outer, T, D, L);
+  else
+    XDE_LAUNCH(xde_hermite_kernel<double>, g, b, st, prof, static_cast<double*>(val_out), static_cast<double*>(der_out),
+               static_cast<const double*>(his), static_cast<const double*>(his_t), static_cast<const double*>(lags), outer, T, D, L);
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

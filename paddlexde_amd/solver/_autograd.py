@@ -13,26 +13,29 @@ from .. import _hip
 
 class CombineFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, backend, coef, mode, scale, dt, y0, *ks):
+    def forward(ctx, backend, coef, mode, scale, dt, damp, y0, *ks):
         out = torch.empty_like(y0)
-        backend.stage_combine(out, y0.detach(), [k.detach() for k in ks], coef, mode, scale=scale, dt_host=float(dt))
+        backend.stage_combine(out, y0.detach(), [k.detach() for k in ks], coef, mode, scale=scale, dt_host=float(dt),
+                              damping=float(damp))
         ctx.backend = backend
-        ctx.meta = (tuple(float(c) for c in coef), mode, float(scale), float(dt))
+        ctx.meta = (tuple(float(c) for c in coef), mode, float(scale), float(dt), float(damp))
         ctx.needs = (y0.requires_grad,) + tuple(k.requires_grad for k in ks)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        coef, mode, scale, dt = ctx.meta
+        coef, mode, scale, dt, damp = ctx.meta
+        # damped fuse: (dy - damp*(dy*dt + y0))*dt + y0 = dy*dt*(1 - damp*dt) + y0*(1 - damp*dt)
+        g_damp = 1.0 - damp * dt
         if mode == _hip.COMBINE_RK or mode == _hip.COMBINE_FUSE:
-            # out = y0 + sum_j k_j (c_j dt)   |   out = (sum_j c_j k_j) dt + y0
-            fy0 = 1.0
-            fk = [c * dt for c in coef]
+            # out = y0 + sum_j k_j (c_j dt)   |   out = fuse(sum_j c_j k_j, dt, y0)
+            fy0 = g_damp
+            fk = [c * dt * g_damp for c in coef]
         else:
-            # out = scale * sum_j w_j (k_j dt + y0)
-            fy0 = scale * sum(coef)
-            fk = [scale * w * dt for w in coef]
+            # out = scale * sum_j w_j fuse(k_j, dt, y0)
+            fy0 = scale * sum(coef) * g_damp
+            fk = [scale * w * dt * g_damp for w in coef]
         g = g.contiguous()
         if g.data_ptr() % 16:
             g = g.clone()
@@ -50,4 +53,4 @@ class CombineFn(torch.autograd.Function):
                 todo_f.append(f)
         if todo_o:
             ctx.backend.scale_fanout(todo_o, g, todo_f)
-        return (None, None, None, None, None) + tuple(outs)
+        return (None, None, None, None, None, None) + tuple(outs)

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import _hip
+from ..xde.base_dde import DDE_DAMPING, BaseDDE
 from ..xde.base_ode import BaseODE
 from ._autograd import CombineFn
 from ._common import as_operand, np_dtype, storage_ptr, t_span_to_host
@@ -51,8 +52,14 @@ class FixedSolver(metaclass=abc.ABCMeta):
         self.move = self.xde.move
         self.fuse = self.xde.fuse
         self.on_integrate_step_end = self.xde.on_integrate_step_end
-        if getattr(type(xde), "fuse", None) is not BaseODE.fuse:
-            raise NotImplementedError("only BaseODE.fuse (dy * dt + y0) is mapped onto the HIP combine kernel")
+        # the wrapper's fuse is what xde_stage_combine computes: BaseODE's `dy*dt + y0` or BaseDDE's damped form
+        fuse_impl = getattr(type(xde), "fuse", None)
+        if fuse_impl is BaseODE.fuse:
+            self._damping = 0.0
+        elif fuse_impl is BaseDDE.fuse:
+            self._damping = DDE_DAMPING
+        else:
+            raise NotImplementedError("only BaseODE.fuse / BaseDDE.fuse are mapped onto the HIP combine kernel")
 
         self.backend = _hip.get_backend()
         self.nfe = 0
@@ -72,12 +79,13 @@ class FixedSolver(metaclass=abc.ABCMeta):
         return f
 
     def _combine(self, y0, ks, coef, mode, dt, scale=1.0, out=None):
+        damp = self._damping if mode != _hip.COMBINE_RK else 0.0
         if torch.is_grad_enabled() and (y0.requires_grad or any(k.requires_grad for k in ks)):
             # discretise-then-optimise: keep the autograd graph through the combine
-            return CombineFn.apply(self.backend, list(coef), mode, scale, float(dt), y0, *ks)
+            return CombineFn.apply(self.backend, list(coef), mode, scale, float(dt), damp, y0, *ks)
         if out is None:
             out = torch.empty_like(y0)
-        self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, dt_host=float(dt))
+        self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, dt_host=float(dt), damping=damp)
         return out
 
     # -- time handling ----------------------------------------------------------------------------

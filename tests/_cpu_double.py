@@ -47,7 +47,7 @@ class NumpyDoubleBackend:
 
     # -- K1 -------------------------------------------------------------------------------------
     def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None,
-                      out2=None, coef2=None):
+                      out2=None, coef2=None, damping=0.0):
         self.launches.append("combine")
         T = _NP[out.dtype]
         sel = 0
@@ -79,13 +79,20 @@ class NumpyDoubleBackend:
                 acc = kk[0] * cs[0]
                 for j in range(1, len(kk)):
                     acc = acc + kk[j] * cs[j]
-                o[...] = acc * dt + y
+                o[...] = self._fuse(acc, dt, y, T(damping))
             else:
                 cs = [T(c_) for c_ in coef]
-                acc = (kk[0] * dt + y) * cs[0]
+                acc = self._fuse(kk[0], dt, y, T(damping)) * cs[0]
                 for j in range(1, len(kk)):
-                    acc = acc + (kk[j] * dt + y) * cs[j]
+                    acc = acc + self._fuse(kk[j], dt, y, T(damping)) * cs[j]
                 o[...] = acc * T(scale)
+
+    @staticmethod
+    def _fuse(dy, dt, y0, lam):
+        if lam == 0:
+            return dy * dt + y0
+        y = dy * dt + y0
+        return (dy - lam * y) * dt + y0
 
     # -- K2 -------------------------------------------------------------------------------------
     @staticmethod
@@ -365,6 +372,41 @@ class NumpyDoubleBackend:
         gv = _np(g).reshape(-1)
         for o, f in zip(outs, factors):
             _np(o).reshape(-1)[...] = gv * (T(f) * dt)
+
+    def hermite_gather(self, val, der, his, his_t, lags):
+        self.launches.append("hermite")
+        T = _NP[his.dtype]
+        h = _np(his)
+        ts = _np(his_t)
+        Tn, D = h.shape[-2], h.shape[-1]
+        hh = h.reshape(-1, Tn, D)
+        v, dv = _np(val).reshape(hh.shape[0], -1, D), _np(der).reshape(hh.shape[0], -1, D)
+
+        def h_at(j):
+            jj = j if j < Tn - 1 else Tn - 2
+            return ts[jj + 1] - ts[jj]
+
+        def ser(j):
+            return hh[:, j if j < Tn else Tn - 1, :]
+
+        def drv(j):
+            jj = j if j < Tn - 1 else Tn - 2
+            return (ser(jj + 1) - ser(jj)) / h_at(jj)
+
+        for l, tau in enumerate(_np(lags).reshape(-1)):
+            i = int(np.searchsorted(ts, tau, side="left")) - 1
+            i = min(max(i, 0), Tn - 1)
+            h1 = h_at(i)
+            h2 = h_at(0) if i == 0 else h_at(i - 1)
+            s = T((tau - ts[i]) / h1)
+            p0, p1, d0, d1 = ser(i) / h1, ser(i + 1) / h2, drv(i), drv(i + 1)
+            s2 = s * s
+            s3 = s2 * s
+            c0, c1, c2, c3 = T(2) * s3 - T(3) * s2 + T(1), T(-2) * s3 + T(3) * s2, s3 - T(2) * s2 + s, s3 - s2
+            g0, g1 = T(6) * s2 - T(6) * s, T(-6) * s2 + T(6) * s
+            g2, g3 = T(3) * s2 - T(4) * s + T(1), T(3) * s2 - T(2) * s
+            v[:, l, :] = (((c0 * p0 + c1 * p1) + c2 * d0) + c3 * d1) * h1
+            dv[:, l, :] = ((g0 * p0 + g1 * p1) + g2 * d0) + g3 * d1
 
     def commit(self, ctrl, y0_dst, y1_src, f0_dst, f1_src):
         self.launches.append("commit")

@@ -1,0 +1,173 @@
+"""Delay-equation cases (collected by test_gpu_odeint.py on the GPU and test_host_logic.py on the CPU double)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import xde_oracle as O
+from paddlexde_amd import RK4, AdamsBashforthMoulton, Euler, Midpoint, ddeint, ddeint_adjoint
+from paddlexde_amd.utils import _rms_norm
+from paddlexde_amd.xde import BaseDDE, HistoryIndex
+
+from . import problems as P
+
+SOLVERS = {"euler": Euler, "midpoint": Midpoint, "rk4": RK4, "adams": AdamsBashforthMoulton}
+
+
+def _history(shape, T, uniform, seed=0, dtype=np.float32):
+    rng = np.random.RandomState(seed)
+    t = np.arange(T, dtype=np.float64) if uniform else np.cumsum(rng.uniform(0.3, 1.7, size=T))
+    base = np.sin(0.37 * t)[:, None] * np.linspace(0.5, 1.5, shape[-1])[None, :]
+    his = base + 0.1 * rng.randn(*shape[:-1], T, shape[-1])
+    return his.astype(dtype), t.astype(dtype)
+
+
+@pytest.mark.parametrize("lead", [(3,), (2, 5), ()])
+@pytest.mark.parametrize("uniform", [True, False])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_history_gather_vs_oracle(dev, lead, uniform, dtype):
+    """xde_hermite_gather against the oracle's restatement of CubicHermiteSpline.evaluate / .derivative."""
+    T, D = 24, 7
+    his, t = _history(lead + (D,), T, uniform, dtype=dtype)
+    lags = np.array([t[0] - 0.4, t[0], 0.5 * (t[0] + t[1]), t[5], t[5] + 1e-3, t[11] + 0.77 * (t[12] - t[11]), t[-2], t[-1], t[-1] + 0.9],
+                    dtype=dtype)
+    y_ref, _ = O.history_index(lags, his, t, dtype=dtype)
+    d_ref = O.CubicHermiteSpline(his, t, dtype=dtype).derivative(lags)
+    lg = torch.from_numpy(lags).to(dev).requires_grad_(True)
+    y = HistoryIndex.apply(lg, torch.from_numpy(his).to(dev), torch.from_numpy(t).to(dev))
+    assert y.shape == lead + (len(lags), D)
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    assert P.rel_err(y.detach().cpu().numpy(), y_ref) <= tol
+    # nodes are interpolated (up to the spline's own rounding) and the gradient w.r.t. the lags is the derivative
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(1), dtype=y.dtype).to(dev)
+    (y * w).sum().backward()
+    axes = tuple(a for a in range(w.dim()) if a != w.dim() - 2)
+    g_ref = (w.cpu().numpy() * d_ref).sum(axis=axes)
+    assert lg.grad.shape == lg.shape
+    assert P.rel_err(lg.grad.cpu().numpy(), g_ref) <= (5e-5 if dtype == np.float32 else 1e-11)
+
+
+def test_history_spline_properties(dev):
+    """Independent of the oracle: nodes are reproduced, a linear history is reproduced exactly between nodes and its
+    derivative is the slope (uniform grid)."""
+    T, D = 16, 3
+    t = np.arange(T, dtype=np.float64)
+    his = (2.5 * t[:, None] + np.array([0.0, 1.0, -3.0])[None, :])[None]
+    lags = np.array([0.25, 3.0, 7.5, 14.9], dtype=np.float64)
+    y = HistoryIndex.apply(torch.from_numpy(lags).to(dev), torch.from_numpy(his).to(dev), torch.from_numpy(t).to(dev))
+    assert np.allclose(y.cpu().numpy()[0], 2.5 * lags[:, None] + np.array([0.0, 1.0, -3.0])[None, :], rtol=1e-12, atol=1e-12)
+    rng = np.random.RandomState(0)
+    his2 = rng.randn(2, T, D)
+    nodes = t[1:-1].copy()
+    y2 = HistoryIndex.apply(torch.from_numpy(nodes).to(dev), torch.from_numpy(his2).to(dev), torch.from_numpy(t).to(dev))
+    assert np.allclose(y2.cpu().numpy(), his2[:, 1:-1, :], rtol=1e-12, atol=1e-12)
+
+
+# only +, -, * and indexing, so numpy and torch agree to the last bit
+def _dde_func_np(y_lags, y):
+    return -0.5 * y + 0.25 * (y_lags[..., 0, :] * y_lags[..., -1, :]) - 0.1 * y * y * y + 0.125 * y_lags[..., 1, :]
+
+
+def _dde_func_t(y_lags, y):
+    return -0.5 * y + 0.25 * (y_lags[..., 0, :] * y_lags[..., -1, :]) - 0.1 * y * y * y + 0.125 * y_lags[..., 1, :]
+
+
+@pytest.mark.parametrize("solver", list(SOLVERS))
+def test_ddeint_vs_oracle_bit_exact_with_processed_history(dev, solver):
+    """his_processed=True feeds both sides the same delayed states: the damped fuse (xde/base_dde.py:55-58) and the whole
+    fixed-step trajectory are then bit-exact."""
+    rng = np.random.RandomState(2)
+    B, L, D = 6, 5, 4
+    y0 = rng.randn(B, D).astype(np.float32)
+    y_lags = rng.randn(B, L, D).astype(np.float32)
+    t = np.linspace(0.0, 1.0, 21).astype(np.float32)
+    ref, yl = O.ddeint(_dde_func_np, y0, t, None, y_lags, None, solver, his_processed=True)
+    got, gl = ddeint(_dde_func_t, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), None, torch.from_numpy(y_lags).to(dev), None,
+                     SOLVERS[solver], his_processed=True)
+    assert got.shape == ref.shape == (21 * B, D)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    assert np.array_equal(gl.cpu().numpy(), yl)
+    # the damping really is applied: an undamped RK4 run of the same dynamics differs
+    from paddlexde_amd import odeint
+
+    yl_t = torch.from_numpy(y_lags).to(dev)
+    plain = odeint(lambda t_, y: _dde_func_t(yl_t, y), torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), solver=SOLVERS[solver])
+    assert not torch.equal(plain, got)
+
+
+def test_ddeint_full_path_vs_oracle(dev):
+    his, ht = _history((4, 3), 20, uniform=True)
+    lags = np.array([1.5, 4.0, 7.25, 12.8, 18.0], dtype=np.float32)
+    y0 = his[:, -1, :].copy()
+    t = np.linspace(0.0, 2.0, 17).astype(np.float32)
+    ref, yl = O.ddeint(_dde_func_np, y0, t, lags, his, ht, "rk4")
+    got, gl = ddeint(_dde_func_t, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), torch.from_numpy(lags).to(dev),
+                     torch.from_numpy(his).to(dev), torch.from_numpy(ht).to(dev), RK4)
+    assert P.rel_err(gl.cpu().numpy(), yl) <= 2e-5
+    assert P.rel_err(got.cpu().numpy(), ref) <= 1e-5
+
+
+def test_ddeint_backprop_to_params_and_lags(dev):
+    """The reference trains through ddeint (example/dde_demo.py, D3STN): gradients reach func's parameters through the
+    damped combine nodes and the lags through HistoryIndex.backward — checked against the same scheme in eager ops."""
+    dtype = torch.float64
+    his, ht = _history((3, 2), 18, uniform=True, dtype=np.float64)
+    his_t, ht_t = torch.from_numpy(his).to(dev), torch.from_numpy(ht).to(dev)
+    lin = torch.nn.Linear(2, 2).to(dtype).to(dev)
+
+    def func(y_lags, y):
+        return lin(torch.tanh(y)) + 0.3 * y_lags.mean(dim=-2)
+
+    y0 = torch.from_numpy(his[:, -1, :].copy()).to(dev)
+    t = torch.linspace(0.0, 1.0, 6, dtype=dtype).to(dev)
+    lags = torch.tensor([2.25, 6.5, 11.0], dtype=dtype, device=dev, requires_grad=True)
+    sol, y_lags = ddeint(func, y0, t, lags, his_t, ht_t, RK4)
+    (sol * sol).mean().backward()
+    got = [lags.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    lags.grad = None
+    lin.zero_grad()
+
+    # eager restatement: differentiable cubic Hermite on the uniform grid + the damped RK4 variant
+    i = torch.clamp(torch.bucketize(lags.detach(), ht_t) - 1, 0, len(ht) - 1)
+    s = (lags - ht_t[i]).unsqueeze(-1)  # h = 1
+
+    def ser(j):
+        return his_t[:, torch.clamp(j, max=len(ht) - 1), :]
+
+    def drv(j):
+        jj = torch.clamp(j, max=len(ht) - 2)
+        return ser(jj + 1) - ser(jj)
+
+    p0, p1, d0, d1 = ser(i), ser(i + 1), drv(i), drv(i + 1)
+    yl = (2 * s**3 - 3 * s**2 + 1) * p0 + (-2 * s**3 + 3 * s**2) * p1 + (s**3 - 2 * s**2 + s) * d0 + (s**3 - s**2) * d1
+    assert torch.allclose(yl, y_lags, rtol=1e-12, atol=1e-12)
+
+    def fuse(dy, dt, y):
+        yy = dy * dt + y
+        return (dy - 0.001 * yy) * dt + y
+
+    y, ys = y0, [y0]
+    for k in range(1, len(t)):
+        dt = t[k] - t[k - 1]
+        k1 = func(yl, y)
+        k2 = func(yl, fuse(k1, dt / 3, y))
+        k3 = func(yl, fuse(k1 - k2 / 3, dt, y))
+        k4 = func(yl, fuse(k1 - k2 + k3, dt, y))
+        y = (fuse(k1, dt, y) + 3 * fuse(k2, dt, y) + 3 * fuse(k3, dt, y) + fuse(k4, dt, y)) * 0.125
+        ys.append(y)
+    ref_sol = torch.cat(ys, dim=-2)
+    assert torch.allclose(sol, ref_sol, rtol=1e-11, atol=1e-13)
+    (ref_sol * ref_sol).mean().backward()
+    for a, b in zip(got, [lags.grad, lin.weight.grad, lin.bias.grad]):
+        assert torch.allclose(a, b, rtol=1e-8, atol=1e-12), float((a - b).abs().max())
+
+
+def test_dde_api_conventions(dev):
+    with pytest.raises(NotImplementedError):
+        ddeint_adjoint(func=None)
+    his, ht = _history((2, 3), 8, uniform=True)
+    x = BaseDDE(lambda yl, y: y, y0=torch.zeros(2, 3, device=dev), t_span=torch.tensor([0.0, 1.0]), lags=None,
+                his=torch.from_numpy(his).to(dev), his_span=torch.from_numpy(ht).to(dev), his_processed=True)
+    dy, y0 = torch.ones(2, 3, device=dev), torch.full((2, 3), 2.0, device=dev)
+    assert torch.allclose(x.fuse(dy, 0.5, y0), (dy - 0.001 * (dy * 0.5 + y0)) * 0.5 + y0)
+    with pytest.raises(NotImplementedError):
+        HistoryIndex.apply(torch.zeros(1, device=dev), torch.from_numpy(his).to(dev), torch.from_numpy(ht).to(dev), "linear")

@@ -3,6 +3,7 @@
 tuple flattening, adjoint) without a GPU; the HIP kernels themselves are covered by the `-m gpu` suite."""
 import pytest
 
+from ._dde_cases import *  # noqa: F401,F403
 from ._e2e_cases import *  # noqa: F401,F403
 
 
