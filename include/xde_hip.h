@@ -168,6 +168,20 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
                            const void* e_pre, void* stream);
 
 /*
+ * Error norm AND step controller in ONE launch (single-GPU path with a native norm) — xde_error_norm_partial followed
+ * by xde_rk_control, without the second launch: every workgroup publishes its partial write-through and takes a
+ * ticket (agent-scope atomic add); the workgroup whose ticket is last acquires, reduces the partials in the same fixed
+ * order and runs the controller.  No workgroup waits for another.  rtol/atol/norm_kind are taken from `params`; `ctrl`
+ * supplies dt and the operand select and receives the updated state.  The ticket word lives in `ws` and must be zero
+ * on entry (it is when `ws` was zero-initialised; the launch leaves it zero).
+ */
+int xde_error_norm_control(const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
+                           const void* y0_alt, const void* y1, const xde_segments_t* segs, int dtype, void* ws,
+                           const void* e_pre, xde_ctrl_t* ctrl, const xde_ctrl_params_t* params,
+                           const double* t_span_dev, const double* step_t_dev, void* t_stage_out,
+                           xde_ctrl_t* host_mirror, void* stream);
+
+/*
  * Element-wise error ratio for user-supplied norm callables — the tensor `error_estimate / error_tol` of
  * compute_error_ratio (utils/ode_utils.py:80-82) materialised once: out[i] = (sum_j k_j[i]*(dt*c_err_j)) /
  * (atol + rtol*max(|y0[i]|,|y1[i]|)).  The caller applies its own norm to `out` with framework ops and hands the

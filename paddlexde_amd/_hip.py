@@ -31,6 +31,7 @@ SYMBOLS = (
     "xde_workspace_bytes",
     "xde_stage_combine",
     "xde_error_norm_partial",
+    "xde_error_norm_control",
     "xde_error_ratio",
     "xde_scaled_norm_partial",
     "xde_norm_finalize",
@@ -152,6 +153,9 @@ def load_library():
         lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, vp]
         lib.xde_error_norm_partial.restype = i32
         lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp, vp]
+        lib.xde_error_norm_control.restype = i32
+        lib.xde_error_norm_control.argtypes = [vpp, vp, dp, i32, vp, vp, vp, C.POINTER(XdeSegments), i32, vp, vp, vp,
+                                               C.POINTER(XdeCtrlParams), vp, vp, vp, vp, vp]
         lib.xde_error_ratio.restype = i32
         lib.xde_error_ratio.argtypes = [vp, vpp, dp, i32, vp, vp, dbl, dbl, dbl, vp, i64, i32, vp]
         lib.xde_scaled_norm_partial.restype = i32
@@ -309,6 +313,20 @@ class HipBackend:
             ws.data_ptr(), _ptr(e_pre), self._stream(y0),
         )
         self._check(rc, "xde_error_norm_partial")
+
+    def error_norm_control(self, ks, c_err, y0, y1, segs, ws, ctrl, params, t_span_dev, step_t_dev, t_stage, *, y0_alt=None,
+                           k0_alt=None, e_pre=None):
+        """Error norm + controller in one launch (single GPU, native norm)."""
+        self._require_device(y0, y1, ws, ctrl, e_pre, *ks)
+        m = self._mirrors.get(ctrl.data_ptr())
+        rc = self.lib.xde_error_norm_control(
+            _ptr_array(ks), _ptr(k0_alt), _dbl_array(c_err), len(ks), y0.data_ptr(), _ptr(y0_alt), y1.data_ptr(), C.byref(segs),
+            dtype_code(y0.dtype), ws.data_ptr(), _ptr(e_pre), ctrl.data_ptr(), C.byref(params), t_span_dev.data_ptr(),
+            _ptr(step_t_dev), t_stage.data_ptr(), m.ptr if m is not None else None, self._stream(y0),
+        )
+        self._check(rc, "xde_error_norm_control")
+        if m is not None and not self._capturing:
+            m.seq += 1
 
     def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None):
         self._require_device(out, y0, y1, *ks)

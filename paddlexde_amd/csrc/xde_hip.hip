@@ -59,6 +59,12 @@ int nt_policy() {
   return v;
 }
 
+// grid of the fused error-norm + controller launch: fewer, longer-running workgroups = fewer ticket arrivals
+int fused_grid_cap() {
+  static int cap = env_int("XDE_FUSED_GRID", 1024);
+  return cap > XDE_MAX_PARTIALS ? XDE_MAX_PARTIALS : cap;
+}
+
 int grid_cap() {
   static int cap = env_int("XDE_GRID_BLOCKS", 2048);
   return cap > XDE_MAX_PARTIALS ? XDE_MAX_PARTIALS : cap;
@@ -158,11 +164,18 @@ struct alignas(16) Partial {
 };
 static_assert(sizeof(Partial) == 32, "Partial is two 16-byte stores / loads");
 
+constexpr int kTicketShards = 16;  // first-level arrival counters (one atomic word serialises at ~12 ns per add)
+
 struct NormSlot {
   int32_t nblocks;
   int32_t n_seg;
   int32_t norm_kind;
-  int32_t pad;
+  uint32_t ticket;  // top-level arrivals (one per completed shard) of the fused error-norm + controller launch
+  // first-level arrival counters, one 128-byte line each; all ticket words are zero between launches
+  struct alignas(128) Shard {
+    uint32_t count;
+    uint32_t pad[31];
+  } shard[kTicketShards];
   Partial p[XDE_MAX_PARTIALS];
 };
 
@@ -395,10 +408,16 @@ __device__ __forceinline__ double merge_(double a, double b) {
   return NORM == XDE_NORM_RMS ? a + b : nanmax_(a, b);
 }
 
-template <int NORM>
-__device__ void block_reduce_store(double val, double nf, NormSlot* slot, int seg) {
+// TICKET = false: plain store of the partial (a later launch reduces them).
+// TICKET = true (fused error-norm + controller): the partial is published to the workgroup that arrives last, inside
+// the launch, by the write-through form of cdna_hip_programming.md Guideline 16: 8-byte agent-scope (sc1) stores by ONE
+// lane, that lane's `s_waitcnt vmcnt(0)`, then an agent-scope atomic add on the ticket; the add's return value tells
+// the last arriver.  Returns true in every thread of the last workgroup.
+template <int NORM, bool TICKET = false>
+__device__ bool block_reduce_store(double val, double nf, NormSlot* slot, int seg) {
   __shared__ double s_val[kWaves];
   __shared__ double s_nf[kWaves];
+  __shared__ int s_last;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     val = merge_<NORM>(val, __shfl_down(val, off, 64));
@@ -417,13 +436,36 @@ __device__ void block_reduce_store(double val, double nf, NormSlot* slot, int se
       v = merge_<NORM>(v, s_val[w]);
       f += s_nf[w];
     }
-    Partial rec;
-    rec.val = v;
-    rec.nf = f;
-    rec.seg = seg;
-    rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
-    slot->p[blockIdx.x] = rec;
+    if (!TICKET) {
+      Partial rec;
+      rec.val = v;
+      rec.nf = f;
+      rec.seg = seg;
+      rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+      slot->p[blockIdx.x] = rec;
+    } else {
+      unsigned long long* w = reinterpret_cast<unsigned long long*>(&slot->p[blockIdx.x]);
+      __hip_atomic_store(w + 0, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(w + 1, (unsigned long long)__double_as_longlong(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(w + 2, (unsigned long long)(unsigned)seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left this CU before the ticket is taken
+      // two-level arrival: shard = blockIdx % 16 (blocks b, b+16, ... share a counter); the last arriver of a shard
+      // arrives at the top-level counter; the last arriver there is the last workgroup of the launch
+      const unsigned nsh = gridDim.x < unsigned(kTicketShards) ? gridDim.x : unsigned(kTicketShards);
+      const unsigned sh = blockIdx.x % nsh;
+      const unsigned members = (gridDim.x - sh + nsh - 1) / nsh;
+      int last = 0;
+      unsigned old = __hip_atomic_fetch_add(&slot->shard[sh].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == members - 1) {
+        unsigned old2 = __hip_atomic_fetch_add(&slot->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (old2 == nsh - 1) ? 1 : 0;
+      }
+      s_last = last;
+    }
   }
+  if (!TICKET) return false;
+  __syncthreads();
+  return s_last != 0;
 }
 
 __device__ __forceinline__ int find_segment(const SegMap& m, int b) {
@@ -557,6 +599,26 @@ __device__ void errnorm_generic(const ErrArgs& a, const T* __restrict__ y0, cons
 }
 
 template <typename T, int NORM, bool VEC>
+__device__ __forceinline__ void errnorm_dispatch(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt,
+                                                 int seg, int lb, int nb, T& acc, int& nf) {
+  if (a.e_pre) {  // host guarantees nk == 1 in this mode: e = e_pre + k_last * (dt * c_last)
+    if (a.nt) errnorm_body<T, 1, NORM, VEC, true, true>(a, y0, k0, dt, seg, lb, nb, acc, nf);
+    else errnorm_body<T, 1, NORM, VEC, false, true>(a, y0, k0, dt, seg, lb, nb, acc, nf);
+  } else
+  switch (a.nk) {
+    case 1: if (a.nt) errnorm_body<T, 1, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 1, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 2: if (a.nt) errnorm_body<T, 2, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 2, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 3: if (a.nt) errnorm_body<T, 3, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 3, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 4: if (a.nt) errnorm_body<T, 4, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 4, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 5: if (a.nt) errnorm_body<T, 5, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 5, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 6: if (a.nt) errnorm_body<T, 6, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 6, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 7: if (a.nt) errnorm_body<T, 7, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 7, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 8: if (a.nt) errnorm_body<T, 8, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 8, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    default: errnorm_generic<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+  }
+}
+
+template <typename T, int NORM, bool VEC>
 __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
   int sel = 0;
   T dt;
@@ -573,21 +635,7 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
   const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
   T acc = T(0);
   int nf = 0;
-  if (a.e_pre) {  // host guarantees nk == 1 in this mode: e = e_pre + k_last * (dt * c_last)
-    if (a.nt) errnorm_body<T, 1, NORM, VEC, true, true>(a, y0, k0, dt, seg, lb, nb, acc, nf);
-    else errnorm_body<T, 1, NORM, VEC, false, true>(a, y0, k0, dt, seg, lb, nb, acc, nf);
-  } else
-  switch (a.nk) {
-    case 1: if (a.nt) errnorm_body<T, 1, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 1, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 2: if (a.nt) errnorm_body<T, 2, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 2, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 3: if (a.nt) errnorm_body<T, 3, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 3, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 4: if (a.nt) errnorm_body<T, 4, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 4, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 5: if (a.nt) errnorm_body<T, 5, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 5, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 6: if (a.nt) errnorm_body<T, 6, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 6, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 7: if (a.nt) errnorm_body<T, 7, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 7, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    case 8: if (a.nt) errnorm_body<T, 8, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 8, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-    default: errnorm_generic<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
-  }
+  errnorm_dispatch<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     a.slot->nblocks = gridDim.x;
     a.slot->n_seg = a.map.n_seg;
@@ -651,7 +699,9 @@ __global__ __launch_bounds__(kBlock) void xde_scalednorm_kernel(ScaledArgs s) {
 // ------------------------------------------------------------------------------------------
 // fixed-order reduction of block partials → per-segment sums (one workgroup)
 // ------------------------------------------------------------------------------------------
-__device__ void reduce_partials(const NormSlot* slot, double* seg_val, double* seg_nf) {
+template <bool SC1 = false>
+__device__ void reduce_partials(const NormSlot* slot, double* seg_val, double* seg_nf, int nblocks_known = -1,
+                                int n_seg_known = 0, int norm_kind_known = 0) {
   // Called by all kBlock threads of ONE block; results land in seg_val/seg_nf (shared, XDE_MAX_SEG each).
   // Every thread first pulls its (up to) XDE_MAX_PARTIALS/kBlock records into registers with independent
   // 32-byte loads (one memory round trip), then the per-segment reductions run on registers:
@@ -660,19 +710,27 @@ __device__ void reduce_partials(const NormSlot* slot, double* seg_val, double* s
   constexpr int kPer = XDE_MAX_PARTIALS / kBlock;
   __shared__ double w_val[kWaves];
   __shared__ double w_nf[kWaves];
-  const int nblocks = slot->nblocks;
-  const int n_seg = slot->n_seg;
-  const bool rms = slot->norm_kind == XDE_NORM_RMS;
+  // (the fused launch knows its own grid; it must not read the header other workgroups are not ordered with)
+  const int nblocks = nblocks_known >= 0 ? nblocks_known : slot->nblocks;
+  const int n_seg = nblocks_known >= 0 ? n_seg_known : slot->n_seg;
+  const bool rms = (nblocks_known >= 0 ? norm_kind_known : slot->norm_kind) == XDE_NORM_RMS;
   double rv[kPer], rf[kPer];
   int rs[kPer];
 #pragma unroll
   for (int i = 0; i < kPer; ++i) {
     const int b = threadIdx.x + i * kBlock;
     if (b < nblocks) {
-      Partial rec = slot->p[b];
-      rv[i] = rec.val;
-      rf[i] = rec.nf;
-      rs[i] = rec.seg;
+      if (SC1) {  // write-through partials of this launch: agent-scope (sc1) loads bypass this CU's L1
+        const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&slot->p[b]);
+        rv[i] = __longlong_as_double((long long)__hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        rf[i] = __longlong_as_double((long long)__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        rs[i] = (int)(unsigned)__hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        Partial rec = slot->p[b];
+        rv[i] = rec.val;
+        rf[i] = rec.nf;
+        rs[i] = rec.seg;
+      }
     } else {
       rv[i] = 0.0;
       rf[i] = 0.0;
@@ -892,16 +950,20 @@ __device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double r
   plan_next<TT>(c, p, step_t, t_stage_out);
 }
 
-__global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const NormSlot* slot,
-                                                             const double* sums, const double* t_span,
-                                                             const double* step_t, void* t_stage_out,
-                                                             xde_ctrl_t* mirror) {
+// The controller workgroup: reduce the partials (or take finalised sums), run the controller on a register copy of
+// the control block, write it back to the device block and the pinned host mirror.  FUSED = called by the last
+// workgroup of the fused error-norm launch (partials were published write-through inside this launch).
+template <bool FUSED>
+__device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const NormSlot* slot, const double* sums,
+                              const double* t_span, const double* step_t, void* t_stage_out, xde_ctrl_t* mirror,
+                              int nblocks, int norm_kind) {
   __shared__ double seg_val[XDE_MAX_SEG];
   __shared__ double seg_nf[XDE_MAX_SEG];
   __shared__ xde_ctrl_t zs;
   constexpr int kWords = sizeof(xde_ctrl_t) / 8;
   constexpr int kSeqWord = offsetof(xde_ctrl_t, seq) / 8;
-  // the control block is fetched by the first lanes while the partials are being reduced
+  // the control block is fetched by the first lanes while the partials are being reduced (it is written only by
+  // controller launches, i.e. before this launch started)
   if (threadIdx.x < kWords)
     reinterpret_cast<uint64_t*>(&zs)[threadIdx.x] = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
   if (sums) {
@@ -916,7 +978,10 @@ __global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_
       seg_nf[threadIdx.x] = 0.0;
     }
     __syncthreads();
-    reduce_partials(slot, seg_val, seg_nf);
+    if (FUSED)
+      reduce_partials<true>(slot, seg_val, seg_nf, nblocks, p.n_seg, norm_kind);
+    else
+      reduce_partials<false>(slot, seg_val, seg_nf);
   }
   if (threadIdx.x == 0) {
     xde_ctrl_t z = zs;  // all controller arithmetic runs on registers
@@ -955,6 +1020,54 @@ __global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_
       __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const NormSlot* slot,
+                                                             const double* sums, const double* t_span,
+                                                             const double* step_t, void* t_stage_out,
+                                                             xde_ctrl_t* mirror) {
+  control_block<false>(c, p, slot, sums, t_span, step_t, t_stage_out, mirror, 0, 0);
+}
+
+// Controller arguments of the fused launch
+struct CtrlTail {
+  xde_ctrl_t* ctrl;
+  xde_ctrl_params_t p;
+  const double* t_span;
+  const double* step_t;
+  void* t_stage_out;
+  xde_ctrl_t* mirror;
+};
+
+// K2+K3 fused: every workgroup does the error-norm pass and publishes its partial; the workgroup whose ticket is the
+// last one acquires (agent scope), reduces all partials in the same fixed order as the standalone controller, runs
+// the controller and resets the ticket.  Nobody waits for anybody: no spin, no residency requirement.
+template <typename T, int NORM, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, CtrlTail tl) {
+  int sel = 0;
+  const T dt = T(a.ctrl->dt);
+  if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  const int seg = find_segment(a.map, blockIdx.x);
+  const int lb = blockIdx.x - a.map.seg_blk[seg];
+  const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
+  T acc = T(0);
+  int nf = 0;
+  errnorm_dispatch<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf);
+  const bool last = block_reduce_store<NORM, true>(double(acc), double(nf), a.slot, seg);
+  if (!last) return;
+  // ---- last arriver: every other workgroup's partial is in L2/memory (sc1 stores, drained before its ticket) ----
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  control_block<true>(tl.ctrl, tl.p, a.slot, nullptr, tl.t_span, tl.step_t, tl.t_stage_out, tl.mirror, int(gridDim.x), NORM);
+  // every workgroup has arrived: re-arm the ticket words for the next launch
+  if (threadIdx.x < kTicketShards)
+    __hip_atomic_store(&a.slot->shard[threadIdx.x].count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(&a.slot->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
@@ -1286,9 +1399,9 @@ struct ProfScope {
       hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                           \
   } while (0)
 
-int build_segmap(const xde_segments_t* segs, int width, bool vec, SegMap* m, int* nblocks_out) {
+int build_segmap(const xde_segments_t* segs, int width, bool vec, SegMap* m, int* nblocks_out, int cap_override = 0) {
   if (!segs || segs->n_seg < 1 || segs->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, "segments: n_seg out of range");
-  const int cap = grid_cap();
+  const int cap = cap_override > 0 ? cap_override : grid_cap();
   m->n_seg = segs->n_seg;
   int64_t total = 0;
   for (int s = 0; s < segs->n_seg; ++s) {
@@ -1415,19 +1528,19 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   return XDE_OK;
 }
 
-int xde_error_norm_partial(const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
-                           const void* y0_alt, const void* y1, double rtol, double atol, double dt_host,
-                           const xde_ctrl_t* ctrl, const xde_segments_t* segs, int norm_kind, int dtype, void* ws,
-                           const void* e_pre, void* stream) {
-  if (!k || !c_err || !y0 || !y1 || !ws || !segs) return fail(XDE_EBADARG, "xde_error_norm_partial: null pointer");
-  if (e_pre && nk != 1) return fail(XDE_EBADARG, "xde_error_norm_partial: e_pre takes exactly one remaining operand");
-  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_error_norm_partial: nk out of range");
-  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_error_norm_partial: bad dtype");
-  if (norm_kind != XDE_NORM_RMS && norm_kind != XDE_NORM_LINF) return fail(XDE_EBADARG, "xde_error_norm_partial: bad norm");
-  if (!e_pre && (y0_alt == nullptr) != (k0_alt == nullptr))
-    return fail(XDE_EBADARG, "xde_error_norm_partial: y0_alt/k0_alt must come together");
-  if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_error_norm_partial: operand select needs ctrl");
-  ErrArgs a;
+static int setup_err_args(const char* who, const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
+                          const void* y0_alt, const void* y1, double rtol, double atol, double dt_host, const xde_ctrl_t* ctrl,
+                          const xde_segments_t* segs, int norm_kind, int dtype, void* ws, const void* e_pre, ErrArgs* out,
+                          bool* vec_out, int* nblocks_out, double* bytes_out, int cap_override = 0) {
+  const std::string w(who);
+  if (!k || !c_err || !y0 || !y1 || !ws || !segs) return fail(XDE_EBADARG, w + ": null pointer");
+  if (e_pre && nk != 1) return fail(XDE_EBADARG, w + ": e_pre takes exactly one remaining operand");
+  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, w + ": nk out of range");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, w + ": bad dtype");
+  if (norm_kind != XDE_NORM_RMS && norm_kind != XDE_NORM_LINF) return fail(XDE_EBADARG, w + ": bad norm");
+  if (!e_pre && (y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, w + ": y0_alt/k0_alt must come together");
+  if (y0_alt && !ctrl) return fail(XDE_EBADARG, w + ": operand select needs ctrl");
+  ErrArgs& a = *out;
   memset(&a, 0, sizeof(a));
   a.y0[0] = y0;
   a.y0[1] = y0_alt ? y0_alt : y0;
@@ -1437,7 +1550,7 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   const int width = dtype == XDE_F32 ? 4 : 2;
   bool vec = aligned16(y0) && aligned16(a.y0[1]) && aligned16(y1) && aligned16(a.k0_alt) && segs_vec_ok(segs, width);
   for (int j = 0; j < nk; ++j) {
-    if (!k[j]) return fail(XDE_EBADARG, "xde_error_norm_partial: null k[j]");
+    if (!k[j]) return fail(XDE_EBADARG, w + ": null k[j]");
     a.k[j] = k[j];
     a.coef[j] = c_err[j];
     vec = vec && aligned16(k[j]);
@@ -1451,13 +1564,28 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   a.e_pre = e_pre;
   if (e_pre) vec = vec && aligned16(e_pre);
   a.nt = nt_policy() & 1;
-  int nblocks = 0;
-  int rc = build_segmap(segs, vec ? width : 1, vec, &a.map, &nblocks);
+  int rc = build_segmap(segs, vec ? width : 1, vec, &a.map, nblocks_out, cap_override);
   if (rc != XDE_OK) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   double total = 0;
   for (int s = 0; s < segs->n_seg; ++s) total += double(segs->seg_len[s]);
-  ProfScope prof(XDE_KID_ERRNORM, double(nk + 2 + (e_pre ? 1 : 0)) * total * (dtype == XDE_F32 ? 4.0 : 8.0));
+  *bytes_out = double(nk + 2 + (e_pre ? 1 : 0)) * total * (dtype == XDE_F32 ? 4.0 : 8.0);
+  *vec_out = vec;
+  return XDE_OK;
+}
+
+int xde_error_norm_partial(const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
+                           const void* y0_alt, const void* y1, double rtol, double atol, double dt_host,
+                           const xde_ctrl_t* ctrl, const xde_segments_t* segs, int norm_kind, int dtype, void* ws,
+                           const void* e_pre, void* stream) {
+  ErrArgs a;
+  bool vec = false;
+  int nblocks = 0;
+  double bytes = 0;
+  int rc = setup_err_args("xde_error_norm_partial", k, k0_alt, c_err, nk, y0, y0_alt, y1, rtol, atol, dt_host, ctrl, segs, norm_kind,
+                          dtype, ws, e_pre, &a, &vec, &nblocks, &bytes);
+  if (rc != XDE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_ERRNORM, bytes);
   dim3 g(nblocks), b(kBlock);
 #define LAUNCH_ERR(T, NORM)                                                       \
   do {                                                                            \
@@ -1474,6 +1602,53 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
     else LAUNCH_ERR(double, XDE_NORM_LINF);
   }
 #undef LAUNCH_ERR
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+static int check_params(const xde_ctrl_params_t* p, const char* who);
+
+int xde_error_norm_control(const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
+                           const void* y0_alt, const void* y1, const xde_segments_t* segs, int dtype, void* ws,
+                           const void* e_pre, xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const double* t_span_dev,
+                           const double* step_t_dev, void* t_stage_out, xde_ctrl_t* host_mirror, void* stream) {
+  if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_error_norm_control: null pointer");
+  int rc = check_params(params, "xde_error_norm_control");
+  if (rc != XDE_OK) return rc;
+  if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_error_norm_control: n_step_t > 0 without step_t_dev");
+  if (!segs || segs->n_seg != params->n_seg) return fail(XDE_EBADARG, "xde_error_norm_control: segments do not match params->n_seg");
+  ErrArgs a;
+  bool vec = false;
+  int nblocks = 0;
+  double bytes = 0;
+  rc = setup_err_args("xde_error_norm_control", k, k0_alt, c_err, nk, y0, y0_alt, y1, params->rtol, params->atol, 0.0, ctrl, segs,
+                      params->norm_kind, dtype, ws, e_pre, &a, &vec, &nblocks, &bytes, fused_grid_cap());
+  if (rc != XDE_OK) return rc;
+  CtrlTail tl;
+  tl.ctrl = ctrl;
+  tl.p = *params;
+  tl.t_span = t_span_dev;
+  tl.step_t = step_t_dev;
+  tl.t_stage_out = t_stage_out;
+  tl.mirror = host_mirror;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_ERRNORM, bytes);
+  dim3 g(nblocks), b(kBlock);
+#define LAUNCH_EC(T, NORM)                                                                 \
+  do {                                                                                     \
+    if (vec)                                                                               \
+      XDE_LAUNCH((xde_errnorm_control_kernel<T, NORM, true>), g, b, st, prof, a, tl);      \
+    else                                                                                   \
+      XDE_LAUNCH((xde_errnorm_control_kernel<T, NORM, false>), g, b, st, prof, a, tl);     \
+  } while (0)
+  if (dtype == XDE_F32) {
+    if (params->norm_kind == XDE_NORM_RMS) LAUNCH_EC(float, XDE_NORM_RMS);
+    else LAUNCH_EC(float, XDE_NORM_LINF);
+  } else {
+    if (params->norm_kind == XDE_NORM_RMS) LAUNCH_EC(double, XDE_NORM_RMS);
+    else LAUNCH_EC(double, XDE_NORM_LINF);
+  }
+#undef LAUNCH_EC
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

@@ -133,6 +133,12 @@ class NumpyDoubleBackend:
             r = e / tol
         self._slots[0] = self._seg_reduce(r, y0v, segs, norm_kind) + (norm_kind, segs.n_seg)
 
+    def error_norm_control(self, ks, c_err, y0, y1, segs, ws, ctrl, params, t_span_dev, step_t_dev, t_stage, *, y0_alt=None,
+                           k0_alt=None, e_pre=None):
+        self.error_norm_partial(ks, c_err, y0, y1, params.rtol, params.atol, segs, params.norm_kind, ws, ctrl=ctrl, y0_alt=y0_alt,
+                                k0_alt=k0_alt, e_pre=e_pre)
+        self.rk_control(ctrl, params, ws, None, t_span_dev, step_t_dev, t_stage)
+
     def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None):
         self.launches.append("ratio")
         T = _NP[y0.dtype]

@@ -167,6 +167,95 @@ def test_error_norm_and_control(be, dbl, dtype, norm_kind, n):
         assert np.allclose(g[11], r[11], rtol=3e-6)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("norm_kind", [_hip.NORM_RMS, _hip.NORM_LINF])
+@pytest.mark.parametrize("n", [1, 777, 1 << 16, (1 << 21) + 3, (1 << 23)])
+def test_fused_error_norm_control_equals_two_launches(be, dtype, norm_kind, n):
+    """xde_error_norm_control (last-workgroup-done controller, write-through partials + agent acquire) leaves exactly the
+    control block, stage times and mirror contents that xde_error_norm_partial + xde_rk_control leave — over repeated
+    launches (ticket reset), from one workgroup up to the full grid."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    y0 = _rand(n, dt, 1, dev)
+    y1 = y0 + 1e-3 * _rand(n, dt, 2, dev)
+    ks = [_rand(n, dt, 20 + j, dev) for j in range(3)]
+    c_err = [1.2e-3, -7.5e-3, 4.1e-3]
+    segs = _hip.make_segments([(0, n)])
+    p = _hip.XdeCtrlParams()
+    p.rtol, p.atol, p.min_step, p.max_step = 1e-3, 1e-5, 0.0, float("inf")
+    p.safety, p.ifactor, p.dfactor, p.order = 0.9, 10.0, 0.2, 5.0
+    p.max_num_steps = 2**31 - 1
+    p.time_dtype = _hip.XDE_F32
+    p.state_dtype = _hip.dtype_code(dt)
+    p.direction, p.norm_kind, p.n_stage, p.n_seg = 1, norm_kind, 6, 1
+    for i, a in enumerate([0.2, 0.3, 0.8, 8 / 9, 1.0, 1.0]):
+        p.alpha[i] = a
+    p.seg_count[0] = float(n)
+    t_span = torch.tensor([0.0, 0.004, 0.03, 10.0], dtype=torch.float64, device=dev)
+
+    def run(fused):
+        ctrl, ws = be.new_ctrl(dev), be.new_workspace(dev)
+        ts = torch.zeros(_hip.XDE_MAX_STAGE, dtype=dt, device=dev)
+        be.ctrl_init(ctrl, p, 0.0, 0.01, 4, t_span, None, ts)
+        recs = []
+        for _ in range(5):
+            if fused:
+                be.error_norm_control(ks, c_err, y0, y1, segs, ws, ctrl, p, t_span, None, ts)
+            else:
+                be.error_norm_partial(ks, c_err, y0, y1, p.rtol, p.atol, segs, norm_kind, ws, ctrl=ctrl)
+                be.rk_control(ctrl, p, ws, None, t_span, None, ts)
+            c = be.ctrl_read(ctrl)
+            recs.append((bytes(c)[: _hip.XdeCtrl.seq.offset], ts.cpu().numpy().tobytes(), ctrl.cpu().numpy().tobytes()[: _hip.XdeCtrl.seq.offset]))
+        return recs
+
+    a, b = run(False), run(True)
+    assert a == b
+
+
+def test_fused_error_norm_control_segments_and_select(be):
+    """The fused launch with a padded multi-segment layout (mixed norm) and device-side operand select."""
+    dev = torch.device("cuda:0")
+    dt = torch.float64
+    lens = [1, 5000, 5000, 100, 50]
+    segl, off = [], 0
+    for l in lens:
+        segl.append((off, l))
+        off += -(-l // 2) * 2
+    y0, y0b = _rand(off, dt, 1, dev), _rand(off, dt, 7, dev)
+    y1 = y0 + 1e-3 * _rand(off, dt, 2, dev)
+    ks = [_rand(off, dt, 20 + j, dev) for j in range(3)]
+    k0b = _rand(off, dt, 9, dev)
+    segs = _hip.make_segments(segl)
+    p = _hip.XdeCtrlParams()
+    p.rtol, p.atol, p.min_step, p.max_step = 1e-3, 1e-5, 0.0, float("inf")
+    p.safety, p.ifactor, p.dfactor, p.order = 0.9, 10.0, 0.2, 5.0
+    p.max_num_steps = 2**31 - 1
+    p.time_dtype = p.state_dtype = _hip.XDE_F64
+    p.direction, p.norm_kind, p.n_stage, p.n_seg = 1, _hip.NORM_RMS, 6, len(lens)
+    for i, a in enumerate([0.2, 0.3, 0.8, 8 / 9, 1.0, 1.0]):
+        p.alpha[i] = a
+    for i, l in enumerate(lens):
+        p.seg_count[i] = float(l)
+    t_span = torch.tensor([0.0, 10.0], dtype=torch.float64, device=dev)
+
+    def run(fused):
+        ctrl, ws = be.new_ctrl(dev), be.new_workspace(dev)
+        ts = torch.zeros(_hip.XDE_MAX_STAGE, dtype=dt, device=dev)
+        be.ctrl_init(ctrl, p, 0.0, 0.01, 2, t_span, None, ts)
+        out = []
+        for _ in range(4):  # accept flips the select between (y0, k0) and (y0b, k0b)
+            if fused:
+                be.error_norm_control(ks, [1e-3, -2e-3, 5e-4], y0, y1, segs, ws, ctrl, p, t_span, None, ts, y0_alt=y0b, k0_alt=k0b)
+            else:
+                be.error_norm_partial(ks, [1e-3, -2e-3, 5e-4], y0, y1, p.rtol, p.atol, segs, _hip.NORM_RMS, ws, ctrl=ctrl, y0_alt=y0b, k0_alt=k0b)
+                be.rk_control(ctrl, p, ws, None, t_span, None, ts)
+            c = be.ctrl_read(ctrl)
+            out.append((c.ratio, c.accept, c.dt, tuple(c.ratio_seg[: len(lens)])))
+        return out
+
+    assert run(False) == run(True)
+
+
 def test_error_norm_nonfinite_flag(be):
     dev = torch.device("cuda:0")
     n = 5000
