@@ -1,0 +1,48 @@
+"""The driver's contract for bench.py: `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the
+agreed keys (metric/value/unit/…/config.workload, roofline{bound,achieved,peak,unit,frac,traffic}, cpu_baseline{value,
+unit,cores,kind,sample}) and times exactly K steps."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "4096", *extra],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract():
+    j = _run()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 6 and j["warmup"] == 2
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"]
+    assert j["unit"] == "states/s" and j["value"] > 0 and j["ms_per_step"] > 0
+    assert abs(j["value"] - 4096 * 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6  # value = states per step / step time
+    assert j["solver"]["n_steps"] == 8  # warmup + steps attempted, nothing skipped
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["achieved"] > 0
+    assert "traffic" in rf
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "states/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+
+
+def test_bench_side_workloads_run():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--pipeline", "graph"], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["results"]["float64"]["n_reject"] > 0 and j["results"]["float64"]["finite"]
