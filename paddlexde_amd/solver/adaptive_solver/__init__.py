@@ -1,5 +1,7 @@
-from .adaptive_heun import AdaptiveHeun  # noqa: F401
-from .bosh3 import Bosh3  # noqa: F401
-from .dopri5 import Dopri5  # noqa: F401
-from .dopri8 import Dopri8  # noqa: F401
-from .fehlberg2 import Fehlberg2  # noqa: F401
+"""Embedded Runge-Kutta solver classes (the names the reference exports from this package)."""
+from . import _tableaus, dopri8
+
+Dopri5, Bosh3, Fehlberg2, AdaptiveHeun = _tableaus.Dopri5, _tableaus.Bosh3, _tableaus.Fehlberg2, _tableaus.AdaptiveHeun
+Dopri8 = dopri8.Dopri8
+
+__all__ = ["AdaptiveHeun", "Bosh3", "Dopri5", "Dopri8", "Fehlberg2"]

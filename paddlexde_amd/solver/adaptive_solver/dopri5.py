@@ -1,44 +1,2 @@
-"""Dormand-Prince(-Shampine) 5(4) pair (reference: paddlexde/solver/adaptive_solver/dopri5.py:5-61).
-
-Coefficients are kept as Python floats (double); the kernels round them to the state dtype at use,
-which is what the reference's ``.astype(y0.dtype)`` does (base_adaptive_solver_rk.py:73-79).
-"""
-from ..base_adaptive_solver_rk import AdaptiveRKSolver, _ButcherTableau
-
-_DORMAND_PRINCE_SHAMPINE_TABLEAU = _ButcherTableau(
-    alpha=[1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0],
-    beta=[
-        [1 / 5],
-        [3 / 40, 9 / 40],
-        [44 / 45, -56 / 15, 32 / 9],
-        [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
-        [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
-        [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
-    ],
-    c_sol=[35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0],
-    c_error=[
-        35 / 384 - 1951 / 21600,
-        0,
-        500 / 1113 - 22642 / 50085,
-        125 / 192 - 451 / 720,
-        -2187 / 6784 - -12231 / 42400,
-        11 / 84 - 649 / 6300,
-        -1.0 / 60.0,
-    ],
-)
-
-DPS_C_MID = [
-    6025192743 / 30085553152 / 2,
-    0,
-    51252292925 / 65400821598 / 2,
-    -2691868925 / 45128329728 / 2,
-    187940372067 / 1594534317056 / 2,
-    -1776094331 / 19743644256 / 2,
-    11237099 / 235043384 / 2,
-]
-
-
-class Dopri5(AdaptiveRKSolver):
-    order = 5
-    tableau = _DORMAND_PRINCE_SHAMPINE_TABLEAU
-    mid = DPS_C_MID
+"""`Dopri5` (reference: paddlexde/solver/adaptive_solver/dopri5.py:58-61); the tableau lives in _tableaus.py."""
+from ._tableaus import Dopri5  # noqa: F401

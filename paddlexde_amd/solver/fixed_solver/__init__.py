@@ -1,4 +1,7 @@
-from .adams import AdamsBashforthMoulton  # noqa: F401
-from .euler import Euler  # noqa: F401
-from .midpoint import Midpoint  # noqa: F401
-from .rk4 import RK4  # noqa: F401
+"""Fixed-grid solver classes (the names the reference exports from this package)."""
+from . import adams, euler, midpoint, rk4
+
+RK4, Euler, Midpoint = rk4.RK4, euler.Euler, midpoint.Midpoint
+AdamsBashforthMoulton = adams.AdamsBashforthMoulton
+
+__all__ = ["AdamsBashforthMoulton", "Euler", "Midpoint", "RK4"]
