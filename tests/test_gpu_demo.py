@@ -1,0 +1,19 @@
+"""The spiral neural-ODE demo (examples/ode_demo.py, counterpart of the reference's example/ode_demo.py) trains: the loss goes
+down when back-propagating through odeint(RK4), through odeint_adjoint(RK4) and through odeint_adjoint(Dopri5)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+
+
+@pytest.mark.parametrize("adjoint,solver", [(False, "rk4"), (True, "rk4"), (True, "dopri5")])
+def test_demo_loss_decreases(adjoint, solver):
+    import ode_demo
+
+    steps = 120 if solver == "rk4" else 60
+    losses = ode_demo.train(max_steps=steps, adjoint=adjoint, solver=solver, log_every=0)
+    head, tail = sum(losses[:10]) / 10, sum(losses[-10:]) / 10
+    assert tail < 0.9 * head, (head, tail)
