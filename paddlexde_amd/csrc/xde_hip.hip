@@ -1892,7 +1892,10 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
   }
   const int64_t work = vec ? (n + width - 1) / width : n;
   int64_t blocks = (work + kBlock - 1) / kBlock;
-  if (blocks > grid_cap()) blocks = grid_cap();
+  // predicated launch: most launches of the speculative pipeline exit at once, so keep the grid small (a no-op
+  // launch costs ~5 us with 2048 workgroups); the streaming rate does not depend on the grid between 512 and 4096
+  const int64_t dense_cap = grid_cap() < 512 ? grid_cap() : 512;
+  if (blocks > dense_cap) blocks = dense_cap;
   if (blocks < 1) blocks = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_DENSE, double(nk + 4) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));

@@ -5,7 +5,6 @@ import torch
 
 from oracle import xde_oracle as O
 from paddlexde_amd import RK4, AdamsBashforthMoulton, Euler, Midpoint, ddeint, ddeint_adjoint
-from paddlexde_amd.utils import _rms_norm
 from paddlexde_amd.xde import BaseDDE, HistoryIndex
 
 from . import problems as P

@@ -1,7 +1,6 @@
 """GPU parity, kernel level: every C-ABI kernel against the numpy statement of its contract
 (tests/_cpu_double.py, same op order as the reference's eager ops).  Element-wise kernels must be
 BIT-EXACT (the library is built with -ffp-contract=off); reductions agree to fp64-accumulation accuracy."""
-import ctypes as C
 
 import numpy as np
 import pytest
