@@ -231,9 +231,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # XDE_BENCH_FORCE_DIST=1: take the sharded code path (finalize -> RCCL all-reduce -> controller) even with one
+    # rank, to measure its per-step overhead on a one-GPU box
+    force_dist = os.environ.get("XDE_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -251,7 +259,7 @@ def main():
     t_span = torch.tensor([0.0, 1.0e9])
     xde = BaseODE(func, y0=y0, t_span=t_span)
     solver = Dopri5(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=args.pipeline,
-                    process_group=(True if world > 1 else None))
+                    process_group=(True if (world > 1 or force_dist) else None))
     solver.y0 = y0
     solver._before_integrate(np.asarray([0.0, 1.0e9], dtype=np.float32))
     be = _hip.get_backend()
@@ -345,7 +353,7 @@ def main():
             a2 = en["bytes"] / (en["ms"] * 1e-3) / 1e9
             out["roofline_errnorm"] = {"bound": "hbm", "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS,
                                        "avg_launch_us": 1e3 * en["ms"] / en["launches"]}
-        per_step = {"combine": 6, "errnorm": 1, "control": 1, "finalize": 1 if world > 1 else 0}
+        per_step = {"combine": 6, "errnorm": 1, "control": 1, "finalize": 1 if (world > 1 or force_dist) else 0}
         solver_ms = sum(per_step[k] * prof[k]["ms"] / prof[k]["launches"] for k in per_step if prof[k]["launches"])
         out["solver_kernel_ms_per_step"] = solver_ms
         out["solver_only_states_per_s"] = N_local / (solver_ms * 1e-3) if solver_ms > 0 else None
