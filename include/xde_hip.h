@@ -146,11 +146,14 @@ int64_t xde_workspace_bytes(void);
  *   kernel reads 4 arrays instead of 8 (xde_error_norm_partial, e_pre).
  *   damping (FUSE/WFUSE): lambda of the delay-equation wrapper's fuse, `y = dy*dt + y0; (dy - lambda*y)*dt + y0`
  *   (xde/base_dde.py:55-58; the reference uses 0.001); 0 selects BaseODE.fuse.
+ *   nt_mask: cache-policy hint — bit j set = this launch is the last reader of k[j] (bit 31: of y0), load it
+ *   non-temporally so that it does not displace lines that will be re-read from the Infinity Cache.  Results never
+ *   depend on it.  (Operands >= 64 MiB are always streamed, whatever the mask.)
  */
 int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k,
                       const void* k0_alt, const double* coef, int nk, int mode, double scale,
                       double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, void* out2,
-                      const double* coef2, double damping, void* stream);
+                      const double* coef2, double damping, uint32_t nt_mask, void* stream);
 
 /*
  * Error-norm partials — replaces `y1_error = sum(k * (dt * c_error), -1)` (base_adaptive_solver_rk.py:180),

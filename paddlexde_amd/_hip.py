@@ -150,7 +150,7 @@ def load_library():
         lib.xde_sizeof_ctrl.restype = i64
         lib.xde_workspace_bytes.restype = i64
         lib.xde_stage_combine.restype = i32
-        lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, vp]
+        lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, C.c_uint32, vp]
         lib.xde_error_norm_partial.restype = i32
         lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp, vp]
         lib.xde_error_norm_control.restype = i32
@@ -293,14 +293,14 @@ class HipBackend:
 
     # -- kernels ---------------------------------------------------------------------------
     def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None,
-                      out2=None, coef2=None, damping=0.0):
+                      out2=None, coef2=None, damping=0.0, nt_mask=0):
         self._require_device(out, y0, out2, *ks)
         if out.numel() == 0:
             return
         rc = self.lib.xde_stage_combine(
             out.data_ptr(), y0.data_ptr(), _ptr(y0_alt), _ptr_array(ks), _ptr(k0_alt), _dbl_array(coef), len(ks),
             mode, float(scale), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype), _ptr(out2),
-            _dbl_array(coef2) if coef2 is not None else None, float(damping), self._stream(out),
+            _dbl_array(coef2) if coef2 is not None else None, float(damping), int(nt_mask) & 0xFFFFFFFF, self._stream(out),
         )
         self._check(rc, "xde_stage_combine")
 

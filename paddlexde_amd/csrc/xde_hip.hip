@@ -51,11 +51,12 @@ int env_int(const char* name, int dflt) {
 }
 
 // XDE_NT: bit 0 = stream the dead operands of the error-norm kernel with non-temporal loads; bit 1 = stream every
-// operand load of the combine / error-norm kernels when one operand is >= XDE_NT_BYTES (default 64 MiB).  Default 3.
+// operand load of the combine / error-norm kernels when one operand is >= XDE_NT_BYTES (default 64 MiB); bit 2 = honour
+// the caller's per-operand last-use mask in the stage combines (-1.6 % step time on config 2).  Default 7.
 int nt_policy() {
   static int v = [] {
     const char* e = getenv("XDE_NT");
-    return (e && *e) ? atoi(e) : 3;
+    return (e && *e) ? atoi(e) : 7;
   }();
   return v;
 }
@@ -129,6 +130,12 @@ template <typename T> struct Pack<T, false> {
   __device__ void store(T* p, int64_t i) const { p[i] = v[0]; }
 };
 
+// load with a run-time (wave-uniform) choice of cache policy
+template <typename P, typename T>
+__device__ __forceinline__ P load_sel(const T* p, int64_t i, bool nt) {
+  return nt ? P::load_nt(p, i) : P::load(p, i);
+}
+
 template <typename T> __device__ inline bool finite_(T x) { return (x - x) == T(0); }
 template <typename T> __device__ inline T abs_(T x) { return x < T(0) ? -x : x; }
 __device__ inline float abs_(float x) { return fabsf(x); }
@@ -156,7 +163,7 @@ struct CombineArgs {
   int64_t n;
   int nk;
   int use_sel;
-  int nt;  // stream operand loads non-temporally (operands far larger than the Infinity Cache)
+  int nt;  // non-temporal mask: bit j = stream operand k_j (its last use), bit 31 = stream y0
 };
 
 struct SegMap {
@@ -243,9 +250,10 @@ __device__ __forceinline__ T fuse_(T dy, T dt, T y0, T lam) {
 // ------------------------------------------------------------------------------------------
 // K1: stage combine
 // ------------------------------------------------------------------------------------------
-template <typename T, int MODE, int NK, bool VEC, bool OUT2, bool NT>
+template <typename T, int MODE, int NK, bool VEC, bool OUT2>
 __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __restrict__ y0,
                                              const T* __restrict__ k0, T dt) {
+  const unsigned ntm = unsigned(a.nt);  // bit j: stream operand k_j; bit 31: stream y0
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
   T* __restrict__ out = static_cast<T*>(a.out);
@@ -270,10 +278,10 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
     // NT: with operands of >= 64 MiB nothing survives in the 256 MiB Infinity Cache between uses anyway; streaming
     // loads then run 12-17 % faster (5.1 -> 5.8 TB/s at 128 MiB x 7 streams).  At the 32 MiB headline size the
     // default policy wins by 18 % (the working set half-fits the cache), so the flag is size-dependent (host).
-    P y = NT ? P::load_nt(y0, i) : P::load(y0, i);
+    P y = load_sel<P>(y0, i, (ntm >> 31) & 1u);
     P kk[NK];
 #pragma unroll
-    for (int j = 0; j < NK; ++j) kk[j] = NT ? P::load_nt(kp[j], i) : P::load(kp[j], i);
+    for (int j = 0; j < NK; ++j) kk[j] = load_sel<P>(kp[j], i, (ntm >> j) & 1u);
     P o;
     P o2;
 #pragma unroll
@@ -402,13 +410,13 @@ __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
   const T* y0 = static_cast<const T*>(a.y0[sel]);
   const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
   switch (a.nk) {
-    case 1: if (a.nt) combine_body<T, MODE, 1, VEC, OUT2, true>(a, y0, k0, dt); else combine_body<T, MODE, 1, VEC, OUT2, false>(a, y0, k0, dt); break;
-    case 2: if (a.nt) combine_body<T, MODE, 2, VEC, OUT2, true>(a, y0, k0, dt); else combine_body<T, MODE, 2, VEC, OUT2, false>(a, y0, k0, dt); break;
-    case 3: if (a.nt) combine_body<T, MODE, 3, VEC, OUT2, true>(a, y0, k0, dt); else combine_body<T, MODE, 3, VEC, OUT2, false>(a, y0, k0, dt); break;
-    case 4: if (a.nt) combine_body<T, MODE, 4, VEC, OUT2, true>(a, y0, k0, dt); else combine_body<T, MODE, 4, VEC, OUT2, false>(a, y0, k0, dt); break;
-    case 5: if (a.nt) combine_body<T, MODE, 5, VEC, OUT2, true>(a, y0, k0, dt); else combine_body<T, MODE, 5, VEC, OUT2, false>(a, y0, k0, dt); break;
-    case 6: if (a.nt) combine_body<T, MODE, 6, VEC, OUT2, true>(a, y0, k0, dt); else combine_body<T, MODE, 6, VEC, OUT2, false>(a, y0, k0, dt); break;
-    case 7: if (a.nt) combine_body<T, MODE, 7, VEC, OUT2, true>(a, y0, k0, dt); else combine_body<T, MODE, 7, VEC, OUT2, false>(a, y0, k0, dt); break;
+    case 1: combine_body<T, MODE, 1, VEC, OUT2>(a, y0, k0, dt); break;
+    case 2: combine_body<T, MODE, 2, VEC, OUT2>(a, y0, k0, dt); break;
+    case 3: combine_body<T, MODE, 3, VEC, OUT2>(a, y0, k0, dt); break;
+    case 4: combine_body<T, MODE, 4, VEC, OUT2>(a, y0, k0, dt); break;
+    case 5: combine_body<T, MODE, 5, VEC, OUT2>(a, y0, k0, dt); break;
+    case 6: combine_body<T, MODE, 6, VEC, OUT2>(a, y0, k0, dt); break;
+    case 7: combine_body<T, MODE, 7, VEC, OUT2>(a, y0, k0, dt); break;
     default: combine_generic<T, MODE, VEC, OUT2>(a, y0, k0, dt); break;
   }
 }
@@ -1465,7 +1473,7 @@ int64_t xde_workspace_bytes(void) { return int64_t(sizeof(NormSlot)) * kSlots; }
 
 int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
                       const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
-                      int64_t n, int dtype, void* out2, const double* coef2, double damping, void* stream) {
+                      int64_t n, int dtype, void* out2, const double* coef2, double damping, uint32_t nt_mask, void* stream) {
   if (!out || !y0 || !k || !coef) return fail(XDE_EBADARG, "xde_stage_combine: null pointer");
   if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_stage_combine: nk out of range");
   if (n < 0) return fail(XDE_EBADARG, "xde_stage_combine: negative n");
@@ -1495,7 +1503,8 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   if (out2) vec = vec && aligned16(out2);
   if (damping != 0.0 && mode == XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: damping applies to FUSE/WFUSE");
   a.damp = damping;
-  a.nt = big_operand(n, dtype) ? 1 : 0;
+  // operands far larger than the Infinity Cache: stream everything; otherwise only what the caller marks as last use
+  a.nt = big_operand(n, dtype) ? int(0xFFFFFFFFu) : ((nt_policy() & 4) ? int(nt_mask) : 0);
   a.scale = scale;
   a.dt_host = dt_host;
   a.ctrl = ctrl;

@@ -142,6 +142,22 @@ class AdaptiveRKSolver(AdaptiveSolver):
         )
         if self._fuse_err:
             self._err2_coef = [float(tab.c_error[j]) for j in last_idx]
+        # cache-policy hint per stage: bit p set = operand p of that stage's list is read there for the last time in an
+        # accepted step (later readers: stages, the unfused error estimate; dense output is rare and lazy)
+        last_use = {}
+        for i, (idx_i, _) in enumerate(self._stage_plan):
+            for j in idx_i:
+                last_use[j] = i
+        later = set(self._sol_plan[0]) if not self._fsal else set()
+        if not self._fuse_err:
+            later |= set(self._err_plan[0])
+        self._stage_nt = []
+        for i, (idx_i, _) in enumerate(self._stage_plan):
+            m = 0
+            for pos, j in enumerate(idx_i):
+                if last_use[j] == i and j not in later:
+                    m |= 1 << pos
+            self._stage_nt.append(m)
 
         # -- segments / norm ---------------------------------------------------------------------
         n = self.y0.numel()
@@ -270,7 +286,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._sums = be.new_sums(dev)
         self._seg_count = self._global_counts()
         self._scratch = torch.empty_like(y0)
-        self._ebuf = torch.empty_like(y0) if self._fuse_err else None
+        # the partial error sum of the last stage goes into the stage scratch buffer: by then the previous stage's
+        # input it held has been consumed by func (one buffer less in the step's working set)
+        self._ebuf = self._scratch if self._fuse_err else None
 
         # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
         f0 = self._eval(self._scalar_t(t_span[0], self.dtype), y0)
@@ -334,9 +352,10 @@ class AdaptiveRKSolver(AdaptiveSolver):
             out = torch.empty_like(y0) if (i == S - 1 and self._fsal) else self._scratch
             if i == S - 1 and fuse:
                 be.stage_combine(out, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt,
-                                 out2=self._ebuf, coef2=self._err2_coef)
+                                 out2=self._ebuf, coef2=self._err2_coef, nt_mask=self._stage_nt[i])
             else:
-                be.stage_combine(out, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
+                be.stage_combine(out, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt,
+                                 nt_mask=self._stage_nt[i] if fuse else 0)
             ks.append(self._eval(self._t_stage[i], out, live=ks + keep))
             y_stage = out
         if self._fsal:

@@ -47,7 +47,7 @@ class NumpyDoubleBackend:
 
     # -- K1 -------------------------------------------------------------------------------------
     def stage_combine(self, out, y0, ks, coef, mode, *, scale=1.0, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None,
-                      out2=None, coef2=None, damping=0.0):
+                      out2=None, coef2=None, damping=0.0, nt_mask=0):
         self.launches.append("combine")
         T = _NP[out.dtype]
         sel = 0

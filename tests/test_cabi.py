@@ -44,7 +44,7 @@ def test_struct_layouts_match():
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected on the host before any HIP call (safe on a CPU-only box)."""
     lib = _hip.load_library()
-    assert lib.xde_stage_combine(None, None, None, None, None, None, 1, 0, 1.0, 0.0, None, 8, 0, None, None, 0.0, None) == _hip.XDE_EBADARG
+    assert lib.xde_stage_combine(None, None, None, None, None, None, 1, 0, 1.0, 0.0, None, 8, 0, None, None, 0.0, 0, None) == _hip.XDE_EBADARG
     assert lib.xde_hermite_gather(None, None, None, None, None, 1, 4, 2, 3, 0, None) == _hip.XDE_EBADARG
     assert b"null pointer" in lib.xde_last_error()
     assert lib.xde_norm_finalize(None, 0, None, None) == _hip.XDE_EBADARG

@@ -41,7 +41,7 @@ def test_dopri5_through_raw_c_abi():
     lib.xde_last_error.restype = C.c_char_p
     lib.xde_sizeof_ctrl.restype = i64
     lib.xde_workspace_bytes.restype = i64
-    lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, vp]
+    lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, C.c_uint32, vp]
     lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(Segs), i32, i32, vp, vp, vp]
     lib.xde_rk_control.argtypes = [vp, C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp]
     lib.xde_ctrl_init.argtypes = [vp, C.POINTER(Params), dbl, dbl, C.c_int32, vp, vp, vp, i64, vp]
@@ -108,7 +108,7 @@ def test_dopri5_through_raw_c_abi():
             idx = [0] + [j for j in range(1, i + 1) if beta[i][j] != 0]
             out = torch.empty_like(y)
             ok(lib.xde_stage_combine(out.data_ptr(), y.data_ptr(), None, ptrs([ks[j] for j in idx]), None, dbls([beta[i][j] for j in idx]),
-                                     len(idx), 0, 1.0, 0.0, ctrl.data_ptr(), n, 0, None, None, 0.0, stream))
+                                     len(idx), 0, 1.0, 0.0, ctrl.data_ptr(), n, 0, None, None, 0.0, 0, stream))
             ks.append(func(t_stage[i], out).contiguous())
             y1 = out
         eidx = [0, 2, 3, 4, 5, 6]
