@@ -247,7 +247,21 @@ int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void
  */
 int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_start,
                   double first_step, int32_t n_out, const double* t_span_dev,
-                  const double* step_t_dev, void* t_stage_out, int64_t seq0, void* stream);
+                  const double* step_t_dev, void* t_stage_out, int64_t seq0,
+                  const double* first_step_dev, void* stream);
+
+/*
+ * Scalar part of the initial-step heuristic on the device — AdaptiveSolver.select_initial_step
+ * (solver/base_adaptive_solver.py:55-72) without reading the three norms back to the host.
+ *   phase 0: res_dev = {d0, d1} (xde_norm_result outputs) -> h0 (hs_dev[2]); ctrl->dt = h0, so that the Euler probe
+ *            `fuse(f0, h0, y0)` is an xde_stage_combine that reads dt from ctrl; *t_probe_out = t_start + h0 (dtype
+ *            probe_dtype = promote(time dtype, state dtype)) is the time func is evaluated at.
+ *   phase 1: res_dev = {norm((f1 - f0)/scale)} -> d2 = |./h0| -> h1 -> hs_dev[3] = min(100 h0, h1) in the time dtype;
+ *            pass hs_dev + 3 to xde_ctrl_init as first_step_dev.  (first_step_dev != NULL overrides first_step; the
+ *            direction's sign is applied there.)
+ */
+int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde_ctrl_params_t* params,
+                     double t_start, void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl, void* stream);
 
 /* Blocking device->host copy of the control block (hipMemcpyAsync + stream synchronise). */
 int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream);

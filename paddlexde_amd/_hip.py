@@ -38,6 +38,7 @@ SYMBOLS = (
     "xde_norm_result",
     "xde_rk_control",
     "xde_ctrl_init",
+    "xde_initial_step",
     "xde_ctrl_read",
     "xde_host_alloc",
     "xde_host_free",
@@ -167,7 +168,9 @@ def load_library():
         lib.xde_rk_control.restype = i32
         lib.xde_rk_control.argtypes = [vp, C.POINTER(XdeCtrlParams), vp, vp, vp, vp, vp, vp, vp]
         lib.xde_ctrl_init.restype = i32
-        lib.xde_ctrl_init.argtypes = [vp, C.POINTER(XdeCtrlParams), dbl, dbl, C.c_int32, vp, vp, vp, i64, vp]
+        lib.xde_ctrl_init.argtypes = [vp, C.POINTER(XdeCtrlParams), dbl, dbl, C.c_int32, vp, vp, vp, i64, vp, vp]
+        lib.xde_initial_step.restype = i32
+        lib.xde_initial_step.argtypes = [i32, vp, vp, C.POINTER(XdeCtrlParams), dbl, vp, i32, vp, vp]
         lib.xde_host_alloc.restype = i32
         lib.xde_host_alloc.argtypes = [i64, C.POINTER(C.c_void_p)]
         lib.xde_host_free.restype = i32
@@ -247,7 +250,9 @@ class HipBackend:
 
     def _acquire_mirror(self):
         if self._mirror_pool:
-            return self._mirror_pool.pop()
+            m = self._mirror_pool.pop()
+            m.seq0 = m.seq  # nothing published for the new owner yet: ctrl_read falls back to a device copy
+            return m
         ptr = C.c_void_p()
         self._check(self.lib.xde_host_alloc(XDE_MIRROR_SLOTS * C.sizeof(XdeCtrl), C.byref(ptr)), "xde_host_alloc")
         return HipBackend._Mirror(ptr.value)
@@ -365,12 +370,20 @@ class HipBackend:
         if m is not None and not self._capturing:
             m.seq += 1
 
-    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage):
+    def initial_step(self, phase, res, hs, params, t_start, t_probe, ctrl):
+        """Scalar part of select_initial_step on the device (phase 0: h0; phase 1: the first step)."""
+        self._require_device(res, hs, ctrl, t_probe)
+        rc = self.lib.xde_initial_step(int(phase), res.data_ptr(), hs.data_ptr(), C.byref(params), float(t_start), _ptr(t_probe),
+                                       dtype_code(t_probe.dtype) if t_probe is not None else XDE_F32, ctrl.data_ptr(), self._stream(ctrl))
+        self._check(rc, "xde_initial_step")
+
+    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None):
         self._require_device(ctrl, t_span_dev, t_stage)
         m = self._mirrors.get(ctrl.data_ptr())
         seq0 = m.seq if m is not None else 0
         rc = self.lib.xde_ctrl_init(ctrl.data_ptr(), C.byref(params), float(t_start), float(first_step), int(n_out),
-                                    t_span_dev.data_ptr(), _ptr(step_t_dev), t_stage.data_ptr(), seq0, self._stream(ctrl))
+                                    t_span_dev.data_ptr(), _ptr(step_t_dev), t_stage.data_ptr(), seq0, _ptr(first_step_dev),
+                                    self._stream(ctrl))
         self._check(rc, "xde_ctrl_init")
         if m is not None:
             m.seq0 = seq0

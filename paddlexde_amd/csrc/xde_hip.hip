@@ -1093,13 +1093,14 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, 
 
 __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
                                      int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
-                                     int64_t seq0) {
+                                     int64_t seq0, const double* first_step_dev) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   xde_ctrl_t z;
   memset(&z, 0, sizeof(z));
   z.t0 = t_start;
   z.t1 = t_start;
-  z.dt = first_step;
+  // device-resident first step (xde_initial_step): a magnitude, given the direction's sign here
+  z.dt = first_step_dev ? double(p.direction) * fabs(*first_step_dev) : first_step;
   z.n_out = n_out;
   z.ratio_prev = 1e-4;
   // rows whose time equals the start time are y0 itself (the reference's `while next_t > t1` does not
@@ -1124,6 +1125,59 @@ __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double 
   else
     plan_next<double>(&z, p, step_t, t_stage_out);
   *c = z;
+}
+
+// Hairer's initial-step heuristic, scalar part (solver/base_adaptive_solver.py:55-72), in the state dtype Y with the
+// reference's op order.  phase 0: (d0, d1) -> h0, written to ctrl->dt (the Euler probe y0 + h0*f0 is a combine that
+// reads dt from ctrl) and t0 + h0 for func.  phase 1: d2 = |norm((f1-f0)/scale) / h0| -> h1 -> min(100*h0, h1).
+template <typename Y>
+__device__ void initial_step_phase(int phase, const double* res, double* hs, const xde_ctrl_params_t& p, double t_start,
+                                   void* t_probe_out, int probe_dtype, xde_ctrl_t* c) {
+  if (phase == 0) {
+    const Y d0 = Y(fabs(res[0])), d1 = Y(fabs(res[1]));
+    Y h0;
+    if (d0 < Y(1e-5) || d1 < Y(1e-5))
+      h0 = Y(1e-6);
+    else
+      h0 = Y(0.01) * d0 / d1;
+    h0 = h0 < Y(0) ? -h0 : h0;
+    hs[0] = double(d0);
+    hs[1] = double(d1);
+    hs[2] = double(h0);
+    c->dt = double(h0);
+    // t0 + h0: time dtype + state dtype -> the promoted dtype
+    if (probe_dtype == XDE_F32)
+      *static_cast<float*>(t_probe_out) = float(t_start) + float(h0);
+    else
+      *static_cast<double*>(t_probe_out) = (p.time_dtype == XDE_F32 ? double(float(t_start)) : t_start) + double(h0);
+  } else {
+    const Y h0 = Y(hs[2]), d1 = Y(hs[1]);
+    Y d2 = Y(res[0]) / h0;
+    d2 = d2 < Y(0) ? -d2 : d2;
+    Y h1;
+    if (d1 <= Y(1e-15) && d2 <= Y(1e-15)) {
+      const Y a = Y(1e-6), b = h0 * Y(1e-3);
+      h1 = (b > a) ? b : a;  // Python's max(a, b)
+    } else {
+      // Python's max(d1, d2): returns d1 unless d2 > d1 (a NaN d2 is ignored, a NaN d1 is kept)
+      const Y m = (d2 > d1) ? d2 : d1;
+      const Y e = Y(1.0 / (p.order - 1.0 + 1.0));  // called with order - 1: exponent 1 / (order - 1 + 1)
+      h1 = Y(pow_<Y>(Y(0.01) / m, e));
+    }
+    h1 = h1 < Y(0) ? -h1 : h1;
+    const Y a = Y(100.0) * h0;
+    const Y first = fmin__<Y>(a, h1);
+    hs[3] = p.time_dtype == XDE_F32 ? double(float(first)) : double(first);
+  }
+}
+
+__global__ void xde_initial_step_kernel(int phase, const double* res, double* hs, xde_ctrl_params_t p, double t_start,
+                                        void* t_probe_out, int probe_dtype, xde_ctrl_t* c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (p.state_dtype == XDE_F32)
+    initial_step_phase<float>(phase, res, hs, p, t_start, t_probe_out, probe_dtype, c);
+  else
+    initial_step_phase<double>(phase, res, hs, p, t_start, t_probe_out, probe_dtype, c);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1823,7 +1877,8 @@ int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void
 }
 
 int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_start, double first_step, int32_t n_out,
-                  const double* t_span_dev, const double* step_t_dev, void* t_stage_out, int64_t seq0, void* stream) {
+                  const double* t_span_dev, const double* step_t_dev, void* t_stage_out, int64_t seq0,
+                  const double* first_step_dev, void* stream) {
   if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_ctrl_init: null pointer");
   int rc = check_params(params, "xde_ctrl_init");
   if (rc != XDE_OK) return rc;
@@ -1831,7 +1886,22 @@ int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_st
   if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_ctrl_init: n_step_t > 0 without step_t_dev");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(xde_ctrl_init_kernel, dim3(1), dim3(64), 0, st, ctrl, *params, t_start, first_step, n_out,
-                     t_span_dev, step_t_dev, t_stage_out, seq0);
+                     t_span_dev, step_t_dev, t_stage_out, seq0, first_step_dev);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde_ctrl_params_t* params, double t_start,
+                     void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl, void* stream) {
+  if (!res_dev || !hs_dev || !ctrl) return fail(XDE_EBADARG, "xde_initial_step: null pointer");
+  if (phase != 0 && phase != 1) return fail(XDE_EBADARG, "xde_initial_step: phase must be 0 or 1");
+  if (phase == 0 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step: phase 0 needs t_probe_out");
+  if (probe_dtype != XDE_F32 && probe_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step: bad probe dtype");
+  int rc = check_params(params, "xde_initial_step");
+  if (rc != XDE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(xde_initial_step_kernel, dim3(1), dim3(64), 0, st, phase, res_dev, hs_dev, *params, t_start, t_probe_out,
+                     probe_dtype, ctrl);
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

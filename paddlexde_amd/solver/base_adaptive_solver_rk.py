@@ -115,6 +115,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # Bit-identical, but measured no faster than two launches (the controller's latency chain just moves into
         # the tail of the norm kernel: 36.4 us vs 23.1 + 12 us on config 2), so it is off by default.
         self._fuse_control = os.environ.get("XDE_FUSE_CONTROL", "0") == "1"
+        # the initial-step heuristic's scalar arithmetic runs on the device (xde_initial_step; no host read before the first
+        # attempt).  XDE_HOST_FIRST_STEP=1 takes the host version (select_initial_step), which a custom norm always does.
+        self._device_first_step = os.environ.get("XDE_HOST_FIRST_STEP", "0") != "1"
 
         self.backend = _hip.get_backend()
         self.nfe = 0
@@ -290,15 +293,6 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # input it held has been consumed by func (one buffer less in the step's working set)
         self._ebuf = self._scratch if self._fuse_err else None
 
-        # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
-        f0 = self._eval(self._scalar_t(t_span[0], self.dtype), y0)
-        if self.first_step is None:
-            # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
-            first_step = self.select_initial_step(t_span[0], y0, self.order - 1, self.rtol, self.atol)
-        else:
-            first_step = self.first_step
-        self.rk_state = _RungeKuttaState(y0, f0, t_span[0], t_span[0], first_step, None)
-
         # step_t handling                                                                        :95-111
         d = self._direction
         if self.step_t is None:
@@ -331,8 +325,50 @@ class AdaptiveRKSolver(AdaptiveSolver):
         for i, c in enumerate(self._seg_count):
             p.seg_count[i] = float(c)
         self._params = p
-        be.ctrl_init(self._ctrl, p, float(t_span[0]), float(d * abs(first_step)), len(t_span), self._t_span_dev,
-                     self._step_t_dev, self._t_stage)
+
+        # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
+        f0 = self._eval(self._scalar_t(t_span[0], self.dtype), y0)
+        first_dev = None
+        if self.first_step is None:
+            # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
+            if self._custom_norm or not self._device_first_step:
+                first_step = self.select_initial_step(t_span[0], y0, self.order - 1, self.rtol, self.atol)
+            else:
+                first_step, first_dev = None, self._select_initial_step_device(t_span[0], y0)
+        else:
+            first_step = self.first_step
+        self.rk_state = _RungeKuttaState(y0, f0, t_span[0], t_span[0], first_step, None)
+        be.ctrl_init(self._ctrl, p, float(t_span[0]), 0.0 if first_step is None else float(d * abs(first_step)), len(t_span),
+                     self._t_span_dev, self._step_t_dev, self._t_stage, first_step_dev=first_dev)
+
+    def _select_initial_step_device(self, t0, y0):
+        """``select_initial_step`` (base_adaptive_solver.py:33-72) with its scalar arithmetic on the device: the three
+        norms feed two one-thread launches (xde_initial_step) instead of two blocking reads; the first step never visits
+        the host.  Same op order and dtypes as the host version above it in the class hierarchy."""
+        be = self.backend
+        dev = y0.device
+        sdt = _hip.dtype_code(y0.dtype)
+        t0h = np_dtype(self.dtype)(t0)
+        f0 = self._eval(self._scalar_t(t0h, self.dtype), y0)
+        res = torch.empty(2, dtype=torch.float64, device=dev)
+        hs = torch.zeros(4, dtype=torch.float64, device=dev)
+
+        def norm_into(a, b, out):
+            be.scaled_norm_partial(a, b, y0, float(self.rtol), float(self.atol), self._xsegs, self._norm_kind, self._ws, 0)
+            be.norm_finalize(self._ws, 0, self._sums)
+            self._allreduce_sums(self._sums)
+            be.norm_result(self._sums, self._seg_count, self._norm_kind, sdt, out)
+
+        norm_into(y0, None, res[0:1])
+        norm_into(f0, None, res[1:2])
+        t_probe = torch.empty((), dtype=torch.promote_types(self.dtype, y0.dtype), device=dev)
+        be.initial_step(0, res, hs, self._params, float(t0h), t_probe, self._ctrl)  # h0 -> ctrl.dt, t0 + h0 -> t_probe
+        y1 = torch.empty_like(y0)
+        be.stage_combine(y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
+        f1 = self._eval(t_probe, y1)
+        norm_into(f1, f0, res[0:1])
+        be.initial_step(1, res, hs, self._params, float(t0h), None, self._ctrl)
+        return hs[3:4]
 
     # ------------------------------------------------------------------------------------------
     # one attempted step = _runge_kutta_step (:129-181) + error ratio + controller (:183-284)

@@ -222,10 +222,36 @@ class NumpyDoubleBackend:
                 a = Y(p.alpha[i])
                 ts[i] = Y(t1) if a == 1.0 else Y(t0) + a * Y(dt)
 
-    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage):
+    def initial_step(self, phase, res, hs, params, t_start, t_probe, ctrl):
+        Y = np.float32 if params.state_dtype == _hip.XDE_F32 else np.float64
+        r, h = res.numpy(), hs.numpy()
+        with np.errstate(all="ignore"):
+            if phase == 0:
+                d0, d1 = Y(abs(r[0])), Y(abs(r[1]))
+                h0 = Y(1e-6) if (d0 < 1e-5 or d1 < 1e-5) else Y(0.01) * d0 / d1
+                h0 = abs(h0)
+                h[0], h[1], h[2] = d0, d1, h0
+                self._c(ctrl).dt = float(h0)
+                t0 = np.float32(t_start) if params.time_dtype == _hip.XDE_F32 else np.float64(t_start)
+                t_probe.numpy()[...] = t0 + h0
+            else:
+                h0, d1 = Y(h[2]), Y(h[1])
+                d2 = abs(Y(r[0]) / h0)
+                if d1 <= 1e-15 and d2 <= 1e-15:
+                    h1 = max(Y(1e-6), h0 * Y(1e-3))
+                else:
+                    m = d2 if d2 > d1 else d1
+                    h1 = Y((Y(0.01) / m) ** Y(1.0 / (params.order - 1.0 + 1.0)))
+                h1 = abs(h1)
+                first = np.fmin(Y(100.0) * h0, h1)
+                h[3] = float(np.float32(first)) if params.time_dtype == _hip.XDE_F32 else float(first)
+
+    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None):
         c = self._c(ctrl)
         C.memset(C.addressof(c), 0, C.sizeof(c))
         c.t0 = c.t1 = float(t_start)
+        if first_step_dev is not None:
+            first_step = float(params.direction) * abs(float(first_step_dev.numpy()[0]))
         c.dt = float(first_step)
         c.n_out = n_out
         c.ratio_prev = 1e-4

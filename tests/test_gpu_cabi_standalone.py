@@ -44,7 +44,7 @@ def test_dopri5_through_raw_c_abi():
     lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, C.c_uint32, vp]
     lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(Segs), i32, i32, vp, vp, vp]
     lib.xde_rk_control.argtypes = [vp, C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp]
-    lib.xde_ctrl_init.argtypes = [vp, C.POINTER(Params), dbl, dbl, C.c_int32, vp, vp, vp, i64, vp]
+    lib.xde_ctrl_init.argtypes = [vp, C.POINTER(Params), dbl, dbl, C.c_int32, vp, vp, vp, i64, vp, vp]
     lib.xde_ctrl_read.argtypes = [vp, C.POINTER(Ctrl), vp]
     lib.xde_dense_eval.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i64, vp]
     assert lib.xde_sizeof_ctrl() == C.sizeof(Ctrl)
@@ -91,7 +91,7 @@ def test_dopri5_through_raw_c_abi():
     sol = torch.empty(len(t_span), B, D, device=dev)
     sol[0] = y0
     first_step = 0.01
-    ok(lib.xde_ctrl_init(ctrl.data_ptr(), C.byref(p), 0.0, first_step, len(t_span), t_dev.data_ptr(), None, t_stage.data_ptr(), 0, stream))
+    ok(lib.xde_ctrl_init(ctrl.data_ptr(), C.byref(p), 0.0, first_step, len(t_span), t_dev.data_ptr(), None, t_stage.data_ptr(), 0, None, stream))
 
     def ptrs(ts):
         return (C.c_void_p * len(ts))(*[x.data_ptr() for x in ts])

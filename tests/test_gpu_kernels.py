@@ -319,3 +319,49 @@ def test_dense_eval_bit_exact(be, dbl, dtype, n):
     dbl.dense_eval(ref, [k.cpu() for k in ks], mid, y0.cpu(), y1.cpu(), f1.cpu(), torch.frombuffer(bytearray(raw), dtype=torch.uint8), t_span, _hip.XDE_F32)
     assert torch.equal(out.cpu(), ref)
     assert (out[0] == 0).all() and (out[3] == 0).all()
+
+
+@pytest.mark.parametrize("tdtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_initial_step_scalars(be, dbl, dtype, tdtype):
+    """xde_initial_step (both phases) + xde_ctrl_init(first_step_dev) against the numpy statement of
+    select_initial_step's scalar arithmetic: every branch, both directions, NaN."""
+    dev = torch.device("cuda:0")
+    p = _hip.XdeCtrlParams()
+    p.rtol, p.atol, p.min_step, p.max_step = 1e-3, 1e-5, 0.0, float("inf")
+    p.safety, p.ifactor, p.dfactor, p.order = 0.9, 10.0, 0.2, 5.0
+    p.max_num_steps = 2**31 - 1
+    p.time_dtype = _hip.dtype_code(DT[tdtype])
+    p.state_dtype = _hip.dtype_code(DT[dtype])
+    p.norm_kind, p.n_stage, p.n_seg = _hip.NORM_RMS, 6, 1
+    p.seg_count[0] = 8.0
+    probe_dt = torch.promote_types(DT[dtype], DT[tdtype])
+    cases = [(0.7, 3.1, 12.0), (1e-7, 3.1, 0.5), (0.7, 1e-9, 2.0), (0.7, 1e-16, 1e-23), (0.7, 1e-16, 0.0), (250.0, 0.04, 9e5),
+             (float("nan"), 1.0, 1.0), (1.0, 1.0, float("nan")), (3.0, 2.0, 1e-12)]
+    t_span = torch.tensor([0.25, 1.0], dtype=torch.float64)
+    for direction in (1, -1):
+        p.direction = direction
+        for d0, d1, n2 in cases:
+            out = []
+            for backend, device in ((be, dev), (dbl, torch.device("cpu"))):
+                ctrl = backend.new_ctrl(device)
+                ts = torch.zeros(_hip.XDE_MAX_STAGE, dtype=DT[dtype], device=device)
+                res = torch.tensor([d0, d1], dtype=torch.float64, device=device)
+                hs = torch.zeros(4, dtype=torch.float64, device=device)
+                t_probe = torch.zeros((), dtype=probe_dt, device=device)
+                backend.initial_step(0, res, hs, p, 0.25, t_probe, ctrl)
+                h0_in_ctrl = backend.ctrl_read(ctrl).dt
+                res[0] = n2
+                backend.initial_step(1, res, hs, p, 0.25, None, ctrl)
+                backend.ctrl_init(ctrl, p, 0.25, 0.0, 2, t_span.to(device), None, ts, first_step_dev=hs[3:4])
+                out.append((hs.cpu().numpy().copy(), h0_in_ctrl, float(t_probe), backend.ctrl_read(ctrl).dt))
+            (hg, cg, tg, fg), (hr, cr, tr, fr) = out
+            # h0 and the probe time: exact; the first step goes through pow(): 2 ulp of the state dtype
+            np.testing.assert_array_equal(hg[:3], hr[:3])
+            assert cg == cr or (np.isnan(cg) and np.isnan(cr))
+            assert tg == tr or (np.isnan(tg) and np.isnan(tr))
+            eps = np.finfo(np.float32 if dtype == "f32" else np.float64).eps
+            np.testing.assert_allclose(hg[3], hr[3], rtol=2 * eps, atol=0, equal_nan=True)
+            np.testing.assert_allclose(fg, fr, rtol=2 * eps, atol=0, equal_nan=True)
+            if not np.isnan(fr):
+                assert np.sign(fg) == direction
