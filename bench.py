@@ -124,21 +124,23 @@ def side_workload(args):
         y0 = (torch.tensor([2.0, 0.0]) + 0.01 * torch.randn(4096, 2, generator=torch.Generator().manual_seed(0))).to(dev)
         t = torch.tensor([0.0, 1.0])
         res = {}
-        for dtype in (torch.float32, torch.float64):
-            y = y0.to(dtype)
-            for rep in range(2):  # first repetition warms allocator / kernels up
-                xde = BaseODE(vdp, y0=y, t_span=t)
-                s = Dopri5(xde=xde, y0=y, rtol=1e-5, atol=1e-7, norm=_rms_norm, max_num_steps=10**6, pipeline=args.pipeline,
-                           dtype=dtype)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                sol = s.integrate(t)
-                torch.cuda.synchronize()
-                el = time.perf_counter() - t0
-            st = s.stats
-            res[str(dtype).split(".")[-1]] = {"n_accept": st["n_accept"], "n_reject": st["n_reject"], "nfe": st["nfe"],
-                                              "seconds": el, "us_per_attempted_step": 1e6 * el / max(st["n_steps"], 1),
-                                              "finite": bool(torch.isfinite(sol).all())}
+        # "I" is the reference's controller (ode_utils.py:85-97); "PI" is the opt-in one BASELINE.json's config 5 names
+        for controller in ("I", "PI"):
+            for dtype in (torch.float32, torch.float64):
+                y = y0.to(dtype)
+                for rep in range(2):  # first repetition warms allocator / kernels up
+                    xde = BaseODE(vdp, y0=y, t_span=t)
+                    s = Dopri5(xde=xde, y0=y, rtol=1e-5, atol=1e-7, norm=_rms_norm, max_num_steps=10**6, pipeline=args.pipeline,
+                               dtype=dtype, controller=controller)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    sol = s.integrate(t)
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t0
+                st = s.stats
+                res[controller + "/" + str(dtype).split(".")[-1]] = {
+                    "n_accept": st["n_accept"], "n_reject": st["n_reject"], "nfe": st["nfe"], "seconds": el,
+                    "us_per_attempted_step": 1e6 * el / max(st["n_steps"], 1), "finite": bool(torch.isfinite(sol).all())}
         print(json.dumps({"metric": "us per attempted dopri5 step (latency-bound)", "workload": "c5: Van der Pol mu=1000, batch 4096 x 2, "
                           "t in [0,1], rtol 1e-5 atol 1e-7", "pipeline": args.pipeline, "results": res}))
         return

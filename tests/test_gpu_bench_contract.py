@@ -45,4 +45,6 @@ def test_bench_side_workloads_run():
                        text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert j["results"]["float64"]["n_reject"] > 0 and j["results"]["float64"]["finite"]
+    for controller in ("I", "PI"):
+        r64 = j["results"][controller + "/float64"]
+        assert r64["n_reject"] > 0 and r64["finite"]
