@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <ctime>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1934,13 +1935,20 @@ int xde_ctrl_wait(const xde_ctrl_t* host_mirror, int64_t seq, double timeout_ms,
   const xde_ctrl_t* slot = host_mirror + (seq % XDE_MIRROR_SLOTS);
   const auto t_begin = std::chrono::steady_clock::now();
   uint64_t spins = 0;
+  bool slow = false;
   for (;;) {
     int64_t cur = __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE);
     if (cur == seq) break;
     if (cur > seq) return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot already overwritten by a later launch");
-    if ((++spins & 0x3ff) == 0) {
+    if (slow || (++spins & 0x3ff) == 0) {
       double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
       if (ms > timeout_ms) return fail(XDE_ETIMEOUT, "xde_ctrl_wait: timed out waiting for the controller launch");
+      slow = ms > 5.0;  // a long func evaluation is in flight: stop burning the core, poll every ~50 us
+    }
+    if (slow) {
+      struct timespec ts = {0, 50000};
+      nanosleep(&ts, nullptr);
+      continue;
     }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
