@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="rows per GPU")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--pipeline", default="lag", choices=["sync", "lag", "graph"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="state dtype (the headline metric is quoted on f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-func", action="store_true", help="c3: replay the augmented dynamics from a captured HIP graph")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
@@ -255,6 +256,8 @@ def main():
 
     B, D = args.batch, args.dim
     A, y0 = make_problem(B, D, rank, device)
+    if args.dtype == "f64":
+        A, y0 = A.double(), y0.double()
     AT = A.T.contiguous()
     func = lambda t, y: y @ AT  # noqa: E731  the user's func stays a framework call
 
@@ -306,7 +309,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {
             "workload": "linear ODE dy/dt=Ay, dopri5 adaptive (rtol 1e-5, atol 1e-7), batch={} x dim={} per GPU, {} GPU(s), "
@@ -334,14 +337,15 @@ def main():
         achieved = comb["bytes"] / (comb["ms"] * 1e-3) / 1e9 if comb["ms"] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_combine.json")
-        if os.path.exists(tpath) and (B, D) == (65536, 128):  # the PMC passes were taken at the default workload size
+        if os.path.exists(tpath) and (B, D, args.dtype) == (65536, 128, "f32"):  # the PMC passes were taken at the default workload size
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out["roofline"] = {
             "bound": "hbm",
-            "kernel": "xde_combine_kernel<float, RK, vec> (6 launches per step; the last one also emits the partial error sum)",
+            "kernel": "xde_combine_kernel<{}, RK, vec> (6 launches per step; the last one also emits the partial error sum)".format(
+                "float" if args.dtype == "f32" else "double"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -360,7 +364,7 @@ def main():
         out["solver_kernel_ms_per_step"] = solver_ms
         out["solver_only_states_per_s"] = N_local / (solver_ms * 1e-3) if solver_ms > 0 else None
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
         out["cpu_baseline"] = cpu_baseline(D)
 
     if dist is not None:
