@@ -1387,6 +1387,97 @@ __global__ __launch_bounds__(kBlock) void xde_hermite_kernel(T* __restrict__ val
   }
 }
 
+// The same arithmetic with everything that depends only on the lag hoisted out of the element loop: each workgroup
+// builds the per-lag table (interval index, Hermite basis values, the interval widths, which rows feed the two node
+// derivatives) in LDS once, then streams 16-byte vectors along D: three row loads, two stores per output vector.
+constexpr int kHermiteMaxL = 128;
+template <typename T>
+struct HermiteLag {
+  int i, mode, zrow, pad;  // mode 0: interior; 1: i == T-2 (d1 repeats d0's rows); 2: i == T-1 (both use rows T-2, T-1)
+  T h1, h2, ha, hb, c0, c1, c2, c3, g0, g1, g2, g3;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void xde_hermite_vec_kernel(T* __restrict__ val, T* __restrict__ der,
+                                                                 const T* __restrict__ his, const T* __restrict__ ts,
+                                                                 const T* __restrict__ lags, int64_t outer, int Tn, int D, int L) {
+  using P = Pack<T, true>;
+  constexpr int W = P::W;
+  __shared__ HermiteLag<T> tab[kHermiteMaxL];
+  for (int l = threadIdx.x; l < L; l += kBlock) {
+    const T tau = lags[l];
+    int lo = 0, hi = Tn;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (ts[mid] < tau) lo = mid + 1; else hi = mid;
+    }
+    int i = lo - 1;
+    i = i < 0 ? 0 : (i > Tn - 1 ? Tn - 1 : i);
+    auto h_at = [&](int j) -> T {
+      int jj = j < Tn - 1 ? j : Tn - 2;
+      return ts[jj + 1] - ts[jj];
+    };
+    HermiteLag<T> r;
+    r.i = i;
+    r.mode = i <= Tn - 3 ? 0 : (i == Tn - 2 ? 1 : 2);
+    r.zrow = r.mode == 0 ? i + 2 : Tn - 2;
+    r.pad = 0;
+    r.h1 = h_at(i);
+    r.h2 = i == 0 ? h_at(0) : h_at(i - 1);
+    r.ha = h_at(i);
+    r.hb = h_at(i + 1);
+    const T sx = (tau - ts[i]) / r.h1;
+    const T s2 = sx * sx, s3 = s2 * sx;
+    r.c0 = T(2) * s3 - T(3) * s2 + T(1);
+    r.c1 = T(-2) * s3 + T(3) * s2;
+    r.c2 = s3 - T(2) * s2 + sx;
+    r.c3 = s3 - s2;
+    r.g0 = T(6) * s2 - T(6) * sx;
+    r.g1 = T(-6) * s2 + T(6) * sx;
+    r.g2 = T(3) * s2 - T(4) * sx + T(1);
+    r.g3 = T(3) * s2 - T(2) * sx;
+    tab[l] = r;
+  }
+  __syncthreads();
+  const int DV = D / W;
+  const int64_t total = outer * int64_t(L) * DV;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  const int64_t rowv = int64_t(Tn) * DV;  // vectors per outer slice of his
+  for (int64_t e = int64_t(blockIdx.x) * kBlock + threadIdx.x; e < total; e += stride) {
+    int dv, l;
+    int64_t o;
+    if (total < (int64_t(1) << 31)) {  // 32-bit index arithmetic whenever it fits
+      const unsigned eu = unsigned(e), q = eu / unsigned(DV);
+      dv = int(eu - q * unsigned(DV));
+      const unsigned q2 = q / unsigned(L);
+      l = int(q - q2 * unsigned(L));
+      o = q2;
+    } else {
+      dv = int(e % DV);
+      l = int((e / DV) % L);
+      o = e / (int64_t(DV) * L);
+    }
+    const HermiteLag<T>& r = tab[l];
+    const int64_t base = o * rowv + dv;
+    const int i1 = r.i + 1 < Tn ? r.i + 1 : Tn - 1;
+    const P X = P::load(his, base + int64_t(r.i) * DV);
+    const P Y = P::load(his, base + int64_t(i1) * DV);
+    const P Z = P::load(his, base + int64_t(r.zrow) * DV);
+    P v, g;
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+      const T p0 = X.v[x] / r.h1, p1 = Y.v[x] / r.h2;
+      const T n0 = r.mode == 2 ? X.v[x] - Z.v[x] : Y.v[x] - X.v[x];
+      const T n1 = r.mode == 0 ? Z.v[x] - Y.v[x] : n0;
+      const T d0 = n0 / r.ha, d1 = n1 / r.hb;
+      v.v[x] = (((r.c0 * p0 + r.c1 * p1) + r.c2 * d0) + r.c3 * d1) * r.h1;
+      g.v[x] = ((r.g0 * p0 + r.g1 * p1) + r.g2 * d0) + r.g3 * d1;
+    }
+    v.store(val, e);
+    g.store(der, e);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // predicated commit (hipGraph pipeline): (y0, f0) <- (y1, f1) when the step was accepted
 // ------------------------------------------------------------------------------------------
@@ -2073,7 +2164,22 @@ int xde_hermite_gather(void* val_out, void* der_out, const void* his, const void
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > grid_cap()) blocks = grid_cap();
   hipStream_t st = static_cast<hipStream_t>(stream);
-  ProfScope prof(XDE_KID_DENSE, 0.0);
+  const double esz = dtype == XDE_F32 ? 4.0 : 8.0;
+  ProfScope prof(XDE_KID_DENSE, 5.0 * double(total) * esz);  // rows i, i+1, i+2 in; value and derivative out
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  if (D % width == 0 && L <= kHermiteMaxL && aligned16(val_out) && aligned16(der_out) && aligned16(his)) {
+    int64_t vblocks = (total / width + kBlock - 1) / kBlock;
+    if (vblocks > grid_cap()) vblocks = grid_cap();
+    dim3 gv(static_cast<unsigned>(vblocks)), bv(kBlock);
+    if (dtype == XDE_F32)
+      XDE_LAUNCH(xde_hermite_vec_kernel<float>, gv, bv, st, prof, static_cast<float*>(val_out), static_cast<float*>(der_out),
+                 static_cast<const float*>(his), static_cast<const float*>(his_t), static_cast<const float*>(lags), outer, T, D, L);
+    else
+      XDE_LAUNCH(xde_hermite_vec_kernel<double>, gv, bv, st, prof, static_cast<double*>(val_out), static_cast<double*>(der_out),
+                 static_cast<const double*>(his), static_cast<const double*>(his_t), static_cast<const double*>(lags), outer, T, D, L);
+    HIP_TRY(hipGetLastError());
+    return XDE_OK;
+  }
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
   if (dtype == XDE_F32)
     XDE_LAUNCH(xde_hermite_kernel<float>, g, b, st, prof, static_cast<float*>(val_out), static_cast<float*>(der_out),

@@ -23,9 +23,10 @@ def _history(shape, T, uniform, seed=0, dtype=np.float32):
 @pytest.mark.parametrize("lead", [(3,), (2, 5), ()])
 @pytest.mark.parametrize("uniform", [True, False])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_history_gather_vs_oracle(dev, lead, uniform, dtype):
+@pytest.mark.parametrize("D", [7, 8])  # 7: scalar kernel; 8: the 16-byte-vector kernel with the per-lag table in LDS
+def test_history_gather_vs_oracle(dev, lead, uniform, dtype, D):
     """xde_hermite_gather against the oracle's restatement of CubicHermiteSpline.evaluate / .derivative."""
-    T, D = 24, 7
+    T = 24
     his, t = _history(lead + (D,), T, uniform, dtype=dtype)
     lags = np.array([t[0] - 0.4, t[0], 0.5 * (t[0] + t[1]), t[5], t[5] + 1e-3, t[11] + 0.77 * (t[12] - t[11]), t[-2], t[-1], t[-1] + 0.9],
                     dtype=dtype)
