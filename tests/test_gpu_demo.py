@@ -17,3 +17,13 @@ def test_demo_loss_decreases(adjoint, solver):
     losses = ode_demo.train(max_steps=steps, adjoint=adjoint, solver=solver, log_every=0)
     head, tail = sum(losses[:10]) / 10, sum(losses[-10:]) / 10
     assert tail < 0.9 * head, (head, tail)
+
+
+def test_dde_demo_trains_weights_and_lags():
+    """examples/dde_demo.py (counterpart of the reference's example/dde_demo.py): ddeint(RK4) with learned delays."""
+    import dde_demo
+
+    losses, lag_grad = dde_demo.train(max_steps=70, log_every=0)
+    head, tail = sum(losses[:10]) / 10, sum(losses[-10:]) / 10
+    assert tail < 0.9 * head, (head, tail)
+    assert lag_grad > 0.0
