@@ -47,7 +47,7 @@ def _nz_plan(coefs, upto=None):
     """Operand indices with non-zero coefficient; index 0 (f0, the select-able operand) always first."""
     n = len(coefs) if upto is None else upto
     idx = [0] + [j for j in range(1, n) if float(coefs[j]) != 0.0]
-    return idx, [float(coefs[j]) for j in idx]
+    return idx, _hip.dbl_array([float(coefs[j]) for j in idx])  # marshalled once: the C double[] the kernels take
 
 
 class AdaptiveRKSolver(AdaptiveSolver):
@@ -144,7 +144,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._fsal and err_idx[-1] == S and set(err_idx[:-1]) <= set(last_idx) and float(tab.c_error[S]) != 0.0
         )
         if self._fuse_err:
-            self._err2_coef = [float(tab.c_error[j]) for j in last_idx]
+            self._err2_coef = _hip.dbl_array([float(tab.c_error[j]) for j in last_idx])
         # cache-policy hint per stage: bit p set = operand p of that stage's list is read there for the last time in an
         # accepted step (later readers: stages, the unfused error estimate; dense output is rare and lazy)
         last_use = {}
@@ -200,13 +200,14 @@ class AdaptiveRKSolver(AdaptiveSolver):
     # framework call
     # ------------------------------------------------------------------------------------------
     def _eval(self, t, y, live=()):
-        """``xde.move`` -> func(t, y); returns a kernel-ready tensor that aliases nothing we still need."""
+        """``xde.move`` -> func(t, y); returns a kernel-ready tensor that aliases nothing we still need (``live``: the
+        storage pointers of the tensors still in use)."""
         self.nfe += 1
         with torch.no_grad():  # the adaptive path is forward-only; gradients come from odeint_adjoint
             f = self.move(t, None, y)
         f = as_operand(f, like=y)
         sp = storage_ptr(f)
-        if sp == storage_ptr(y) or any(sp == storage_ptr(x) for x in live):
+        if sp == storage_ptr(y) or sp in live:
             f = f.clone()
         return f
 
@@ -284,6 +285,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._t_host = t_span
         self._t_span_dev = torch.from_numpy(t_span.astype(np.float64)).to(dev)
         self._t_stage = torch.zeros(_hip.XDE_MAX_STAGE, dtype=y0.dtype, device=dev)
+        self._t_views = [self._t_stage[i] for i in range(self._n_stage)]  # the 0-dim stage times handed to func
         self._ctrl = be.new_ctrl(dev)
         self._ws = be.new_workspace(dev)
         self._sums = be.new_sums(dev)
@@ -381,7 +383,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         ks = [f0]
         S = self._n_stage
         y_stage = None
-        keep = [y0, f0] + ([y0_alt, k0_alt] if alt is not None else [])
+        live = {storage_ptr(x) for x in ([y0, f0] + ([y0_alt, k0_alt] if alt is not None else []))}
         fuse = self._fuse_err and not self._custom_norm
         for i in range(S):
             idx, coef = self._stage_plan[i]
@@ -392,7 +394,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
             else:
                 be.stage_combine(out, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt,
                                  nt_mask=self._stage_nt[i] if fuse else 0)
-            ks.append(self._eval(self._t_stage[i], out, live=ks + keep))
+            ks.append(self._eval(self._t_views[i], out, live=live))
+            live.add(storage_ptr(ks[-1]))
             y_stage = out
         if self._fsal:
             y1 = y_stage
