@@ -1,14 +1,21 @@
 """Build libxde_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m paddlexde_amd.csrc.build
+    python -m paddlexde_amd.csrc.build [--force]
+
+One object per translation unit (compiled in parallel), then one link.  No relocatable device code is needed: device
+functions shared between kernels live in the ``*_device.hpp`` / ``xde_reduce.hpp`` headers.
 """
+import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SRC = os.path.join(HERE, "xde_hip.hip")
+SOURCES = sorted(glob.glob(os.path.join(HERE, "xde_*.hip")))
+HEADERS = sorted(glob.glob(os.path.join(HERE, "xde_*.hpp")))
+OBJ_DIR = os.path.join(HERE, "build")
 OUT_DIR = os.path.join(os.path.dirname(HERE), "lib")
 OUT = os.path.join(OUT_DIR, "libxde_hip.so")
 INCLUDE = os.path.join(ROOT, "include")
@@ -19,7 +26,6 @@ FLAGS = [
     "-std=c++17",
     "-ffp-contract=off",  # element-wise results follow the reference's unfused op order
     "-fPIC",
-    "-shared",
 ]
 
 
@@ -27,7 +33,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [SRC, os.path.join(INCLUDE, "xde_hip.h")]
+    deps = SOURCES + HEADERS + [os.path.join(INCLUDE, "xde_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -35,8 +41,20 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-o", OUT, SRC]
+
+    def compile_one(src):
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", HERE, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

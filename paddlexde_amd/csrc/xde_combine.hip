@@ -1,0 +1,425 @@
+// libxde_hip.so — hand-written gfx950 (MI355X / CDNA4) kernels for the Runge–Kutta hot path of
+// paddlexde_amd.  C ABI: include/xde_hip.h (each entry point cites the reference lines it replaces).
+//
+// All kernels are HBM-bandwidth bound (≈0.5 flop/byte): 16-byte-per-lane coalesced loads, grid-stride
+// loops sized to keep every CU's memory queue full (2048 workgroups × 256 threads = 8 waves/SIMD),
+// fp32 per-thread accumulation → wave64 __shfl_down → LDS cross-wave → one fp64 partial per workgroup,
+// reduced in a fixed order by a single workgroup (bit-reproducible, and identical on every rank after
+// the all-reduce).  No MFMA: there is no contraction on this path.
+//
+// Built with -ffp-contract=off so that element-wise results follow the reference's (unfused) op
+// order exactly; the kernels are memory bound, so FMA contraction would buy nothing.
+//
+// K1: stage combine (all fixed/adaptive stage formulas), its autograd fan-out, the predicated commit.
+
+#include "xde_common.hpp"
+
+using namespace xde;
+
+namespace {
+
+// `y = dy*dt + y0; (dy - lambda*y)*dt + y0` (xde/base_dde.py:55-58), same op order
+template <typename T>
+__device__ __forceinline__ T fuse_(T dy, T dt, T y0, T lam) {
+  if (lam == T(0)) return dy * dt + y0;
+  T y = dy * dt + y0;
+  return (dy - lam * y) * dt + y0;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: stage combine
+// ------------------------------------------------------------------------------------------
+template <typename T, int MODE, int NK, bool VEC, bool OUT2>
+__device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __restrict__ y0,
+                                             const T* __restrict__ k0, T dt) {
+  const unsigned ntm = unsigned(a.nt);  // bit j: stream operand k_j; bit 31: stream y0
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  T* __restrict__ out = static_cast<T*>(a.out);
+  T* __restrict__ out2 = static_cast<T*>(a.out2);
+  const T* kp[NK];
+  T c[NK];
+  T c2[NK];
+  kp[0] = k0;
+#pragma unroll
+  for (int j = 1; j < NK; ++j) kp[j] = static_cast<const T*>(a.k[j]);
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    // reference: tableau cast to the state dtype, then `beta_i * dt` (RK) — or used as is (FUSE/WFUSE)
+    c[j] = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+    c2[j] = OUT2 ? dt * T(a.coef2[j]) : T(0);  // `dt * tableau.c_error`
+  }
+  const T scale = T(a.scale);
+  const T lam = T(a.damp);
+  const int64_t nvec = a.n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    // NT: with operands of >= 64 MiB nothing survives in the 256 MiB Infinity Cache between uses anyway; streaming
+    // loads then run 12-17 % faster (5.1 -> 5.8 TB/s at 128 MiB x 7 streams).  At the 32 MiB headline size the
+    // default policy wins by 18 % (the working set half-fits the cache), so the flag is size-dependent (host).
+    P y = load_sel<P>(y0, i, (ntm >> 31) & 1u);
+    P kk[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) kk[j] = load_sel<P>(kp[j], i, (ntm >> j) & 1u);
+    P o;
+    P o2;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      if (MODE == XDE_COMBINE_RK) {
+        T acc = kk[0].v[w] * c[0];
+#pragma unroll
+        for (int j = 1; j < NK; ++j) acc = acc + kk[j].v[w] * c[j];
+        o.v[w] = y.v[w] + acc;
+        if (OUT2) {
+          T e = kk[0].v[w] * c2[0];
+#pragma unroll
+          for (int j = 1; j < NK; ++j) e = e + kk[j].v[w] * c2[j];
+          o2.v[w] = e;
+        }
+      } else if (MODE == XDE_COMBINE_FUSE) {
+        T acc = kk[0].v[w] * c[0];
+#pragma unroll
+        for (int j = 1; j < NK; ++j) acc = acc + kk[j].v[w] * c[j];
+        o.v[w] = fuse_(acc, dt, y.v[w], lam);
+      } else {
+        T acc = fuse_(kk[0].v[w], dt, y.v[w], lam) * c[0];
+#pragma unroll
+        for (int j = 1; j < NK; ++j) acc = acc + fuse_(kk[j].v[w], dt, y.v[w], lam) * c[j];
+        o.v[w] = acc * scale;
+      }
+    }
+    o.store(out, i);
+    if (OUT2) o2.store(out2, i);
+  }
+  if (VEC) {
+    // scalar tail (n % W elements), done by the first threads of block 0
+    const int64_t tail0 = nvec * W;
+    const int64_t i = tail0 + threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n) {
+      T yv = y0[i];
+      T acc;
+      if (OUT2) {
+        T e = kp[0][i] * c2[0];
+        for (int j = 1; j < NK; ++j) e = e + kp[j][i] * c2[j];
+        out2[i] = e;
+      }
+      if (MODE == XDE_COMBINE_WFUSE) {
+        acc = fuse_(kp[0][i], dt, yv, lam) * c[0];
+        for (int j = 1; j < NK; ++j) acc = acc + fuse_(kp[j][i], dt, yv, lam) * c[j];
+        out[i] = acc * scale;
+      } else {
+        acc = kp[0][i] * c[0];
+        for (int j = 1; j < NK; ++j) acc = acc + kp[j][i] * c[j];
+        out[i] = (MODE == XDE_COMBINE_RK) ? (yv + acc) : fuse_(acc, dt, yv, lam);
+      }
+    }
+  }
+}
+
+// generic operand count (> 8: Dopri8) — runtime loop, same arithmetic order
+template <typename T, int MODE, bool VEC, bool OUT2>
+__device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  T* __restrict__ out = static_cast<T*>(a.out);
+  const int nk = a.nk;
+  const T scale = T(a.scale);
+  const T lam = T(a.damp);
+  const int64_t nvec = a.n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P y = P::load(y0, i);
+    P acc;
+    P e2;
+    constexpr bool has2 = OUT2;
+    for (int j = 0; j < nk; ++j) {
+      const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+      P kk = P::load(kj, i);
+      T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+      T c2j = has2 ? dt * T(a.coef2[j]) : T(0);
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        T term = (MODE == XDE_COMBINE_WFUSE) ? fuse_(kk.v[w], dt, y.v[w], lam) * cj : kk.v[w] * cj;
+        acc.v[w] = (j == 0) ? term : acc.v[w] + term;
+        if (has2) e2.v[w] = (j == 0) ? kk.v[w] * c2j : e2.v[w] + kk.v[w] * c2j;
+      }
+    }
+    if (has2) e2.store(static_cast<T*>(a.out2), i);
+    P o;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      o.v[w] = (MODE == XDE_COMBINE_RK) ? y.v[w] + acc.v[w]
+               : (MODE == XDE_COMBINE_FUSE) ? fuse_(acc.v[w], dt, y.v[w], lam)
+                                            : acc.v[w] * scale;
+    }
+    o.store(out, i);
+  }
+  if (VEC) {
+    const int64_t i = nvec * W + threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n) {
+      T yv = y0[i];
+      T acc = T(0);
+      T e2 = T(0);
+      constexpr bool has2 = OUT2;
+      for (int j = 0; j < nk; ++j) {
+        const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+        T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+        T term = (MODE == XDE_COMBINE_WFUSE) ? fuse_(kj[i], dt, yv, lam) * cj : kj[i] * cj;
+        acc = (j == 0) ? term : acc + term;
+        if (has2) e2 = (j == 0) ? kj[i] * (dt * T(a.coef2[j])) : e2 + kj[i] * (dt * T(a.coef2[j]));
+      }
+      if (has2) static_cast<T*>(a.out2)[i] = e2;
+      out[i] = (MODE == XDE_COMBINE_RK) ? yv + acc : (MODE == XDE_COMBINE_FUSE) ? fuse_(acc, dt, yv, lam) : acc * scale;
+    }
+  }
+}
+
+// OUT2 (second output, RK mode only) is a separate instantiation: its two accumulators per element would
+// otherwise raise the register budget of EVERY stage launch (62 -> 112 VGPRs, occupancy 8 -> 4 waves/SIMD)
+template <typename T, int MODE, bool VEC, bool OUT2>
+__global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
+  int sel = 0;
+  T dt;
+  if (a.ctrl) {
+    dt = T(a.ctrl->dt);
+    if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+  } else {
+    dt = T(a.dt_host);
+  }
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  switch (a.nk) {
+    case 1: combine_body<T, MODE, 1, VEC, OUT2>(a, y0, k0, dt); break;
+    case 2: combine_body<T, MODE, 2, VEC, OUT2>(a, y0, k0, dt); break;
+    case 3: combine_body<T, MODE, 3, VEC, OUT2>(a, y0, k0, dt); break;
+    case 4: combine_body<T, MODE, 4, VEC, OUT2>(a, y0, k0, dt); break;
+    case 5: combine_body<T, MODE, 5, VEC, OUT2>(a, y0, k0, dt); break;
+    case 6: combine_body<T, MODE, 6, VEC, OUT2>(a, y0, k0, dt); break;
+    case 7: combine_body<T, MODE, 7, VEC, OUT2>(a, y0, k0, dt); break;
+    default: combine_generic<T, MODE, VEC, OUT2>(a, y0, k0, dt); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fan-out: outs[j] = g * factor_j  (backward of the combine)
+// ------------------------------------------------------------------------------------------
+struct FanoutArgs {
+  void* outs[XDE_MAX_K + 1];
+  double factor[XDE_MAX_K + 1];
+  const void* g;
+  const double* dt_dev;
+  int64_t n;
+  int nout;
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_fanout_kernel(FanoutArgs a) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const T* __restrict__ g = static_cast<const T*>(a.g);
+  const T dt = a.dt_dev ? T(*a.dt_dev) : T(1);
+  const int nout = a.nout;
+  const int64_t nvec = a.n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P gv = P::load(g, i);
+    for (int j = 0; j < nout; ++j) {
+      const T f = T(a.factor[j]) * dt;
+      P o;
+#pragma unroll
+      for (int w = 0; w < W; ++w) o.v[w] = gv.v[w] * f;
+      o.store(static_cast<T*>(a.outs[j]), i);
+    }
+  }
+  if (VEC) {
+    const int64_t i = nvec * W + threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n)
+      for (int j = 0; j < nout; ++j) static_cast<T*>(a.outs[j])[i] = g[i] * (T(a.factor[j]) * dt);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// predicated commit (hipGraph pipeline): (y0, f0) <- (y1, f1) when the step was accepted
+// ------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_commit_kernel(const xde_ctrl_t* c, T* __restrict__ y0, const T* __restrict__ y1,
+                                                            T* __restrict__ f0, const T* __restrict__ f1, int64_t n) {
+  if (!c->accept) return;
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const int64_t nvec = n / W;
+  const int64_t stride = int64_t(gridDim.x) * kBlock;
+  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P a = P::load(y1, i);
+    P b = P::load(f1, i);
+    a.store(y0, i);
+    b.store(f0, i);
+  }
+  if (VEC) {
+    const int64_t i = nvec * W + threadIdx.x;
+    if (blockIdx.x == 0 && i < n) {
+      y0[i] = y1[i];
+      f0[i] = f1[i];
+    }
+  }
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
+                      const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
+                      int64_t n, int dtype, void* out2, const double* coef2, double damping, uint32_t nt_mask, void* stream) {
+  if (!out || !y0 || !k || !coef) return fail(XDE_EBADARG, "xde_stage_combine: null pointer");
+  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_stage_combine: nk out of range");
+  if (n < 0) return fail(XDE_EBADARG, "xde_stage_combine: negative n");
+  if (mode < 0 || mode > 2) return fail(XDE_EBADARG, "xde_stage_combine: bad mode");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_stage_combine: bad dtype");
+  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: y0_alt/k0_alt must come together");
+  if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_stage_combine: operand select needs ctrl");
+  if ((out2 == nullptr) != (coef2 == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: out2/coef2 must come together");
+  if (out2 && mode != XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: second output needs mode RK");
+  if (n == 0) return XDE_OK;
+  CombineArgs a;
+  memset(&a, 0, sizeof(a));
+  a.out = out;
+  a.out2 = out2;
+  a.y0[0] = y0;
+  a.y0[1] = y0_alt ? y0_alt : y0;
+  a.k0_alt = k0_alt ? k0_alt : k[0];
+  a.use_sel = y0_alt ? 1 : 0;
+  bool vec = aligned16(out) && aligned16(y0) && aligned16(a.y0[1]) && aligned16(a.k0_alt);
+  for (int j = 0; j < nk; ++j) {
+    if (!k[j]) return fail(XDE_EBADARG, "xde_stage_combine: null k[j]");
+    a.k[j] = k[j];
+    a.coef[j] = coef[j];
+    if (coef2) a.coef2[j] = coef2[j];
+    vec = vec && aligned16(k[j]);
+  }
+  if (out2) vec = vec && aligned16(out2);
+  if (damping != 0.0 && mode == XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: damping applies to FUSE/WFUSE");
+  a.damp = damping;
+  // operands far larger than the Infinity Cache: stream everything; otherwise only what the caller marks as last use
+  a.nt = big_operand(n, dtype) ? int(0xFFFFFFFFu) : ((nt_policy() & 4) ? int(nt_mask) : 0);
+  a.scale = scale;
+  a.dt_host = dt_host;
+  a.ctrl = ctrl;
+  a.n = n;
+  a.nk = nk;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const int64_t work = vec ? (n + width - 1) / width : n;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double elt = dtype == XDE_F32 ? 4.0 : 8.0;
+  ProfScope prof(XDE_KID_COMBINE, double(nk + 2 + (out2 ? 1 : 0)) * double(n) * elt);
+  dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+#define LAUNCH_COMBINE(T, MODE)                                                     \
+  do {                                                                              \
+    if (vec)                                                                        \
+      XDE_LAUNCH((xde_combine_kernel<T, MODE, true, false>), g, b, st, prof, a);    \
+    else                                                                            \
+      XDE_LAUNCH((xde_combine_kernel<T, MODE, false, false>), g, b, st, prof, a);   \
+  } while (0)
+#define LAUNCH_COMBINE2(T)                                                                   \
+  do {                                                                                       \
+    if (vec)                                                                                 \
+      XDE_LAUNCH((xde_combine_kernel<T, XDE_COMBINE_RK, true, true>), g, b, st, prof, a);    \
+    else                                                                                     \
+      XDE_LAUNCH((xde_combine_kernel<T, XDE_COMBINE_RK, false, true>), g, b, st, prof, a);   \
+  } while (0)
+  if (out2) {
+    if (dtype == XDE_F32) LAUNCH_COMBINE2(float);
+    else LAUNCH_COMBINE2(double);
+  } else if (dtype == XDE_F32) {
+    if (mode == XDE_COMBINE_RK) LAUNCH_COMBINE(float, XDE_COMBINE_RK);
+    else if (mode == XDE_COMBINE_FUSE) LAUNCH_COMBINE(float, XDE_COMBINE_FUSE);
+    else LAUNCH_COMBINE(float, XDE_COMBINE_WFUSE);
+  } else {
+    if (mode == XDE_COMBINE_RK) LAUNCH_COMBINE(double, XDE_COMBINE_RK);
+    else if (mode == XDE_COMBINE_FUSE) LAUNCH_COMBINE(double, XDE_COMBINE_FUSE);
+    else LAUNCH_COMBINE(double, XDE_COMBINE_WFUSE);
+  }
+#undef LAUNCH_COMBINE
+#undef LAUNCH_COMBINE2
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_scale_fanout(void* const* outs, const void* g, const double* factors, int nout, const double* dt_dev, int64_t n,
+                     int dtype, void* stream) {
+  if (!outs || !g || !factors) return fail(XDE_EBADARG, "xde_scale_fanout: null pointer");
+  if (nout < 1 || nout > XDE_MAX_K + 1) return fail(XDE_EBADARG, "xde_scale_fanout: nout out of range");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_scale_fanout: bad dtype");
+  if (n < 0) return fail(XDE_EBADARG, "xde_scale_fanout: negative n");
+  if (n == 0) return XDE_OK;
+  FanoutArgs a;
+  memset(&a, 0, sizeof(a));
+  bool vec = aligned16(g);
+  for (int j = 0; j < nout; ++j) {
+    if (!outs[j]) return fail(XDE_EBADARG, "xde_scale_fanout: null outs[j]");
+    a.outs[j] = outs[j];
+    a.factor[j] = factors[j];
+    vec = vec && aligned16(outs[j]);
+  }
+  a.g = g;
+  a.dt_dev = dt_dev;
+  a.n = n;
+  a.nout = nout;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const int64_t work = vec ? (n + width - 1) / width : n;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_COMBINE, double(nout + 1) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 gr(static_cast<unsigned>(blocks)), b(kBlock);
+  if (dtype == XDE_F32) {
+    if (vec) XDE_LAUNCH((xde_fanout_kernel<float, true>), gr, b, st, prof, a);
+    else XDE_LAUNCH((xde_fanout_kernel<float, false>), gr, b, st, prof, a);
+  } else {
+    if (vec) XDE_LAUNCH((xde_fanout_kernel<double, true>), gr, b, st, prof, a);
+    else XDE_LAUNCH((xde_fanout_kernel<double, false>), gr, b, st, prof, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_commit(const xde_ctrl_t* ctrl, void* y0_dst, const void* y1_src, void* f0_dst, const void* f1_src, int64_t n,
+               int dtype, void* stream) {
+  if (!ctrl || !y0_dst || !y1_src || !f0_dst || !f1_src) return fail(XDE_EBADARG, "xde_commit: null pointer");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_commit: bad dtype");
+  if (n < 0) return fail(XDE_EBADARG, "xde_commit: negative n");
+  if (n == 0) return XDE_OK;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const bool vec = aligned16(y0_dst) && aligned16(y1_src) && aligned16(f0_dst) && aligned16(f1_src);
+  const int64_t work = vec ? (n + width - 1) / width : n;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > grid_cap()) blocks = grid_cap();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_COMMIT, 4.0 * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+  if (dtype == XDE_F32) {
+    if (vec)
+      XDE_LAUNCH((xde_commit_kernel<float, true>), g, b, st, prof, ctrl, static_cast<float*>(y0_dst),
+                 static_cast<const float*>(y1_src), static_cast<float*>(f0_dst), static_cast<const float*>(f1_src), n);
+    else
+      XDE_LAUNCH((xde_commit_kernel<float, false>), g, b, st, prof, ctrl, static_cast<float*>(y0_dst),
+                 static_cast<const float*>(y1_src), static_cast<float*>(f0_dst), static_cast<const float*>(f1_src), n);
+  } else {
+    if (vec)
+      XDE_LAUNCH((xde_commit_kernel<double, true>), g, b, st, prof, ctrl, static_cast<double*>(y0_dst),
+                 static_cast<const double*>(y1_src), static_cast<double*>(f0_dst), static_cast<const double*>(f1_src), n);
+    else
+      XDE_LAUNCH((xde_commit_kernel<double, false>), g, b, st, prof, ctrl, static_cast<double*>(y0_dst),
+                 static_cast<const double*>(y1_src), static_cast<double*>(f0_dst), static_cast<const double*>(f1_src), n);
+  }
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// libxde_hip.so — hand-written gfx950 (MI355X / CDNA4) kernels for the Runge–Kutta hot path of
+// paddlexde_amd.  C ABI: include/xde_hip.h (each entry point cites the reference lines it replaces).
+//
+// All kernels are HBM-bandwidth bound (≈0.5 flop/byte): 16-byte-per-lane coalesced loads, grid-stride
+// loops sized to keep every CU's memory queue full (2048 workgroups × 256 threads = 8 waves/SIMD),
+// fp32 per-thread accumulation → wave64 __shfl_down → LDS cross-wave → one fp64 partial per workgroup,
+// reduced in a fixed order by a single workgroup (bit-reproducible, and identical on every rank after
+// the all-reduce).  No MFMA: there is no contraction on this path.
+//
+// Built with -ffp-contract=off so that element-wise results follow the reference's (unfused) op
+// order exactly; the kernels are memory bound, so FMA contraction would buy nothing.
+//
+// K3: the device-resident step controller, control-block init, initial-step scalars, host mirror.
+
+#include "xde_common.hpp"
+#include "xde_reduce.hpp"
+#include "xde_errnorm_device.hpp"
+#include "xde_control_device.hpp"
+
+using namespace xde;
+
+namespace {
+
+__global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const NormSlot* slot,
+                                                             const double* sums, const double* t_span,
+                                                             const double* step_t, void* t_stage_out,
+                                                             xde_ctrl_t* mirror) {
+  control_block<false>(c, p, slot, sums, t_span, step_t, t_stage_out, mirror, 0, 0);
+}
+
+// Controller arguments of the fused launch
+struct CtrlTail {
+  xde_ctrl_t* ctrl;
+  xde_ctrl_params_t p;
+  const double* t_span;
+  const double* step_t;
+  void* t_stage_out;
+  xde_ctrl_t* mirror;
+};
+
+// K2+K3 fused: every workgroup does the error-norm pass and publishes its partial; the workgroup whose ticket is the
+// last one acquires (agent scope), reduces all partials in the same fixed order as the standalone controller, runs
+// the controller and resets the ticket.  Nobody waits for anybody: no spin, no residency requirement.
+template <typename T, int NORM, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, CtrlTail tl) {
+  int sel = 0;
+  const T dt = T(a.ctrl->dt);
+  if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  const int seg = find_segment(a.map, blockIdx.x);
+  const int lb = blockIdx.x - a.map.seg_blk[seg];
+  const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
+  T acc = T(0);
+  int nf = 0;
+  errnorm_dispatch<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf);
+  const bool last = block_reduce_store<NORM, true>(double(acc), double(nf), a.slot, seg);
+  if (!last) return;
+  // ---- last arriver: every other workgroup's partial is in L2/memory (sc1 stores, drained before its ticket) ----
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  control_block<true>(tl.ctrl, tl.p, a.slot, nullptr, tl.t_span, tl.step_t, tl.t_stage_out, tl.mirror, int(gridDim.x), NORM);
+  // every workgroup has arrived: re-arm the ticket words for the next launch
+  if (threadIdx.x < kTicketShards)
+    __hip_atomic_store(&a.slot->shard[threadIdx.x].count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(&a.slot->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
+                                     int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
+                                     int64_t seq0, const double* first_step_dev) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  xde_ctrl_t z;
+  memset(&z, 0, sizeof(z));
+  z.t0 = t_start;
+  z.t1 = t_start;
+  // device-resident first step (xde_initial_step): a magnitude, given the direction's sign here
+  z.dt = first_step_dev ? double(p.direction) * fabs(*first_step_dev) : first_step;
+  z.n_out = n_out;
+  z.ratio_prev = 1e-4;
+  // rows whose time equals the start time are y0 itself (the reference's `while next_t > t1` does not
+  // step for them); the host fills them.
+  const double dir = double(p.direction);
+  int e = 1;
+  while (e < n_out && dir * t_span[e] <= dir * t_start) ++e;
+  z.next_out = e;
+  z.out_begin = e;
+  z.out_end = e;
+  z.done = (e >= n_out) ? 1 : 0;
+  // next_step_index = min(bisect(step_t, t0), len-1)                 base_adaptive_solver_rk.py:109-111
+  int idx = 0;
+  if (p.n_step_t > 0 && step_t) {
+    while (idx < p.n_step_t && dir * step_t[idx] <= dir * t_start) ++idx;
+    if (idx > p.n_step_t - 1) idx = p.n_step_t - 1;
+  }
+  z.next_step_index = idx;
+  z.seq = seq0;
+  if (p.time_dtype == XDE_F32)
+    plan_next<float>(&z, p, step_t, t_stage_out);
+  else
+    plan_next<double>(&z, p, step_t, t_stage_out);
+  *c = z;
+}
+
+// Hairer's initial-step heuristic, scalar part (solver/base_adaptive_solver.py:55-72), in the state dtype Y with the
+// reference's op order.  phase 0: (d0, d1) -> h0, written to ctrl->dt (the Euler probe y0 + h0*f0 is a combine that
+// reads dt from ctrl) and t0 + h0 for func.  phase 1: d2 = |norm((f1-f0)/scale) / h0| -> h1 -> min(100*h0, h1).
+template <typename Y>
+__device__ void initial_step_phase(int phase, const double* res, double* hs, const xde_ctrl_params_t& p, double t_start,
+                                   void* t_probe_out, int probe_dtype, xde_ctrl_t* c) {
+  if (phase == 0) {
+    const Y d0 = Y(fabs(res[0])), d1 = Y(fabs(res[1]));
+    Y h0;
+    if (d0 < Y(1e-5) || d1 < Y(1e-5))
+      h0 = Y(1e-6);
+    else
+      h0 = Y(0.01) * d0 / d1;
+    h0 = h0 < Y(0) ? -h0 : h0;
+    hs[0] = double(d0);
+    hs[1] = double(d1);
+    hs[2] = double(h0);
+    c->dt = double(h0);
+    // t0 + h0: time dtype + state dtype -> the promoted dtype
+    if (probe_dtype == XDE_F32)
+      *static_cast<float*>(t_probe_out) = float(t_start) + float(h0);
+    else
+      *static_cast<double*>(t_probe_out) = (p.time_dtype == XDE_F32 ? double(float(t_start)) : t_start) + double(h0);
+  } else {
+    const Y h0 = Y(hs[2]), d1 = Y(hs[1]);
+    Y d2 = Y(res[0]) / h0;
+    d2 = d2 < Y(0) ? -d2 : d2;
+    Y h1;
+    if (d1 <= Y(1e-15) && d2 <= Y(1e-15)) {
+      const Y a = Y(1e-6), b = h0 * Y(1e-3);
+      h1 = (b > a) ? b : a;  // Python's max(a, b)
+    } else {
+      // Python's max(d1, d2): returns d1 unless d2 > d1 (a NaN d2 is ignored, a NaN d1 is kept)
+      const Y m = (d2 > d1) ? d2 : d1;
+      const Y e = Y(1.0 / (p.order - 1.0 + 1.0));  // called with order - 1: exponent 1 / (order - 1 + 1)
+      h1 = Y(pow_<Y>(Y(0.01) / m, e));
+    }
+    h1 = h1 < Y(0) ? -h1 : h1;
+    const Y a = Y(100.0) * h0;
+    const Y first = fmin__<Y>(a, h1);
+    hs[3] = p.time_dtype == XDE_F32 ? double(float(first)) : double(first);
+  }
+}
+
+__global__ void xde_initial_step_kernel(int phase, const double* res, double* hs, xde_ctrl_params_t p, double t_start,
+                                        void* t_probe_out, int probe_dtype, xde_ctrl_t* c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (p.state_dtype == XDE_F32)
+    initial_step_phase<float>(phase, res, hs, p, t_start, t_probe_out, probe_dtype, c);
+  else
+    initial_step_phase<double>(phase, res, hs, p, t_start, t_probe_out, probe_dtype, c);
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int xde_error_norm_control(const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
+                           const void* y0_alt, const void* y1, const xde_segments_t* segs, int dtype, void* ws,
+                           const void* e_pre, xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const double* t_span_dev,
+                           const double* step_t_dev, void* t_stage_out, xde_ctrl_t* host_mirror, void* stream) {
+  if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_error_norm_control: null pointer");
+  int rc = check_params(params, "xde_error_norm_control");
+  if (rc != XDE_OK) return rc;
+  if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_error_norm_control: n_step_t > 0 without step_t_dev");
+  if (!segs || segs->n_seg != params->n_seg) return fail(XDE_EBADARG, "xde_error_norm_control: segments do not match params->n_seg");
+  ErrArgs a;
+  bool vec = false;
+  int nblocks = 0;
+  double bytes = 0;
+  rc = setup_err_args("xde_error_norm_control", k, k0_alt, c_err, nk, y0, y0_alt, y1, params->rtol, params->atol, 0.0, ctrl, segs,
+                      params->norm_kind, dtype, ws, e_pre, &a, &vec, &nblocks, &bytes, fused_grid_cap());
+  if (rc != XDE_OK) return rc;
+  CtrlTail tl;
+  tl.ctrl = ctrl;
+  tl.p = *params;
+  tl.t_span = t_span_dev;
+  tl.step_t = step_t_dev;
+  tl.t_stage_out = t_stage_out;
+  tl.mirror = host_mirror;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_ERRNORM, bytes);
+  dim3 g(nblocks), b(kBlock);
+#define LAUNCH_EC(T, NORM)                                                                 \
+  do {                                                                                     \
+    if (vec)                                                                               \
+      XDE_LAUNCH((xde_errnorm_control_kernel<T, NORM, true>), g, b, st, prof, a, tl);      \
+    else                                                                                   \
+      XDE_LAUNCH((xde_errnorm_control_kernel<T, NORM, false>), g, b, st, prof, a, tl);     \
+  } while (0)
+  if (dtype == XDE_F32) {
+    if (params->norm_kind == XDE_NORM_RMS) LAUNCH_EC(float, XDE_NORM_RMS);
+    else LAUNCH_EC(float, XDE_NORM_LINF);
+  } else {
+    if (params->norm_kind == XDE_NORM_RMS) LAUNCH_EC(double, XDE_NORM_RMS);
+    else LAUNCH_EC(double, XDE_NORM_LINF);
+  }
+#undef LAUNCH_EC
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void* ws, const double* sums,
+                   const double* t_span_dev, const double* step_t_dev, void* t_stage_out, xde_ctrl_t* host_mirror,
+                   void* stream) {
+  if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_rk_control: null pointer");
+  if (!ws && !sums) return fail(XDE_EBADARG, "xde_rk_control: need ws or sums");
+  int rc = check_params(params, "xde_rk_control");
+  if (rc != XDE_OK) return rc;
+  if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_rk_control: n_step_t > 0 without step_t_dev");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_CONTROL, 0.0);
+  XDE_LAUNCH(xde_control_kernel, dim3(1), dim3(kBlock), st, prof, ctrl, *params, ws ? slot_ptr(ws, 0) : nullptr, sums,
+             t_span_dev, step_t_dev, t_stage_out, host_mirror);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_start, double first_step, int32_t n_out,
+                  const double* t_span_dev, const double* step_t_dev, void* t_stage_out, int64_t seq0,
+                  const double* first_step_dev, void* stream) {
+  if (!ctrl || !t_span_dev || !t_stage_out) return fail(XDE_EBADARG, "xde_ctrl_init: null pointer");
+  int rc = check_params(params, "xde_ctrl_init");
+  if (rc != XDE_OK) return rc;
+  if (n_out < 1) return fail(XDE_EBADARG, "xde_ctrl_init: n_out must be >= 1");
+  if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_ctrl_init: n_step_t > 0 without step_t_dev");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(xde_ctrl_init_kernel, dim3(1), dim3(64), 0, st, ctrl, *params, t_start, first_step, n_out,
+                     t_span_dev, step_t_dev, t_stage_out, seq0, first_step_dev);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde_ctrl_params_t* params, double t_start,
+                     void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl, void* stream) {
+  if (!res_dev || !hs_dev || !ctrl) return fail(XDE_EBADARG, "xde_initial_step: null pointer");
+  if (phase != 0 && phase != 1) return fail(XDE_EBADARG, "xde_initial_step: phase must be 0 or 1");
+  if (phase == 0 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step: phase 0 needs t_probe_out");
+  if (probe_dtype != XDE_F32 && probe_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step: bad probe dtype");
+  int rc = check_params(params, "xde_initial_step");
+  if (rc != XDE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(xde_initial_step_kernel, dim3(1), dim3(64), 0, st, phase, res_dev, hs_dev, *params, t_start, t_probe_out,
+                     probe_dtype, ctrl);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream) {
+  if (!ctrl_dev || !host_out) return fail(XDE_EBADARG, "xde_ctrl_read: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(host_out, ctrl_dev, sizeof(xde_ctrl_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return XDE_OK;
+}
+
+int xde_host_alloc(int64_t bytes, void** ptr_out) {
+  if (bytes <= 0 || !ptr_out) return fail(XDE_EBADARG, "xde_host_alloc: bad argument");
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, size_t(bytes), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(p, 0, size_t(bytes));
+  *ptr_out = p;
+  return XDE_OK;
+}
+
+int xde_host_free(void* ptr) {
+  if (!ptr) return XDE_OK;
+  HIP_TRY(hipHostFree(ptr));
+  return XDE_OK;
+}
+
+int xde_ctrl_wait(const xde_ctrl_t* host_mirror, int64_t seq, double timeout_ms, xde_ctrl_t* host_out) {
+  if (!host_mirror || !host_out || seq < 0) return fail(XDE_EBADARG, "xde_ctrl_wait: bad argument");
+  const xde_ctrl_t* slot = host_mirror + (seq % XDE_MIRROR_SLOTS);
+  const auto t_begin = std::chrono::steady_clock::now();
+  uint64_t spins = 0;
+  bool slow = false;
+  for (;;) {
+    int64_t cur = __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE);
+    if (cur == seq) break;
+    if (cur > seq) return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot already overwritten by a later launch");
+    if (slow || (++spins & 0x3ff) == 0) {
+      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+      if (ms > timeout_ms) return fail(XDE_ETIMEOUT, "xde_ctrl_wait: timed out waiting for the controller launch");
+      slow = ms > 5.0;  // a long func evaluation is in flight: stop burning the core, poll every ~50 us
+    }
+    if (slow) {
+      struct timespec ts = {0, 50000};
+      nanosleep(&ts, nullptr);
+      continue;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  memcpy(host_out, slot, sizeof(xde_ctrl_t));
+  // the slot may have been overwritten while copying (only if the host lags >= SLOTS launches behind)
+  if (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != seq)
+    return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot overwritten while reading");
+  return XDE_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+// Device body of the step controller (accept/reject, optimal step size, stage times, output bookkeeping, mirror
+// publish), shared by xde_control_kernel and the opt-in one-launch error-norm + controller kernel.
+#pragma once
+#include "xde_common.hpp"
+#include "xde_reduce.hpp"
+
+namespace xde {
+
+// ------------------------------------------------------------------------------------------
+// K3: controller
+// ------------------------------------------------------------------------------------------
+template <typename TT> __device__ inline TT pow_(TT a, TT b);
+template <> __device__ inline float pow_<float>(float a, float b) { return powf(a, b); }
+template <> __device__ inline double pow_<double>(double a, double b) { return pow(a, b); }
+template <typename TT> __device__ inline TT fmin__(TT a, TT b);
+template <> __device__ inline float fmin__<float>(float a, float b) { return fminf(a, b); }
+template <> __device__ inline double fmin__<double>(double a, double b) { return fmin(a, b); }
+template <typename TT> __device__ inline TT fmax__(TT a, TT b);
+template <> __device__ inline float fmax__<float>(float a, float b) { return fmaxf(a, b); }
+template <> __device__ inline double fmax__<double>(double a, double b) { return fmax(a, b); }
+
+// Plan the pending attempt: step_t clipping (base_adaptive_solver_rk.py:209-215), the underflow and
+// max_num_steps assertions (:200, :120-122) and the stage times of _runge_kutta_step (:159-164).
+template <typename TT>
+__device__ void plan_next(xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* step_t, void* t_stage_out) {
+  const TT dir = TT(p.direction);
+  TT t0 = TT(c->t1);
+  TT dt = TT(c->dt);
+  TT t1 = t0 + dt;
+  int on = 0;
+  if (p.n_step_t > 0 && step_t) {
+    TT nxt = TT(step_t[c->next_step_index]);
+    if (dir * t0 < dir * nxt && dir * nxt < dir * (t0 + dt)) {
+      on = 1;
+      t1 = nxt;
+      dt = t1 - t0;
+    }
+  }
+  c->on_step_t = on;
+  c->dt = double(dt);
+  c->t_plan = double(t1);
+  if (!c->done) {
+    if (!(dir * (t0 + dt) > dir * t0) && c->status == XDE_STATUS_OK) c->status = XDE_STATUS_DT_UNDERFLOW;
+    if (c->steps_in_interval >= p.max_num_steps && c->status == XDE_STATUS_OK) c->status = XDE_STATUS_MAX_STEPS;
+  }
+  // stage times in the state dtype: `t0.astype(t_dtype)`, `ti = t1 if alpha_i == 1 else t0 + alpha_i * dt`
+  for (int i = 0; i < p.n_stage; ++i) {
+    if (p.state_dtype == XDE_F32) {
+      float a = float(p.alpha[i]);
+      float ti = (a == 1.0f) ? float(t1) : float(t0) + a * float(dt);
+      static_cast<float*>(t_stage_out)[i] = ti;
+    } else {
+      double a = p.alpha[i];
+      double ti = (a == 1.0) ? double(t1) : double(t0) + a * double(dt);
+      static_cast<double*>(t_stage_out)[i] = ti;
+    }
+  }
+}
+
+template <typename TT>
+__device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double ratio_d, double nonfinite,
+                             const double* t_span, const double* step_t, void* t_stage_out) {
+  const TT dir = TT(p.direction);
+  const TT t0 = TT(c->t1);
+  const TT dt = TT(c->dt);
+  const TT t1 = TT(c->t_plan);
+  const TT min_step = TT(p.min_step), max_step = TT(p.max_step);
+
+  if (nonfinite > 0.0 && c->status == XDE_STATUS_OK) c->status = XDE_STATUS_NONFINITE;
+
+  // accept / reject                                         base_adaptive_solver_rk.py:244-250
+  int accept = (ratio_d <= 1.0) ? 1 : 0;  // NaN -> reject
+  if (dir * dt > max_step) accept = 0;
+  if (dir * dt <= min_step) accept = 1;
+
+  // optimal_step_size                                                  utils/ode_utils.py:85-97
+  TT dt_next;
+  if (ratio_d == 0.0) {
+    dt_next = dt * TT(p.ifactor);
+  } else {
+    TT dfactor = TT(p.dfactor);
+    if (ratio_d < 1.0) dfactor = TT(1);
+    TT ratio = TT(ratio_d);
+    TT factor;
+    if (p.pi_controller) {
+      // opt-in PI controller (Hairer's dopri5 form); never used for parity
+      TT beta = TT(p.pi_beta);
+      TT alpha = TT(1) / TT(p.order) - TT(0.75) * beta;
+      TT prev = TT(c->ratio_prev > 1e-4 ? c->ratio_prev : 1e-4);
+      factor = fmin__<TT>(TT(p.ifactor), fmax__<TT>(TT(p.safety) * pow_<TT>(prev, beta) / pow_<TT>(ratio, alpha), dfactor));
+    } else {
+      TT exponent = TT(1) / TT(p.order);
+      factor = fmin__<TT>(TT(p.ifactor), fmax__<TT>(TT(p.safety) / pow_<TT>(ratio, exponent), dfactor));
+    }
+    dt_next = dt * factor;
+  }
+  // dt_next.clip(min_step, max_step) on the magnitude (direction-aware)
+  {
+    TT mag = dir * dt_next;
+    if (mag < min_step) mag = min_step;
+    if (mag > max_step) mag = max_step;
+    dt_next = (mag != mag) ? dt_next : dir * mag;
+  }
+
+  c->n_steps += 1;
+  c->steps_in_interval += 1;
+  if (accept) {
+    c->n_accept += 1;
+    if (ratio_d == ratio_d) c->ratio_prev = ratio_d;
+  } else {
+    c->n_reject += 1;
+  }
+  c->sel_used = c->accept;
+  c->accept = accept;
+  c->ratio = ratio_d;
+  c->nonfinite = nonfinite;
+  c->t0 = double(t0);
+  c->t1 = accept ? double(t1) : double(t0);
+  c->dt_last = double(dt);
+  c->dt = double(dt_next);
+
+  // outputs covered by this step: step() loops `while next_t > rk_state.t1`  (:116-127)
+  int b = c->next_out;
+  int e = b;
+  if (accept) {
+    while (e < c->n_out && dir * TT(t_span[e]) <= dir * t1) ++e;
+  }
+  c->out_begin = b;
+  c->out_end = e;
+  c->next_out = e;
+  if (e > b) c->steps_in_interval = 0;
+  c->done = (e >= c->n_out) ? 1 : 0;
+
+  if (accept && c->on_step_t && c->next_step_index != p.n_step_t - 1) c->next_step_index += 1;  // :263-265
+
+  plan_next<TT>(c, p, step_t, t_stage_out);
+}
+
+// The controller workgroup: reduce the partials (or take finalised sums), run the controller on a register copy of
+// the control block, write it back to the device block and the pinned host mirror.  FUSED = called by the last
+// workgroup of the fused error-norm launch (partials were published write-through inside this launch).
+template <bool FUSED>
+__device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const NormSlot* slot, const double* sums,
+                              const double* t_span, const double* step_t, void* t_stage_out, xde_ctrl_t* mirror,
+                              int nblocks, int norm_kind) {
+  __shared__ double seg_val[XDE_MAX_SEG];
+  __shared__ double seg_nf[XDE_MAX_SEG];
+  __shared__ xde_ctrl_t zs;
+  constexpr int kWords = sizeof(xde_ctrl_t) / 8;
+  constexpr int kSeqWord = offsetof(xde_ctrl_t, seq) / 8;
+  // the control block is fetched by the first lanes while the partials are being reduced (it is written only by
+  // controller launches, i.e. before this launch started)
+  if (threadIdx.x < kWords)
+    reinterpret_cast<uint64_t*>(&zs)[threadIdx.x] = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
+  if (sums) {
+    if (threadIdx.x < XDE_MAX_SEG) {
+      seg_val[threadIdx.x] = sums[threadIdx.x];
+      seg_nf[threadIdx.x] = sums[XDE_MAX_SEG + threadIdx.x];
+    }
+    __syncthreads();
+  } else {
+    if (threadIdx.x < XDE_MAX_SEG) {
+      seg_val[threadIdx.x] = 0.0;
+      seg_nf[threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+    if (FUSED)
+      reduce_partials<true>(slot, seg_val, seg_nf, nblocks, p.n_seg, norm_kind);
+    else
+      reduce_partials<false>(slot, seg_val, seg_nf);
+  }
+  if (threadIdx.x == 0) {
+    xde_ctrl_t z = zs;  // all controller arithmetic runs on registers
+    z.seq += 1;
+    if (z.done) {
+      // an attempt enqueued past the last output (speculative / graph replay) is a no-op: nothing to commit,
+      // no rows to emit
+      z.accept = 0;
+      z.out_begin = z.out_end = z.next_out;
+    } else {
+      double ratio = norm_from_sums(seg_val, p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, z.ratio_seg);
+      double nf = 0.0;
+      for (int s = 0; s < p.n_seg; ++s) nf += seg_nf[s];
+      if (p.time_dtype == XDE_F32)
+        control_step<float>(&z, p, ratio, nf, t_span, step_t, t_stage_out);
+      else
+        control_step<double>(&z, p, ratio, nf, t_span, step_t, t_stage_out);
+    }
+    zs = z;
+  }
+  __syncthreads();
+  // write-back: one wave instruction to the device block, one to the pinned host mirror slot
+  // (slot[seq % SLOTS]); the slot's seq word is stored last, after a system-scope release
+  if (threadIdx.x < kWords) {
+    const uint64_t word = reinterpret_cast<const uint64_t*>(&zs)[threadIdx.x];
+    reinterpret_cast<uint64_t*>(c)[threadIdx.x] = word;
+    if (mirror && threadIdx.x != kSeqWord) {
+      xde_ctrl_t* ms = mirror + (zs.seq % XDE_MIRROR_SLOTS);
+      __hip_atomic_store(reinterpret_cast<uint64_t*>(ms) + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (mirror && threadIdx.x < 64) {  // the wave that wrote the words releases them, then publishes seq
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+      xde_ctrl_t* ms = mirror + (zs.seq % XDE_MIRROR_SLOTS);
+      __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+
+inline int check_params(const xde_ctrl_params_t* p, const char* who) {
+  if (!p) return fail(XDE_EBADARG, std::string(who) + ": null params");
+  if (p->n_stage < 1 || p->n_stage > XDE_MAX_STAGE) return fail(XDE_EBADARG, std::string(who) + ": n_stage out of range");
+  if (p->n_seg < 1 || p->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, std::string(who) + ": n_seg out of range");
+  if (p->direction != 1 && p->direction != -1) return fail(XDE_EBADARG, std::string(who) + ": direction must be +-1");
+  if (p->time_dtype != XDE_F32 && p->time_dtype != XDE_F64) return fail(XDE_EBADARG, std::string(who) + ": bad time_dtype");
+  if (p->state_dtype != XDE_F32 && p->state_dtype != XDE_F64) return fail(XDE_EBADARG, std::string(who) + ": bad state_dtype");
+  if (!(p->order > 0)) return fail(XDE_EBADARG, std::string(who) + ": order must be positive");
+  return XDE_OK;
+}
+
+
+}  // namespace xde

@@ -4,7 +4,7 @@ Lives in tests/ on purpose: it lets `-m "not gpu"` tests drive the product's HOS
 operand plans, buffer rotation, output bookkeeping, tuple flattening, the adjoint, the process-group
 reduction hook) in a container without a GPU.  It is never importable from the product package and the
 product has no code path that selects it.  Each method states the kernel contract of include/xde_hip.h
-in numpy, in the same op order as csrc/xde_hip.hip.
+in numpy, in the same op order as csrc/xde_*.hip.
 """
 import ctypes as C
 

@@ -75,7 +75,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "paddlexde_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, flags=re.M), os.path.join(dirpath, f)
                 assert "xde_oracle" not in src and "import_module(\"oracle" not in src, os.path.join(dirpath, f)
