@@ -365,3 +365,38 @@ def test_initial_step_scalars(be, dbl, dtype, tdtype):
             np.testing.assert_allclose(fg, fr, rtol=2 * eps, atol=0, equal_nan=True)
             if not np.isnan(fr):
                 assert np.sign(fg) == direction
+
+
+def test_stage_combine_and_error_norm_beyond_2_31_elements(be):
+    """Maximum sizes: N = 2^31 + 5 fp32 elements (8 GiB per operand) — 64-bit indexing in the combine and in the norm
+    partials.  Checked against torch on slices at both ends and around the 2^31 boundary, and through the norm of a
+    constant."""
+    dev = torch.device("cuda:0")
+    n = (1 << 31) + 5
+    y0 = torch.empty(n, dtype=torch.float32, device=dev)
+    k = torch.empty(n, dtype=torch.float32, device=dev)
+    chunk = 1 << 28
+    for s in range(0, n, chunk):  # fill in pieces (bounded temporaries)
+        e = min(n, s + chunk)
+        idx = torch.arange(s, e, device=dev, dtype=torch.float64)
+        y0[s:e] = torch.sin(idx * 1e-3).float()
+        k[s:e] = torch.cos(idx * 7e-4).float()
+        del idx
+    out = torch.empty_like(y0)
+    be.stage_combine(out, y0, [k], [0.3], _hip.COMBINE_RK, dt_host=0.25)
+    c = np.float32(0.3) * np.float32(0.25)
+    for s, e in ((0, 4096), ((1 << 31) - 2048, (1 << 31) + 5), (n - 9, n)):
+        ref = y0[s:e].cpu().numpy() + k[s:e].cpu().numpy() * c
+        np.testing.assert_array_equal(out[s:e].cpu().numpy(), ref)
+    # error norm over all n elements: err = dt*c*k with k = 1 everywhere, y0 = y1 = 0  ->  ratio = dt*c/atol exactly
+    del out
+    k.fill_(1.0)
+    y0.zero_()
+    segs = _hip.make_segments([(0, n)])
+    ws, sums = be.new_workspace(dev), be.new_sums(dev)
+    be.error_norm_partial([k], [0.5], y0, y0, 0.0, 1e-2, segs, _hip.NORM_RMS, ws, dt_host=0.125)
+    be.norm_finalize(ws, 0, sums)
+    res = torch.zeros(1, dtype=torch.float64, device=dev)
+    be.norm_result(sums, [float(n)], _hip.NORM_RMS, _hip.XDE_F32, res)
+    assert abs(float(res) - 0.125 * 0.5 / 1e-2) <= 1e-5 * 6.25
+    assert float(sums[0]) == pytest.approx(n * (np.float32(0.0625) / np.float32(1e-2)) ** 2, rel=1e-6)
