@@ -400,3 +400,125 @@ def test_stage_combine_and_error_norm_beyond_2_31_elements(be):
     be.norm_result(sums, [float(n)], _hip.NORM_RMS, _hip.XDE_F32, res)
     assert abs(float(res) - 0.125 * 0.5 / 1e-2) <= 1e-5 * 6.25
     assert float(sums[0]) == pytest.approx(n * (np.float32(0.0625) / np.float32(1e-2)) ** 2, rel=1e-6)
+
+
+def test_stage_combine_randomised_sweep(be, dbl):
+    """300 seeded random configurations of xde_stage_combine — size, operand count, mode, dtype, 16-byte (mis)alignment of
+    every operand, device dt + operand select, damping, second output, cache-policy mask — all BIT-EXACT against the numpy
+    contract (the cache-policy mask must never change a value)."""
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(20240607)
+    for case in range(300):
+        dtype = ("f32", "f64")[rng.randint(2)]
+        dt = DT[dtype]
+        n = int(rng.choice([1, 2, 3, 5, 63, 64, 255, 1023, 1024, 4099, 65537, 300001])) if rng.rand() < 0.5 else int(rng.randint(1, 200000))
+        nk = int(rng.randint(1, _hip.XDE_MAX_K + 1))
+        mode = int(rng.choice([_hip.COMBINE_RK, _hip.COMBINE_FUSE, _hip.COMBINE_WFUSE]))
+
+        def operand(seed):
+            off = int(rng.randint(0, 4)) if rng.rand() < 0.3 else 0  # element offset: breaks 16-byte alignment
+            buf = _rand(n + 4, dt, seed, dev)
+            return buf[off : off + n]
+
+        y0 = operand(1000 + case)
+        ks = [operand(2000 + 17 * case + j) for j in range(nk)]
+        coef = list(rng.uniform(-2.0, 2.0, size=nk))
+        for j in range(nk):  # zero coefficients are legal operands too
+            if rng.rand() < 0.1:
+                coef[j] = 0.0
+        kw = dict(scale=float(rng.choice([1.0, 0.125, 1.0 / 6.0])), damping=float(rng.choice([0.0, 0.001])) if mode != _hip.COMBINE_RK else 0.0,
+                  nt_mask=int(rng.randint(0, 1 << 16)) | (int(rng.randint(2)) << 31))
+        use_ctrl = rng.rand() < 0.4
+        ctrl_h = _hip.XdeCtrl()
+        ctrl_h.dt = float(np.float32(rng.uniform(-0.5, 0.5)))
+        ctrl_h.accept = int(rng.randint(2))
+        alt = use_ctrl and rng.rand() < 0.5
+        y0b, k0b = (operand(5000 + case), operand(6000 + case)) if alt else (None, None)
+        out2 = coef2 = None
+        if mode == _hip.COMBINE_RK and rng.rand() < 0.3:
+            out2, coef2 = torch.empty(n, dtype=dt, device=dev), list(rng.uniform(-1e-2, 1e-2, size=nk))
+        out = torch.empty(n, dtype=dt, device=dev)
+        ref, ref2 = torch.empty(n, dtype=dt), (torch.empty(n, dtype=dt) if out2 is not None else None)
+        cpu = lambda x: None if x is None else x.cpu()  # noqa: E731
+        if use_ctrl:
+            raw = bytearray(bytes(ctrl_h))
+            be.stage_combine(out, y0, ks, coef, mode, ctrl=torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev), y0_alt=y0b, k0_alt=k0b,
+                             out2=out2, coef2=coef2, **kw)
+            dbl.stage_combine(ref, y0.cpu(), [k.cpu() for k in ks], coef, mode, ctrl=torch.frombuffer(bytearray(raw), dtype=torch.uint8),
+                              y0_alt=cpu(y0b), k0_alt=cpu(k0b), out2=ref2, coef2=coef2, **kw)
+        else:
+            h = float(np.float32(rng.uniform(-0.5, 0.5)))
+            be.stage_combine(out, y0, ks, coef, mode, dt_host=h, out2=out2, coef2=coef2, **kw)
+            dbl.stage_combine(ref, y0.cpu(), [k.cpu() for k in ks], coef, mode, dt_host=h, out2=ref2, coef2=coef2, **kw)
+        assert torch.equal(out.cpu(), ref), (case, dtype, n, nk, mode, use_ctrl, alt)
+        if out2 is not None:
+            assert torch.equal(out2.cpu(), ref2), (case, dtype, n, nk)
+
+
+def test_dense_eval_and_error_norm_randomised_sweep(be, dbl):
+    """150 seeded random configurations: xde_dense_eval (operand count, rows covered, time dtype, reverse time, operand
+    select, predication on accept / expect_step, misalignment) BIT-EXACT; xde_error_norm_partial + finalize (RMS and
+    LINF, fused / unfused, segments) to 1e-12 relative on the fp64 sums."""
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(777)
+    for case in range(150):
+        dtype = ("f32", "f64")[rng.randint(2)]
+        dt = DT[dtype]
+        n = int(rng.choice([1, 3, 64, 1000, 4099, 70001])) if rng.rand() < 0.5 else int(rng.randint(1, 100000))
+        nk = int(rng.randint(2, 9))
+
+        def operand(seed, misalign=True):
+            off = int(rng.randint(0, 4)) if (misalign and rng.rand() < 0.25) else 0
+            return _rand(n + 4, dt, seed, dev)[off : off + n]
+
+        y0, y1 = operand(10 * case + 1), operand(10 * case + 2)
+        ks = [operand(100 * case + j) for j in range(nk)]
+        cpu = lambda x: None if x is None else x.cpu()  # noqa: E731
+        # ---- dense output ---------------------------------------------------------------------------------------
+        tt = (_hip.XDE_F32, _hip.XDE_F64)[rng.randint(2)]
+        tdt = np.float32 if tt == _hip.XDE_F32 else np.float64
+        direction = 1 if rng.rand() < 0.7 else -1
+        t0 = tdt(rng.uniform(-1, 1))
+        t1 = tdt(t0 + direction * tdt(rng.uniform(0.05, 0.5)))
+        rows = int(rng.randint(1, 5))
+        inner = np.sort(rng.uniform(0.0, 1.0, size=rows))
+        t_out = [float(tdt(t0 + (t1 - t0) * tdt(x))) for x in inner]
+        t_span = torch.tensor([float(t0) - direction] + t_out + [float(t1) + direction], dtype=torch.float64)
+        ch = _hip.XdeCtrl()
+        ch.t0, ch.t1, ch.dt_last = float(t0), float(t1), float(tdt(t1 - t0))
+        ch.accept = int(rng.rand() < 0.8)
+        ch.out_begin, ch.out_end = 1, 1 + rows
+        ch.n_steps = int(rng.randint(1, 50))
+        expect = -1 if rng.rand() < 0.5 else (ch.n_steps if rng.rand() < 0.7 else ch.n_steps + 1)
+        raw = bytearray(bytes(ch))
+        alt = rng.rand() < 0.3
+        y0b, k0b = (operand(7000 + case), operand(8000 + case)) if alt else (None, None)
+        mid = list(rng.uniform(-0.2, 0.4, size=nk))
+        out = torch.full((rows + 2, n), 7.0, dtype=dt, device=dev)
+        ref = torch.full((rows + 2, n), 7.0, dtype=dt)
+        be.dense_eval(out, ks, mid, y0, y1, ks[-1], torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev), t_span.to(dev), tt,
+                      y0_alt=y0b, k0_alt=k0b, expect_step=expect)
+        dbl.dense_eval(ref, [k.cpu() for k in ks], mid, y0.cpu(), y1.cpu(), ks[-1].cpu(), torch.frombuffer(bytearray(raw), dtype=torch.uint8),
+                       t_span, tt, y0_alt=cpu(y0b), k0_alt=cpu(k0b), expect_step=expect)
+        assert torch.equal(out.cpu(), ref), ("dense", case, dtype, n, nk, tt, direction, rows, alt, expect)
+        # ---- error norm -----------------------------------------------------------------------------------------
+        norm_kind = (_hip.NORM_RMS, _hip.NORM_LINF)[rng.randint(2)]
+        width = 4 if dtype == "f32" else 2
+        if n >= 64 and rng.rand() < 0.4:  # two or three segments, vector-aligned starts
+            cut = sorted({int(width * rng.randint(1, n // width)) for _ in range(int(rng.randint(1, 3)))})
+            bounds = [0] + cut + [n]
+            seg_list = [(a, b - a) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+        else:
+            seg_list = [(0, n)]
+        segs = _hip.make_segments(seg_list)
+        c_err = list(rng.uniform(-1e-2, 1e-2, size=nk))
+        h = float(np.float32(rng.uniform(0.01, 0.3)))
+        rtol, atol = float(10 ** rng.uniform(-7, -2)), float(10 ** rng.uniform(-9, -4))
+        got = []
+        for backend, mv, device in ((be, (lambda x: x), dev), (dbl, cpu, torch.device("cpu"))):
+            ws, sums = backend.new_workspace(device), backend.new_sums(device)
+            backend.error_norm_partial([mv(k) for k in ks], c_err, mv(y0), mv(y1), rtol, atol, segs, norm_kind, ws, dt_host=h)
+            backend.norm_finalize(ws, 0, sums)
+            got.append(sums.cpu().numpy().copy())
+        np.testing.assert_allclose(got[0], got[1], rtol=(2e-6 if dtype == "f32" else 1e-12), atol=0,
+                                   err_msg=str(("errnorm", case, dtype, n, nk, norm_kind, seg_list)))
