@@ -253,8 +253,8 @@ int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_st
 /*
  * Scalar part of the initial-step heuristic on the device — AdaptiveSolver.select_initial_step
  * (solver/base_adaptive_solver.py:55-72) without reading the three norms back to the host.
- *   phase 0: res_dev = {d0, d1} (xde_norm_result outputs) -> h0 (hs_dev[2]); ctrl->dt = h0, so that the Euler probe
- *            `fuse(f0, h0, y0)` is an xde_stage_combine that reads dt from ctrl; *t_probe_out = t_start + h0 (dtype
+ *   phase 0: res_dev = {d0, d1} (xde_norm_result outputs) -> h0 (hs_dev[2]); ctrl->dt = direction*h0, so that the Euler probe
+ *            `fuse(f0, h0, y0)` is an xde_stage_combine that reads dt from ctrl; *t_probe_out = t_start + direction*h0 (dtype
  *            probe_dtype = promote(time dtype, state dtype)) is the time func is evaluated at.
  *   phase 1: res_dev = {norm((f1 - f0)/scale)} -> d2 = |./h0| -> h1 -> hs_dev[3] = min(100 h0, h1) in the time dtype;
  *            pass hs_dev + 3 to xde_ctrl_init as first_step_dev.  (first_step_dev != NULL overrides first_step; the

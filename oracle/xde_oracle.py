@@ -30,7 +30,7 @@ D1  ``xde.format`` is undefined -> identity.
 D2  ``RK4`` uses ``rk4_alt_step_func`` with stage-3 input ``k1 - k2/3`` -> reproduced.
 D3  fixed solvers concat on axis -2, adaptive solvers stack on axis 0 -> reproduced.
 D4  tuple state: flatten -> integrate -> unflatten (torchdiffeq intent).
-D5  adaptive reverse time: ``t -> -t, f -> -f`` flip (torchdiffeq intent).
+D5  adaptive reverse time: ``t -> -t, f -> -f`` flip, ``step_t`` flipped with it (torchdiffeq intent).
 D6  backward additionally returns the gradient w.r.t. ``y0`` (superset).
 D7  ``jump_t``, ``step_size``/``grid_constructor`` sub-stepping -> NotImplementedError.
 D9  plain integral controller (``ode_utils.py:85-97``), not PI.
@@ -677,6 +677,8 @@ def odeint(func, y0, t_span, solver, *, rtol=1e-7, atol=1e-9, options=None, retu
             inner = func
             func = lambda t, y: -inner(-t, y)  # noqa: E731
             t_span = -t_span
+            if options.get("step_t") is not None:  # forced grid points are given in real time: they flip with it
+                options["step_t"] = -np.asarray(options["step_t"])
         s = AdaptiveRKSolver(func, y0, rtol, atol, method=solver, **options)
         solution = s.integrate(t_span)
         if shapes is not None:

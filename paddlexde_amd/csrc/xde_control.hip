@@ -122,12 +122,15 @@ __device__ void initial_step_phase(int phase, const double* res, double* hs, con
     hs[0] = double(d0);
     hs[1] = double(d1);
     hs[2] = double(h0);
-    c->dt = double(h0);
+    // the Euler probe is taken in the direction of integration (the reference integrates forward only; in reverse time
+    // this equals its heuristic on the flipped problem t -> -t, f -> -f)
+    const Y hs0 = p.direction < 0 ? -h0 : h0;
+    c->dt = double(hs0);
     // t0 + h0: time dtype + state dtype -> the promoted dtype
     if (probe_dtype == XDE_F32)
-      *static_cast<float*>(t_probe_out) = float(t_start) + float(h0);
+      *static_cast<float*>(t_probe_out) = float(t_start) + float(hs0);
     else
-      *static_cast<double*>(t_probe_out) = (p.time_dtype == XDE_F32 ? double(float(t_start)) : t_start) + double(h0);
+      *static_cast<double*>(t_probe_out) = (p.time_dtype == XDE_F32 ? double(float(t_start)) : t_start) + double(hs0);
   } else {
     const Y h0 = Y(hs[2]), d1 = Y(hs[1]);
     Y d2 = Y(res[0]) / h0;

@@ -86,9 +86,12 @@ class AdaptiveSolver(metaclass=abc.ABCMeta):
         else:
             h0 = 0.01 * d0 / d1
         h0 = abs(h0)
+        # the Euler probe goes in the direction of integration (the reference integrates forward only; in reverse time this
+        # is its heuristic on the flipped problem t -> -t, f -> -f)
+        hs0 = -h0 if getattr(self, "_direction", 1) < 0 else h0
         y1 = torch.empty_like(y0)
-        be.stage_combine(y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, dt_host=float(h0))  # fuse(f0, h0, y0)
-        f1 = self._eval(self._scalar_t(t0h + h0, torch.promote_types(self.dtype, y0.dtype)), y1)
+        be.stage_combine(y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, dt_host=float(hs0))  # fuse(f0, h0, y0)
+        f1 = self._eval(self._scalar_t(t0h + hs0, torch.promote_types(self.dtype, y0.dtype)), y1)
         (n2,) = self._scaled_norms([(f1, f0)], y0, rtol, atol)
         with np.errstate(all="ignore"):
             d2 = abs(yt(n2) / h0)

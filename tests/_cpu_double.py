@@ -231,9 +231,10 @@ class NumpyDoubleBackend:
                 h0 = Y(1e-6) if (d0 < 1e-5 or d1 < 1e-5) else Y(0.01) * d0 / d1
                 h0 = abs(h0)
                 h[0], h[1], h[2] = d0, d1, h0
-                self._c(ctrl).dt = float(h0)
+                hs0 = -h0 if params.direction < 0 else h0
+                self._c(ctrl).dt = float(hs0)
                 t0 = np.float32(t_start) if params.time_dtype == _hip.XDE_F32 else np.float64(t_start)
-                t_probe.numpy()[...] = t0 + h0
+                t_probe.numpy()[...] = t0 + hs0
             else:
                 h0, d1 = Y(h[2]), Y(h[1])
                 d2 = abs(Y(r[0]) / h0)
