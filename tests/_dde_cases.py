@@ -171,3 +171,42 @@ def test_dde_api_conventions(dev):
     assert torch.allclose(x.fuse(dy, 0.5, y0), (dy - 0.001 * (dy * 0.5 + y0)) * 0.5 + y0)
     with pytest.raises(NotImplementedError):
         HistoryIndex.apply(torch.zeros(1, device=dev), torch.from_numpy(his).to(dev), torch.from_numpy(ht).to(dev), "linear")
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_randomised_ddeint_sweep_vs_oracle(dev, block):
+    """8 random configurations per block: solver, dtype, leading axes, history length and grid (uniform or not), number of
+    lags (some outside the history span: clamped / extrapolated as the reference does), output grid.  The gathered delayed
+    states to the spline bar; with the delayed states handed over (``his_processed``) the trajectory is bit-exact."""
+    rng = np.random.RandomState(555 + block)
+    for case in range(8):
+        solver = list(SOLVERS)[rng.randint(len(SOLVERS))]
+        dtype = (np.float32, np.float64)[rng.randint(2)]
+        lead = tuple(int(x) for x in rng.randint(1, 5, size=rng.randint(1, 3)))
+        D = int(rng.choice([1, 2, 3, 4, 8, 12]))
+        Th = int(rng.randint(4, 40))
+        uniform = bool(rng.rand() < 0.5)
+        his, ht = _history(lead + (D,), Th, uniform, seed=int(rng.randint(1000)), dtype=dtype)
+        nl = int(rng.randint(1, 9))
+        lags = rng.uniform(ht[0] - 0.5, ht[-1] + 0.5, size=nl).astype(dtype)
+        if rng.rand() < 0.5:
+            lags[rng.randint(nl)] = ht[rng.randint(Th)]  # exactly on a node
+        y0 = his[..., -1, :].copy()
+        T = int(rng.randint(2, 12))
+        t = np.cumsum(rng.uniform(0.01, 0.1, size=T)).astype(dtype)
+        tag = (block, case, solver, dtype.__name__, lead, D, Th, uniform, nl, T)
+
+        def f_np(y_lags, y):
+            return -0.5 * y + 0.25 * (y_lags[..., 0, :] * y_lags[..., -1, :]) - 0.1 * y * y * y
+
+        ref, yl = O.ddeint(f_np, y0, t, lags, his, ht, solver)
+        tt = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+        got, gl = ddeint(f_np, tt(y0), tt(t), tt(lags), tt(his), tt(ht), SOLVERS[solver])
+        assert tuple(gl.shape) == yl.shape == lead + (nl, D), tag
+        assert P.rel_err(gl.cpu().numpy(), yl) <= (5e-5 if dtype == np.float32 else 1e-11), (tag, P.rel_err(gl.cpu().numpy(), yl))
+        assert tuple(got.shape) == ref.shape, tag
+        assert P.rel_err(got.cpu().numpy(), ref) <= (5e-5 if dtype == np.float32 else 1e-10), (tag, P.rel_err(got.cpu().numpy(), ref))
+        # same delayed states on both sides -> bit-exact trajectory
+        ref2, _ = O.ddeint(f_np, y0, t, None, yl, None, solver, his_processed=True)
+        got2, _ = ddeint(f_np, tt(y0), tt(t), None, tt(yl), None, SOLVERS[solver], his_processed=True)
+        assert np.array_equal(got2.cpu().numpy(), ref2), tag

@@ -761,3 +761,132 @@ def test_randomised_adaptive_sweep_vs_oracle(dev, block):
             continue
         assert P.parity_ok(got, ref, rtol=1e-9, atol=1e-11), (tag, P.worst(got, ref, 1e-9, 1e-11))
         assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == (so.n_accept, so.n_reject, so.nfe), tag
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_randomised_fixed_sweep_vs_oracle(dev, block):
+    """10 random configurations per block: solver, state shape ``[..., L, D]`` (0-3 leading axes), dtype, non-uniform /
+    reversed grids, ``interp``, Adams order / corrector, time-dependent cubic dynamics built from +, -, * only — the whole
+    trajectory BIT-EXACT and the same number of ``func`` evaluations."""
+    rng = np.random.RandomState(9100 + block)
+    for case in range(10):
+        name = ("euler", "midpoint", "rk4", "adams", "adams_implicit")[rng.randint(5)]
+        dtype = (np.float32, np.float64)[rng.randint(2)]
+        lead = tuple(int(x) for x in rng.randint(1, 4, size=rng.randint(0, 4)))
+        L, D = int(rng.randint(1, 4)), int(rng.randint(1, 6))
+        y0 = rng.uniform(-1.0, 1.0, size=lead + (L, D)).astype(dtype)
+        T = int(rng.randint(2, 24))
+        t = np.cumsum(rng.uniform(0.005, 0.03, size=T)).astype(dtype) if rng.rand() < 0.5 else np.linspace(0.0, 0.4, T).astype(dtype)
+        if rng.rand() < 0.25:
+            t = t[::-1].copy()
+        interp = ("linear", "cubic")[rng.randint(2)] if rng.rand() < 0.5 else "linear"
+        w = rng.uniform(-1.0, 1.0, size=(D,)).astype(dtype)
+        wt = torch.from_numpy(w).to(dev)
+        calls = {"np": 0, "t": 0}
+
+        def f_np(t_, y):
+            calls["np"] += 1
+            return -0.5 * y - 0.1 * (y * y * y) + w * t_ + 0.25 * (y * w)
+
+        def f_t(t_, y):
+            calls["t"] += 1
+            return -0.5 * y - 0.1 * (y * y * y) + wt * t_ + 0.25 * (y * wt)
+
+        o_opts = {"norm": O._rms_norm, "interp": interp}
+        k_opts = {"norm": _rms_norm, "interp": interp}
+        solver = FIXED[name.replace("_implicit", "")]
+        if name.startswith("adams"):
+            mo = int(rng.choice([3, 4, 6, 12]))
+            o_opts["max_order"] = k_opts["max_order"] = mo
+            k_opts["implicit"] = name.endswith("implicit")
+        ref = O.odeint(f_np, y0, t, name, rtol=1e-3, atol=1e-4, options=o_opts)
+        got = odeint(f_t, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), solver=solver, rtol=1e-3, atol=1e-4, options=k_opts)
+        tag = (block, case, name, dtype.__name__, lead, L, D, T, interp)
+        assert tuple(got.shape) == ref.shape == lead + (T * L, D), tag
+        assert np.array_equal(got.cpu().numpy(), ref), (tag, float(np.abs(got.cpu().numpy() - ref).max()))
+        assert calls["np"] == calls["t"], (tag, calls)
+
+
+class _SmallMLP(nn.Module):
+    def __init__(self, d, h, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.W1 = nn.Parameter(0.3 * torch.randn(d, h, generator=g, dtype=torch.float64))
+        self.b1 = nn.Parameter(0.1 * torch.randn(h, generator=g, dtype=torch.float64))
+        self.W2 = nn.Parameter(0.3 * torch.randn(h, d, generator=g, dtype=torch.float64))
+        self.b2 = nn.Parameter(0.1 * torch.randn(d, generator=g, dtype=torch.float64))
+
+    def forward(self, t, y):
+        return torch.tanh((y * y * y) @ self.W1 + self.b1) @ self.W2 + self.b2 + 0.1 * t
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_randomised_adjoint_sweep_vs_oracle(dev, block):
+    """6 random configurations per block (fp64): forward / adjoint solver pair, tolerances, adjoint tolerances, the adjoint's
+    default norm or "seminorm", batch, width, number of output times, a random cotangent — solution, d/dy0 and every
+    parameter gradient against the oracle's adjoint to 1e-8 of each tensor's scale."""
+    rng = np.random.RandomState(31337 + block)
+    for case in range(6):
+        solver = ("dopri5", "bosh3", "dopri8", "rk4", "midpoint", "euler")[rng.randint(6)]
+        adj_solver = None if rng.rand() < 0.6 else ("dopri5", "rk4", "bosh3")[rng.randint(3)]
+        B, d, h = int(rng.randint(1, 12)), int(rng.randint(1, 5)), int(rng.randint(2, 9))
+        m = _SmallMLP(d, h, seed=int(rng.randint(1 << 30)))
+        W1, b1, W2, b2 = [p.detach().numpy().copy() for p in m.parameters()]
+
+        def fn(t_, y):
+            return np.tanh((y * y * y) @ W1 + b1) @ W2 + b2 + 0.1 * t_
+
+        def vjp(t_, y, cot):
+            u = y * y * y
+            a = np.tanh(u @ W1 + b1)
+            gh = (cot @ W2.T) * (1 - a * a)
+            u2, a2, gh2, c2 = u.reshape(-1, d), a.reshape(-1, h), gh.reshape(-1, h), cot.reshape(-1, d)
+            return (gh @ W1.T) * 3 * y * y, [u2.T @ gh2, gh2.sum(0), a2.T @ c2, c2.sum(0)]
+
+        m = m.to(dev)
+        T = int(rng.randint(2, 7))
+        fixed = solver in FIXED
+        if fixed:
+            y0 = rng.uniform(-1.5, 1.5, size=(B, 1, d))  # fixed solvers concatenate on axis -2
+        else:
+            y0 = rng.uniform(-1.5, 1.5, size=(B, d))
+        t = np.sort(rng.uniform(0.0, 0.8, size=T))
+        rtol = float(10 ** rng.uniform(-9, -6))
+        tol = dict(rtol=rtol, atol=rtol * 1e-2)
+        kw, okw = {}, {}
+        if rng.rand() < 0.3:
+            kw["adjoint_rtol"] = okw["adjoint_rtol"] = rtol * 0.1
+            kw["adjoint_atol"] = okw["adjoint_atol"] = rtol * 1e-3
+        if adj_solver is not None:
+            kw["adjoint_solver"], okw["adjoint_solver"] = {**FIXED, **ADAPTIVE}[adj_solver], adj_solver
+        opts, oopts = {"norm": _rms_norm}, {"norm": O._rms_norm}
+        if not fixed:
+            opts["dtype"], oopts["dtype"] = torch.float64, np.float64
+        adj_adaptive = (adj_solver or solver) in ADAPTIVE
+        if adj_solver is not None and adj_solver != solver:
+            # odeint_adjoint.py:204-207: with a different adjoint solver the adjoint options must be given explicitly
+            kw["adjoint_options"], okw["adjoint_options"] = {}, {}
+            if adj_adaptive:
+                kw["adjoint_options"]["dtype"], okw["adjoint_options"]["dtype"] = torch.float64, np.float64
+        if adj_adaptive and rng.rand() < 0.4:
+            # explicit adjoint options replace the inherited ones (odeint_adjoint.py:209-214): keep the fp64 time dtype
+            kw.setdefault("adjoint_options", {"dtype": torch.float64})["norm"] = "seminorm"
+            okw.setdefault("adjoint_options", {"dtype": np.float64})["norm"] = "seminorm"
+            kw["adjoint_options"].setdefault("dtype", torch.float64)
+            okw["adjoint_options"].setdefault("dtype", np.float64)
+        tag = (block, case, solver, adj_solver, B, d, h, T, rtol, sorted(kw))
+        y0g = torch.from_numpy(y0).to(dev).requires_grad_(True)
+        sol = odeint_adjoint(m, y0g, torch.from_numpy(t).to(dev), solver={**FIXED, **ADAPTIVE}[solver], options=opts, **tol, **kw)
+        ans, bw = O.odeint_adjoint(fn, vjp, [W1, b1, W2, b2], y0, t, solver, options=oopts, **tol, **okw)
+        assert tuple(sol.shape) == ans.shape, tag
+        cot = rng.standard_normal(ans.shape)
+        sol.backward(torch.from_numpy(cot).to(dev))
+        gy0, gps = bw(cot)
+        # Dopri8 on short intervals: error estimates below the round-off of their own terms make dt rounding noise (see
+        # test_randomised_adaptive_sweep_vs_oracle), and its outputs carry the quartic interpolant's error (measured against
+        # a 1e-13 Dopri5 solve: oracle 3.9e-7, this package 2.5e-7, each other 1.4e-7) — two valid integrations, not bit twins
+        bar = 1e-5 if "dopri8" in (solver, adj_solver) else 1e-8  # 1e-5: the bar north_star states
+        assert P.rel_err(sol.detach().cpu().numpy(), ans) <= bar, (tag, P.rel_err(sol.detach().cpu().numpy(), ans))
+        assert P.rel_err(y0g.grad.cpu().numpy(), gy0) <= bar, (tag, "y0", P.rel_err(y0g.grad.cpu().numpy(), gy0))
+        for i, (p_, g_) in enumerate(zip(m.parameters(), gps)):
+            assert P.rel_err(p_.grad.cpu().numpy(), g_) <= bar, (tag, i, P.rel_err(p_.grad.cpu().numpy(), g_))
