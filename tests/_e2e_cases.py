@@ -261,7 +261,9 @@ def test_pi_controller_is_opt_in(dev):
 
 
 def test_repeated_start_time_rows(dev):
-    """t_span = [t0, t0, t1]: the reference's loop takes no step for the second row; it must equal y0."""
+    """t_span = [t0, t0, t1]: the reference's loop takes no step for the second row (base_adaptive_solver_rk.py:119) and
+    then evaluates its interpolant on the empty interval [t0, t0] — 0/0, a NaN row (ode_utils.py:65-68; torchdiffeq, whose
+    loop this is, rejects such grids up front).  Deliberate deviation: the row is y0, the only value it can mean."""
     A, y0 = _linear(8, 4, torch.float64)
     Ad = A.to(dev)
     t = torch.tensor([0.0, 0.0, 0.5], dtype=torch.float64)
@@ -693,7 +695,7 @@ def test_config2_full_size_properties(dev):
 @pytest.mark.parametrize("block", range(10))
 def test_randomised_adaptive_sweep_vs_oracle(dev, block):
     """8 random configurations per block: tableau, pipeline, tolerances, number and spacing of output times, direction of
-    time, norm, first_step / max_step / safety / ifactor / dfactor, step_t, time-dependent cubic dynamics.  Solution to
+    time, norm, first_step / min_step / max_step / safety / ifactor / dfactor / max_num_steps, step_t, time-dependent cubic dynamics.  Solution to
     1e-9 relative, identical accept / reject / NFE counts; the reference's assertion where the oracle raises it."""
     from paddlexde_amd.xde import BaseODE
 
@@ -725,6 +727,10 @@ def test_randomised_adaptive_sweep_vs_oracle(dev, block):
             lo, hi = min(t[0], t[-1]), max(t[0], t[-1])
             opts["step_t"] = np.sort(rng.uniform(lo, hi, size=int(rng.randint(1, 4))))
         linf = rng.rand() < 0.3
+        if rng.rand() < 0.2:
+            opts["min_step"] = float(10 ** rng.uniform(-3, -1.3))  # steps at or below it are accepted whatever the error
+        if rng.rand() < 0.1:
+            opts["max_num_steps"] = int(rng.randint(2, 12))  # "max_num_steps exceeded" where the oracle says so
         An = A.numpy()
         Ad = A.to(dev)
 
