@@ -896,3 +896,45 @@ def test_randomised_adjoint_sweep_vs_oracle(dev, block):
         assert P.rel_err(y0g.grad.cpu().numpy(), gy0) <= bar, (tag, "y0", P.rel_err(y0g.grad.cpu().numpy(), gy0))
         for i, (p_, g_) in enumerate(zip(m.parameters(), gps)):
             assert P.rel_err(p_.grad.cpu().numpy(), g_) <= bar, (tag, i, P.rel_err(p_.grad.cpu().numpy(), g_))
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_randomised_tuple_state_sweep_vs_oracle(dev, block):
+    """8 random configurations per block: a tuple state of 1-5 components of odd shapes (every segment start is padded to
+    16 bytes inside the flat buffer the kernels see), coupled time-dependent dynamics, every tableau and pipeline, both
+    directions of time, rms / linf norms — each component to 1e-9."""
+    rng = np.random.RandomState(8800 + block)
+    shapes_pool = [(1,), (3,), (5,), (2, 3), (7, 1, 2), (4, 4), (1, 1), (9,), (2, 2, 2), (13,)]
+    for case in range(8):
+        name = list(ADAPTIVE)[rng.randint(len(ADAPTIVE))]
+        if name == "dopri8":
+            name = "dopri5"  # its noise regime is the subject of test_randomised_adaptive_sweep_vs_oracle
+        pipeline = ("sync", "lag", "graph")[rng.randint(3)]
+        ncomp = int(rng.randint(1, 6))
+        shapes = [shapes_pool[rng.randint(len(shapes_pool))] for _ in range(ncomp)]
+        y0 = [rng.uniform(-1.0, 1.0, size=sh) for sh in shapes]
+        rates = rng.uniform(-0.8, 0.3, size=ncomp)
+        T = int(rng.randint(2, 6))
+        t = np.sort(rng.uniform(0.0, 1.2, size=T))
+        if rng.rand() < 0.3:
+            t = t[::-1].copy()
+        rtol = float(10 ** rng.uniform(-8, -5))
+        if name in ("adaptive_heun", "fehlberg2"):
+            rtol = max(rtol, 1e-5)
+        linf = rng.rand() < 0.3
+
+        def f(t_, y):  # the same code runs on numpy arrays and on torch tensors: +, -, *, sum only
+            tot = y[0].sum()
+            for c in y[1:]:
+                tot = tot + c.sum()
+            return tuple(float(r) * c - 0.05 * (c * c * c) + 0.01 * tot + 0.2 * t_ for r, c in zip(rates, y))
+
+        ref, so = O.odeint(f, tuple(y0), t, name, rtol=rtol, atol=rtol * 1e-2,
+                           options={"norm": O._linf_norm if linf else O._rms_norm, "dtype": np.float64}, return_solver=True)
+        got = odeint(f, tuple(torch.from_numpy(c).to(dev) for c in y0), torch.from_numpy(t), solver=ADAPTIVE[name], rtol=rtol, atol=rtol * 1e-2,
+                     options={"norm": _linf_norm if linf else _rms_norm, "dtype": torch.float64, "pipeline": pipeline})
+        tag = (block, case, name, pipeline, shapes, T, rtol, linf)
+        assert len(got) == len(ref) == ncomp, tag
+        for g, r, sh in zip(got, ref, shapes):
+            assert tuple(g.shape) == r.shape == (T,) + sh, tag
+            assert P.parity_ok(g.cpu().numpy(), r, 1e-9, 1e-11), (tag, P.worst(g.cpu().numpy(), r, 1e-9, 1e-11))
