@@ -64,15 +64,16 @@ def _worker(rank, world, port, out_dir, norm_name, pipeline, device="cpu"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("norm_name,pipeline", [("rms", "sync"), ("rms", "lag"), ("linf", "sync")])
-def test_two_rank_sharded_equals_unsharded(tmp_path, cpu_double, norm_name, pipeline):
-    world = 2
+@pytest.mark.parametrize("norm_name,pipeline,world", [("rms", "sync", 2), ("rms", "lag", 2), ("linf", "sync", 2), ("rms", "lag", 3)])
+def test_two_rank_sharded_equals_unsharded(tmp_path, cpu_double, norm_name, pipeline, world):
+    """world 3 splits the 64 rows 21 / 21 / 22: uneven shards (the global element count is itself all-reduced)."""
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), norm_name, pipeline), nprocs=world, join=True)
-    r0 = np.load(tmp_path / "rank0.npz")
-    r1 = np.load(tmp_path / "rank1.npz")
-    # (i) lock-step: identical (t0, dt, ratio, accept) on both ranks, bit for bit
-    assert np.array_equal(r0["trace"], r1["trace"])
+    rs = [np.load(tmp_path / "rank{}.npz".format(r)) for r in range(world)]
+    r0 = rs[0]
+    # (i) lock-step: identical (t0, dt, ratio, accept) on every rank, bit for bit
+    for r in rs[1:]:
+        assert np.array_equal(r0["trace"], r["trace"])
     # (ii) equals the single-process run over the whole batch
     B, D = 64, 16
     A, y0 = _problem(B, D)
@@ -82,7 +83,7 @@ def test_two_rank_sharded_equals_unsharded(tmp_path, cpu_double, norm_name, pipe
     assert tr.shape == r0["trace"].shape
     assert np.array_equal(tr[:, 3], r0["trace"][:, 3])
     assert np.allclose(tr[:, :3], r0["trace"][:, :3], rtol=1e-6)
-    got = np.concatenate([r0["sol"], r1["sol"]], axis=1)
+    got = np.concatenate([r["sol"] for r in rs], axis=1)
     assert P.rel_err(got, full) <= 1e-6
     # (iii) the shards really are coupled: the small-magnitude shard alone would have taken different steps
     alone, s_alone = _solve(y0[: B // 2].contiguous(), A, None, norm_name, pipeline)
