@@ -108,3 +108,77 @@ def test_two_ranks_on_one_gpu_hip_kernels(tmp_path, pipeline):
     assert tr.shape == r0["trace"].shape and np.array_equal(tr[:, 3], r0["trace"][:, 3])
     got = np.concatenate([r0["sol"], r1["sol"]], axis=1)
     assert P.rel_err(got, full.cpu().numpy()) <= 1e-6
+
+
+# ----------------------------------------------------------------------------------------------
+# batch-sharded odeint_adjoint: forward and backward both under the global error norm
+# ----------------------------------------------------------------------------------------------
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.W1 = torch.nn.Parameter(0.4 * torch.randn(4, 8, generator=g, dtype=torch.float64))
+        self.W2 = torch.nn.Parameter(0.4 * torch.randn(8, 4, generator=g, dtype=torch.float64))
+
+    def forward(self, t, y):
+        return torch.tanh(y @ self.W1) @ self.W2 - 0.1 * y
+
+
+def _adjoint_run(y0, pg):
+    from paddlexde_amd import Dopri5, odeint_adjoint
+    from paddlexde_amd.utils import _rms_norm
+
+    m = _Net()
+    y0 = y0.clone().requires_grad_(True)
+    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64)
+    opts = {"norm": _rms_norm, "dtype": torch.float64}
+    if pg:
+        opts["process_group"] = True
+    # "seminorm": the adjoint's step control looks at (y, adj_y) only — quantities every rank holds a shard of, so the
+    # all-reduced norm is exactly the unsharded one (parameter adjoints are per-rank partial sums)
+    sol = odeint_adjoint(m, y0, t, solver=Dopri5, rtol=1e-7, atol=1e-9, options=opts,
+                         adjoint_options={"norm": "seminorm", "dtype": torch.float64, **({"process_group": True} if pg else {})})
+    w = torch.linspace(-1.0, 1.0, sol.numel(), dtype=torch.float64).reshape(sol.shape)
+    return m, y0, sol, w
+
+
+def _adjoint_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from paddlexde_amd import _hip
+
+        from ._cpu_double import NumpyDoubleBackend
+
+        _hip._set_backend_for_testing(NumpyDoubleBackend())
+        torch.set_num_threads(1)
+        B = 12
+        y_all = torch.randn(B, 4, generator=torch.Generator().manual_seed(11), dtype=torch.float64)
+        y_all[B // 2 :] *= 4.0
+        rows = slice(rank * B // world, (rank + 1) * B // world)
+        m, y0, sol, _ = _adjoint_run(y_all[rows].contiguous(), True)
+        w_all = torch.linspace(-1.0, 1.0, 4 * B * 4, dtype=torch.float64).reshape(4, B, 4)
+        (sol * w_all[:, rows]).sum().backward()
+        np.savez(os.path.join(out_dir, "adj{}.npz".format(rank)), sol=sol.detach().numpy(), gy=y0.grad.numpy(),
+                 gW1=m.W1.grad.numpy(), gW2=m.W2.grad.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_adjoint(tmp_path, cpu_double):
+    """Forward AND adjoint backward batch-sharded over two ranks: solution rows and d/dy0 rows equal the unsharded run's,
+    the per-rank parameter gradients SUM to the unsharded ones (what DDP's gradient all-reduce does)."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_adjoint_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [np.load(tmp_path / "adj{}.npz".format(r)) for r in range(world)]
+    B = 12
+    y_all = torch.randn(B, 4, generator=torch.Generator().manual_seed(11), dtype=torch.float64)
+    y_all[B // 2 :] *= 4.0
+    m, y0, sol, w = _adjoint_run(y_all, False)
+    (sol * w).sum().backward()
+    assert P.rel_err(np.concatenate([r["sol"] for r in rs], axis=1), sol.detach().numpy()) <= 1e-9
+    assert P.rel_err(np.concatenate([r["gy"] for r in rs], axis=0), y0.grad.numpy()) <= 1e-8
+    assert P.rel_err(sum(r["gW1"] for r in rs), m.W1.grad.numpy()) <= 1e-8
+    assert P.rel_err(sum(r["gW2"] for r in rs), m.W2.grad.numpy()) <= 1e-8
