@@ -181,6 +181,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 grad_t_span = torch.empty(T, dtype=t_span.dtype, device=t_span.device)
             else:
                 grad_t_span = None
+            # one device->host read of the output times for all intervals (each inner odeint would otherwise do its own)
+            t_host = t_span.detach().to("cpu")
             for i in range(T - 1, 0, -1):
                 if t_requires_grad:
                     func_eval = func(t_span[i], y_ans[i])
@@ -192,7 +194,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 aug = odeint(
                     func=augmented_dynamics,
                     y0=tuple(aug_state),
-                    t_span=t_span[i - 1 : i + 1].flip(0),
+                    t_span=t_host[i - 1 : i + 1].flip(0),
                     solver=adjoint_method,
                     rtol=adjoint_rtol,
                     atol=adjoint_atol,

@@ -39,3 +39,17 @@ def t_span_to_host(t_span, np_time_dtype):
     else:
         arr = np.asarray(t_span)
     return arr.astype(np_time_dtype)
+
+
+def upload(arr, device):
+    """Host numpy array -> device tensor without blocking the host: staged through torch's caching pinned allocator and
+    copied asynchronously on the current stream (a pageable H2D copy would wait for everything enqueued before it)."""
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+def scalar(value, dtype, device):
+    """0-dim device tensor holding ``value``: a fill kernel with the value as argument (no host-to-device copy)."""
+    return torch.full((), float(value), dtype=dtype, device=device)

@@ -29,7 +29,7 @@ import torch
 
 from .. import _hip
 from ..utils.ode_utils import native_norm_spec
-from ._common import as_operand, np_dtype, storage_ptr
+from ._common import as_operand, np_dtype, scalar, storage_ptr, upload
 from .base_adaptive_solver import AdaptiveSolver
 
 _ButcherTableau = collections.namedtuple("_ButcherTableau", "alpha, beta, c_sol, c_error")
@@ -212,7 +212,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         return f
 
     def _scalar_t(self, value, dtype):
-        return torch.tensor(float(value), dtype=dtype, device=self.y0.device)
+        return scalar(value, dtype, self.y0.device)
 
     # ------------------------------------------------------------------------------------------
     # reductions (optionally all-reduced across the batch-sharding process group)
@@ -283,7 +283,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         tt = np_dtype(self.dtype)
         self._direction = -1 if t_span[1] < t_span[0] else 1
         self._t_host = t_span
-        self._t_span_dev = torch.from_numpy(t_span.astype(np.float64)).to(dev)
+        self._t_span_dev = upload(t_span.astype(np.float64), dev)
         self._t_stage = torch.zeros(_hip.XDE_MAX_STAGE, dtype=y0.dtype, device=dev)
         self._t_views = [self._t_stage[i] for i in range(self._n_stage)]  # the 0-dim stage times handed to func
         self._ctrl = be.new_ctrl(dev)
@@ -304,7 +304,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
             st = st[d * st >= d * t_span[0]]
             step_t = np.sort(d * st) * d
         self._step_t_host = step_t
-        self._step_t_dev = torch.from_numpy(step_t.astype(np.float64)).to(dev) if len(step_t) else None
+        self._step_t_dev = upload(step_t.astype(np.float64), dev) if len(step_t) else None
         self.next_step_index = min(bisect.bisect((d * step_t).tolist(), d * t_span[0]), len(step_t) - 1)
 
         p = _hip.XdeCtrlParams()

@@ -18,7 +18,7 @@ from .. import _hip
 from ..xde.base_dde import DDE_DAMPING, BaseDDE
 from ..xde.base_ode import BaseODE
 from ._autograd import CombineFn
-from ._common import as_operand, np_dtype, storage_ptr, t_span_to_host
+from ._common import as_operand, np_dtype, storage_ptr, t_span_to_host, upload
 
 _one_third = 1 / 3
 _two_thirds = 2 / 3
@@ -109,7 +109,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
         key = (float(value), like.dtype)
         t = self._tdev_cache.get(key)
         if t is None:
-            t = torch.tensor([float(value)], dtype=like.dtype, device=like.device)
+            t = torch.full((1,), float(value), dtype=like.dtype, device=like.device)
             if len(self._tdev_cache) < 1024:
                 self._tdev_cache[key] = t
         return t
@@ -130,7 +130,8 @@ class FixedSolver(metaclass=abc.ABCMeta):
         pred_len = len(t_span)
         t_dtype = t_span.dtype if t_span.dtype in (torch.float32, torch.float64) else torch.float32
         t_host = t_span_to_host(t_span, np_dtype(t_dtype))
-        t_dev = t_span.detach().to(device=y0.device, dtype=t_dtype)
+        # (values rounded to the time dtype on the host, as t_span.astype would; no blocking pageable copy)
+        t_dev = t_span.detach().to(device=y0.device, dtype=t_dtype) if t_span.is_cuda else upload(t_host, y0.device)
 
         # one upload: per step [t-like values the step passes to move()]
         rows = []
@@ -140,7 +141,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
             rows.append([t0h + v if is_time else v for v, is_time in self._time_values_tagged(dt)])
         table = None
         if rows and len(rows[0]):
-            table = torch.from_numpy(np.asarray(rows, dtype=np_dtype(t_dtype))).to(y0.device)
+            table = upload(np.asarray(rows, dtype=np_dtype(t_dtype)), y0.device)
 
         tracking = torch.is_grad_enabled() and y0.requires_grad
         y0 = as_operand(y0 if tracking else y0.detach())
