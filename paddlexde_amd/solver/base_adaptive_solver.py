@@ -57,17 +57,23 @@ class AdaptiveSolver(metaclass=abc.ABCMeta):
         solution[0] = y0
         if len(t_host) < 2:
             return solution
-        self._before_integrate(t_host)
-        # rows whose time equals the start time need no step (`while next_t > rk_state.t1` is false at once,
-        # base_adaptive_solver_rk.py:119); the device controller starts its row counter after them
-        d = -1 if t_host[1] < t_host[0] else 1
-        e = 1
-        while e < len(t_host) and d * t_host[e] <= d * t_host[0]:
-            solution[e] = y0
-            e += 1
-        if e < len(t_host):
-            self._run(solution)
+        try:
+            self._before_integrate(t_host)
+            # rows whose time equals the start time need no step (`while next_t > rk_state.t1` is false at once,
+            # base_adaptive_solver_rk.py:119); the device controller starts its row counter after them
+            d = -1 if t_host[1] < t_host[0] else 1
+            e = 1
+            while e < len(t_host) and d * t_host[e] <= d * t_host[0]:
+                solution[e] = y0
+                e += 1
+            if e < len(t_host):
+                self._run(solution)
+        finally:
+            self._after_integrate()
         return solution
+
+    def _after_integrate(self):
+        """Hook: the solve has ended (normally or by an assertion); solvers are single-use, as in the reference."""
 
     # base_adaptive_solver.py:33-72
     def select_initial_step(self, t0, y0, order, rtol, atol, f0=None):

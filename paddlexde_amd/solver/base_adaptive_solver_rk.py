@@ -50,6 +50,47 @@ def _nz_plan(coefs, upto=None):
     return idx, _hip.dbl_array([float(coefs[j]) for j in idx])  # marshalled once: the C double[] the kernels take
 
 
+_PLANS = {}
+
+
+def _build_plans(tab, mid):
+    """Operand plans of a tableau: only non-zero entries are read."""
+    n_stage = len(tab.alpha)
+    stage_plan = [_nz_plan(beta, upto=i + 1) for i, beta in enumerate(tab.beta)]
+    c_sol = [float(c) for c in tab.c_sol]
+    last_beta = [float(b) for b in tab.beta[-1]]
+    # :172-176 "This property (true for Dormand-Prince) lets us save a few FLOPs."
+    fsal = c_sol[-1] == 0 and c_sol[:-1] == last_beta
+    sol_plan = _nz_plan(c_sol)
+    err_plan = _nz_plan(tab.c_error)
+    mid_plan = _nz_plan(mid)
+    # Error-estimate fusion: if the last stage (whose output is y1, FSAL) loads every operand the error estimate
+    # needs except the last derivative, it emits the partial sum as a second output and the error-norm kernel
+    # reads {e_partial, k_last, y0, y1} instead of all the k's (Dopri5: 8N -> 4N + 1N written).
+    last_idx = stage_plan[-1][0]
+    err_idx = err_plan[0]
+    S = n_stage
+    fuse_err = fsal and err_idx[-1] == S and set(err_idx[:-1]) <= set(last_idx) and float(tab.c_error[S]) != 0.0
+    err2_coef = _hip.dbl_array([float(tab.c_error[j]) for j in last_idx]) if fuse_err else None
+    # cache-policy hint per stage: bit p set = operand p of that stage's list is read there for the last time in an
+    # accepted step (later readers: stages, the unfused error estimate; dense output is rare and lazy)
+    last_use = {}
+    for i, (idx_i, _) in enumerate(stage_plan):
+        for j in idx_i:
+            last_use[j] = i
+    later = set(sol_plan[0]) if not fsal else set()
+    if not fuse_err:
+        later |= set(err_plan[0])
+    stage_nt = []
+    for i, (idx_i, _) in enumerate(stage_plan):
+        m = 0
+        for pos, j in enumerate(idx_i):
+            if last_use[j] == i and j not in later:
+                m |= 1 << pos
+        stage_nt.append(m)
+    return n_stage, stage_plan, fsal, sol_plan, err_plan, mid_plan, fuse_err, err2_coef, stage_nt
+
+
 class AdaptiveRKSolver(AdaptiveSolver):
     order: int
     tableau: _ButcherTableau
@@ -123,44 +164,12 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self.nfe = 0
         self.stats = {}
 
-        # -- operand plans: only non-zero tableau entries are read ---------------------------------
-        tab = self.tableau
-        self._n_stage = len(tab.alpha)
-        self._stage_plan = [_nz_plan(beta, upto=i + 1) for i, beta in enumerate(tab.beta)]
-        c_sol = [float(c) for c in tab.c_sol]
-        last_beta = [float(b) for b in tab.beta[-1]]
-        # :172-176 "This property (true for Dormand-Prince) lets us save a few FLOPs."
-        self._fsal = c_sol[-1] == 0 and c_sol[:-1] == last_beta
-        self._sol_plan = _nz_plan(c_sol)
-        self._err_plan = _nz_plan(tab.c_error)
-        self._mid_plan = _nz_plan(self.mid)
-        # Error-estimate fusion: if the last stage (whose output is y1, FSAL) loads every operand the error estimate
-        # needs except the last derivative, it emits the partial sum as a second output and the error-norm kernel
-        # reads {e_partial, k_last, y0, y1} instead of all the k's (Dopri5: 8N -> 4N + 1N written).
-        last_idx = self._stage_plan[-1][0]
-        err_idx = self._err_plan[0]
-        S = self._n_stage
-        self._fuse_err = (
-            self._fsal and err_idx[-1] == S and set(err_idx[:-1]) <= set(last_idx) and float(tab.c_error[S]) != 0.0
-        )
-        if self._fuse_err:
-            self._err2_coef = _hip.dbl_array([float(tab.c_error[j]) for j in last_idx])
-        # cache-policy hint per stage: bit p set = operand p of that stage's list is read there for the last time in an
-        # accepted step (later readers: stages, the unfused error estimate; dense output is rare and lazy)
-        last_use = {}
-        for i, (idx_i, _) in enumerate(self._stage_plan):
-            for j in idx_i:
-                last_use[j] = i
-        later = set(self._sol_plan[0]) if not self._fsal else set()
-        if not self._fuse_err:
-            later |= set(self._err_plan[0])
-        self._stage_nt = []
-        for i, (idx_i, _) in enumerate(self._stage_plan):
-            m = 0
-            for pos, j in enumerate(idx_i):
-                if last_use[j] == i and j not in later:
-                    m |= 1 << pos
-            self._stage_nt.append(m)
+        # -- operand plans (a function of the tableau only: built once per solver class) ---------------
+        plans = _PLANS.get(type(self))
+        if plans is None:
+            plans = _PLANS[type(self)] = _build_plans(self.tableau, self.mid)
+        (self._n_stage, self._stage_plan, self._fsal, self._sol_plan, self._err_plan, self._mid_plan, self._fuse_err,
+         self._err2_coef, self._stage_nt) = plans
 
         # -- segments / norm ---------------------------------------------------------------------
         n = self.y0.numel()
@@ -284,11 +293,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._direction = -1 if t_span[1] < t_span[0] else 1
         self._t_host = t_span
         self._t_span_dev = upload(t_span.astype(np.float64), dev)
-        self._t_stage = torch.zeros(_hip.XDE_MAX_STAGE, dtype=y0.dtype, device=dev)
+        self._work = w = be.acquire_work(dev, y0.dtype)  # recycled by integrate() when the solve has ended
+        self._t_stage, self._ctrl, self._ws, self._sums = w.t_stage, w.ctrl, w.ws, w.sums
         self._t_views = [self._t_stage[i] for i in range(self._n_stage)]  # the 0-dim stage times handed to func
-        self._ctrl = be.new_ctrl(dev)
-        self._ws = be.new_workspace(dev)
-        self._sums = be.new_sums(dev)
         self._seg_count = self._global_counts()
         self._scratch = torch.empty_like(y0)
         # the partial error sum of the last stage goes into the stage scratch buffer: by then the previous stage's
@@ -342,6 +349,11 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self.rk_state = _RungeKuttaState(y0, f0, t_span[0], t_span[0], first_step, None)
         be.ctrl_init(self._ctrl, p, float(t_span[0]), 0.0 if first_step is None else float(d * abs(first_step)), len(t_span),
                      self._t_span_dev, self._step_t_dev, self._t_stage, first_step_dev=first_dev)
+
+    def _after_integrate(self):
+        w, self._work = getattr(self, "_work", None), None
+        if w is not None and self.pipeline != "graph":  # a captured graph keeps addressing its buffers
+            self.backend.release_work(w)
 
     def _select_initial_step_device(self, t0, y0):
         """``select_initial_step`` (base_adaptive_solver.py:33-72) with its scalar arithmetic on the device: the three

@@ -41,6 +41,16 @@ class NumpyDoubleBackend:
     def new_sums(self, device):
         return torch.zeros(2 * _hip.XDE_MAX_SEG, dtype=torch.float64)
 
+    def acquire_work(self, device, state_dtype):
+        w = _hip._Work()
+        w.key = None
+        w.ctrl, w.ws, w.sums = self.new_ctrl(device), self.new_workspace(device), self.new_sums(device)
+        w.t_stage = torch.zeros(_hip.XDE_MAX_STAGE, dtype=state_dtype)
+        return w
+
+    def release_work(self, w):
+        pass
+
     @staticmethod
     def _c(ctrl) -> XdeCtrl:
         return XdeCtrl.from_buffer(ctrl.numpy())
