@@ -116,12 +116,18 @@ def enable_tunable_op(on):
 
         tunable.enable(True)
         tunable.tuning_enable(True)
-        tunable.write_file_on_exit(False)
-        tunable.set_max_tuning_duration(30)
-        tunable.set_max_tuning_iterations(50)
-        return True
     except Exception:
         return False
+    import tempfile
+
+    for call, arg in (("write_file_on_exit", False),  # (not in every release)
+                      ("set_filename", os.path.join(tempfile.gettempdir(), "xde_bench_tunableop.csv")),  # keep the tree clean
+                      ("set_max_tuning_duration", 30), ("set_max_tuning_iterations", 50)):
+        try:
+            getattr(tunable, call)(arg)
+        except Exception:
+            pass
+    return True
 
 
 def side_workload(args):
