@@ -139,6 +139,36 @@ def side_workload(args):
     from paddlexde_amd.xde import BaseODE
 
     dev = torch.device("cuda", 0)
+    if args.workload == "c1":
+        # BASELINE.json configs[0]: example/ode_demo.py's data generation (demo_utils.py:136-164) — spiral y' = (y^3) A,
+        # y0 = [[2, 0]], t = linspace(0, 25, 1000), the reference's RK4.  Plumbing: 999 steps of a 2-element state.
+        from oracle import xde_oracle as O  # checker only: the GPU trajectory must equal the oracle's bit for bit
+        from paddlexde_amd import RK4, odeint
+        from paddlexde_amd.utils import GraphedFunc
+
+        A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]])
+        An = A.numpy()
+        y0 = torch.tensor([[2.0, 0.0]])
+        t = torch.linspace(0.0, 25.0, 1000)
+        Ad = A.to(dev)
+        res = {}
+        for label, func in (("eager func", lambda t_, y: (y * y * y) @ Ad), ("GraphedFunc(func)", GraphedFunc(lambda t_, y: (y * y * y) @ Ad))):
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    sol = odeint(func, y0.to(dev), t.to(dev), solver=RK4)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            res[label] = {"seconds": el, "us_per_step": 1e6 * el / 999, "shape": list(sol.shape)}
+            last = sol
+        t0 = time.perf_counter()
+        ref = O.odeint(lambda t_, y: (y * y * y) @ An, y0.numpy(), t.numpy(), "rk4")
+        res["cpu_baseline"] = {"seconds": time.perf_counter() - t0, "kind": "port", "cores": 1, "sample": "the whole trajectory, numpy oracle"}
+        res["bit_exact_vs_oracle"] = bool(np.array_equal(last.cpu().numpy(), ref))
+        print(json.dumps({"metric": "seconds for the 1000-point spiral trajectory (launch-latency-bound plumbing)", "workload": "c1: "
+                          "example/ode_demo.py spiral, RK4 (reference variant), batch 1 x dim 2, 999 steps", "results": res}))
+        return
     if args.workload == "c5":
         mu = 1000.0
 
@@ -233,8 +263,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="state dtype (the headline metric is quoted on f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-func", action="store_true", help="c3: replay the augmented dynamics from a captured HIP graph")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
-                    help="c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"],
+                    help="c1: configs[0], the demo's 1000-point spiral with RK4 (plumbing); c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
                          "batch 8192 (latency-bound, reports ms per fwd+bwd and per attempted step); c5: stiff Van der Pol "
                          "mu=1000 batch 4096 (step-rejection stress, reports accepted/rejected and us per step)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing")
