@@ -133,15 +133,14 @@ class FixedSolver(metaclass=abc.ABCMeta):
         # (values rounded to the time dtype on the host, as t_span.astype would; no blocking pageable copy)
         t_dev = t_span.detach().to(device=y0.device, dtype=t_dtype) if t_span.is_cuda else upload(t_host, y0.device)
 
-        # one upload: per step [t-like values the step passes to move()]
-        rows = []
-        for i in range(1, pred_len):
-            t0h = t_host[i - 1]
-            dt = t_host[i] - t_host[i - 1]
-            rows.append([t0h + v if is_time else v for v, is_time in self._time_values_tagged(dt)])
+        # one upload: per step [t-like values the step passes to move()], computed for all steps at once (element-wise numpy
+        # arithmetic in the time dtype gives the values the per-step scalar expressions give)
         table = None
-        if rows and len(rows[0]):
-            table = upload(np.asarray(rows, dtype=np_dtype(t_dtype)), y0.device)
+        if pred_len > 1:
+            dts = t_host[1:] - t_host[:-1]
+            cols = [np.broadcast_to(t_host[:-1] + v if is_time else v, dts.shape) for v, is_time in self._time_values_tagged(dts)]
+            if cols:
+                table = upload(np.stack(cols, axis=1).astype(np_dtype(t_dtype)), y0.device)
 
         tracking = torch.is_grad_enabled() and y0.requires_grad
         y0 = as_operand(y0 if tracking else y0.detach())
