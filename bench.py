@@ -152,12 +152,16 @@ def side_workload(args):
         t = torch.linspace(0.0, 25.0, 1000)
         Ad = A.to(dev)
         res = {}
-        for label, func in (("eager func", lambda t_, y: (y * y * y) @ Ad), ("GraphedFunc(func)", GraphedFunc(lambda t_, y: (y * y * y) @ Ad))):
+        from paddlexde_amd.utils import _rms_norm
+
+        plain = lambda t_, y: (y * y * y) @ Ad  # noqa: E731
+        for label, func, pipeline in (("eager", plain, "sync"), ("GraphedFunc(func)", GraphedFunc(plain), "sync"),
+                                      ("pipeline=graph (one captured step, replayed)", plain, "graph")):
             for rep in range(2):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 with torch.no_grad():
-                    sol = odeint(func, y0.to(dev), t.to(dev), solver=RK4)
+                    sol = odeint(func, y0.to(dev), t.to(dev), solver=RK4, options={"norm": _rms_norm, "pipeline": pipeline})
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
             res[label] = {"seconds": el, "us_per_step": 1e6 * el / 999, "shape": list(sol.shape)}

@@ -10,6 +10,8 @@ eager ops.  Here the whole table of stage times is computed once on the host, in
 with the reference's op order, and uploaded once; ``func`` receives shape-``[1]`` device views of it.
 """
 import abc
+import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -28,13 +30,22 @@ _one_sixth = 1 / 6
 class FixedSolver(metaclass=abc.ABCMeta):
     order: int
 
-    def __init__(self, xde, y0, step_size=None, grid_constructor=None, interp="linear", perturb=False, **kwargs):
+    graphable = True  # the step's control flow does not depend on data (False: AdamsBashforthMoulton)
+    GRAPH_MIN_STEPS = 4
+
+    def __init__(self, xde, y0, step_size=None, grid_constructor=None, interp="linear", perturb=False, pipeline="sync", **kwargs):
         self.xde = xde
         self.y0 = y0
         self.dtype = y0.dtype
         self.step_size = step_size
         self.interp = interp
         self.perturb = perturb
+        if pipeline not in ("sync", "lag", "graph"):
+            raise ValueError("pipeline must be 'sync' or 'graph' ('lag' means 'sync' for a fixed grid)")
+        self.pipeline = pipeline
+        self._g_ctrls = None  # graph pipeline: device dt sources of the step's combines, in call order
+        self._g_slot = 0
+        self._rec = None  # recording pass: the dt every combine of a step receives, for all steps at once
 
         # base_fixed_solver.py:45-47 — KeyError when absent, as in the reference
         self.atol = kwargs["atol"]
@@ -71,6 +82,8 @@ class FixedSolver(metaclass=abc.ABCMeta):
 
     # -- framework call -----------------------------------------------------------------------
     def _f(self, t, dt, y):
+        if self._rec is not None:
+            return None
         self.nfe += 1
         f = self.move(t, dt, y)
         f = as_operand(f, like=y)
@@ -79,7 +92,17 @@ class FixedSolver(metaclass=abc.ABCMeta):
         return f
 
     def _combine(self, y0, ks, coef, mode, dt, scale=1.0, out=None):
+        if self._rec is not None:
+            self._rec.append(dt)
+            return None
         damp = self._damping if mode != _hip.COMBINE_RK else 0.0
+        if self._g_ctrls is not None:  # graph pipeline: dt is read from device memory (rewritten before every replay)
+            ctrl = self._g_ctrls[self._g_slot]
+            self._g_slot += 1
+            if out is None:
+                out = torch.empty_like(y0)
+            self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, ctrl=ctrl, damping=damp)
+            return out
         if torch.is_grad_enabled() and (y0.requires_grad or any(k.requires_grad for k in ks)):
             # discretise-then-optimise: keep the autograd graph through the combine
             return CombineFn.apply(self.backend, list(coef), mode, scale, float(dt), damp, y0, *ks)
@@ -150,6 +173,11 @@ class FixedSolver(metaclass=abc.ABCMeta):
         direct = (int(np.prod(lead)) == 1) if len(lead) else True  # output rows are contiguous slices
         out.narrow(-2, 0, L).copy_(y0)
 
+        if (self.pipeline == "graph" and self.graphable and not tracking and not torch.is_grad_enabled() and table is not None
+                and y0.is_cuda and self.interp != "cubic" and pred_len - 1 >= self.GRAPH_MIN_STEPS
+                and threading.current_thread() is threading.main_thread() and not torch.cuda.is_current_stream_capturing()):
+            return self._integrate_graph(t_host, t_dev, table, y0, out, L)
+
         try:
             for i in range(1, pred_len):
                 t0, t1 = t_dev[i - 1 : i], t_dev[i : i + 1]
@@ -176,6 +204,70 @@ class FixedSolver(metaclass=abc.ABCMeta):
             self._t0_host = None
             self._row = None
             self._y1_out = None
+        return out
+
+    # -- hipGraph pipeline: one captured step, replayed over the grid ------------------------------------------------
+    def _record_combine_dts(self, dts):
+        """The ``dt`` argument of every ``_combine`` call of one step, in call order, as arrays over all steps: ``step`` is
+        run once on the ARRAY of step sizes with ``func`` and the kernels switched off (its host arithmetic is element-wise
+        numpy in the time dtype, so each entry is the scalar the eager loop would pass)."""
+        self._rec, self._dt, self._t0_host = [], dts, None
+        row = torch.zeros(max(len(self._time_values(dts[:1])), 1))
+        self._row = row
+        try:
+            self.step(row[0:1], row[0:1], None)
+            return [np.broadcast_to(np.asarray(v), dts.shape).astype(np.float64) for v in self._rec]
+        finally:
+            self._rec, self._dt, self._row = None, None, None
+
+    def _integrate_graph(self, t_host, t_dev, table, y0, out, L):
+        """``options={"pipeline": "graph"}`` (no autograd, data-independent step): the first step runs eagerly, then ONE step
+        — the combines, the framework ops of ``func``, the state hand-over — is captured into a hipGraph and replayed; per
+        step the host rewrites the step's times and step sizes in device memory (two small copies) and stores the row.
+        Same kernels, same operands: bit-identical to the eager loop.  For launch-latency-bound (small) states."""
+        be = self.backend
+        dev = y0.device
+        n_steps = len(t_host) - 1
+        dts = t_host[1:] - t_host[:-1]
+        dt_table = upload(np.stack(self._record_combine_dts(dts), axis=1), dev)  # [n_steps, K] fp64
+        K = dt_table.shape[1]
+        nb = C.sizeof(_hip.XdeCtrl)
+        ctrls = torch.zeros(K * nb, dtype=torch.uint8, device=dev)
+        ctrl_dt = ctrls.view(torch.float64).view(K, nb // 8)[:, 2]  # the `dt` field of each control block
+        ctrl_list = [ctrls[k * nb : (k + 1) * nb] for k in range(K)]
+        times = torch.cat([t_dev[:-1, None], t_dev[1:, None], table], dim=1).contiguous()  # per step: t0, t1, stage times
+        row = torch.empty(times.shape[1], dtype=times.dtype, device=dev)
+        y_cur, y_next = y0.clone(), torch.empty_like(y0)
+
+        def body():
+            self._row, self._y1_out, self._g_ctrls, self._g_slot = row[2:], y_next, ctrl_list, 0
+            self._dt, self._t0_host = dts[0], t_host[0]  # placeholders: every dt the kernels use comes from `ctrls`
+            try:
+                y1, _ = self.step(row[0:1], row[1:2], y_cur)
+            finally:
+                self._row = self._y1_out = self._g_ctrls = self._dt = self._t0_host = None
+            if y1.data_ptr() != y_next.data_ptr():
+                y_next.copy_(y1)
+            y_cur.copy_(y_next)
+
+        def load(i):
+            row.copy_(times[i])
+            ctrl_dt.copy_(dt_table[i])
+
+        nfe0 = self.nfe
+        load(0)
+        body()  # step 1, eagerly (warm-up of func and of the allocator)
+        out.narrow(-2, L, L).copy_(y_cur)
+        per_step = self.nfe - nfe0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+        self.nfe = nfe0 + per_step  # recording executes nothing
+        for i in range(1, n_steps):
+            load(i)
+            g.replay()
+            out.narrow(-2, (i + 1) * L, L).copy_(y_cur)
+            self.nfe += per_step
         return out
 
     def _time_values_tagged(self, dt):

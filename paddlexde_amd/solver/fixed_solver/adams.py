@@ -28,6 +28,7 @@ _MAX_ITERS = 4
 
 
 class AdamsBashforthMoulton(FixedSolver):
+    graphable = False  # the corrector iterates until a data-dependent convergence test passes
     order = 4
 
     def __init__(self, xde, y0, rtol=1e-3, atol=1e-4, implicit=False, max_iters=_MAX_ITERS, max_order=_MAX_ORDER, **kwargs):

@@ -13,6 +13,8 @@ class RK4(FixedSolver):
         if variant not in ("alt", "classic"):
             raise ValueError("variant must be 'alt' (reference) or 'classic'")
         self.variant = variant
+        # the classical variant builds its stage times as per-step constants (no table row): not replayable from a graph
+        self.graphable = variant == "alt"
 
     @staticmethod
     def _time_values(dt):

@@ -210,3 +210,19 @@ def test_randomised_ddeint_sweep_vs_oracle(dev, block):
         ref2, _ = O.ddeint(f_np, y0, t, None, yl, None, solver, his_processed=True)
         got2, _ = ddeint(f_np, tt(y0), tt(t), None, tt(yl), None, SOLVERS[solver], his_processed=True)
         assert np.array_equal(got2.cpu().numpy(), ref2), tag
+
+
+def test_ddeint_graph_pipeline_is_bitwise_equal_to_eager(dev):
+    """The D3STN-style caller with options["pipeline"] = "graph": damped fuse, delayed states fixed during the solve."""
+    rng = np.random.RandomState(4)
+    y0 = rng.randn(6, 4).astype(np.float32)
+    y_lags = rng.randn(6, 5, 4).astype(np.float32)
+    t = np.linspace(0.0, 1.0, 25).astype(np.float32)
+    from paddlexde_amd.utils import _rms_norm
+
+    with torch.no_grad():
+        a, _ = ddeint(_dde_func_t, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), None, torch.from_numpy(y_lags).to(dev), None, RK4,
+                      his_processed=True)
+        b, _ = ddeint(_dde_func_t, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), None, torch.from_numpy(y_lags).to(dev), None, RK4,
+                      his_processed=True, options={"norm": _rms_norm, "pipeline": "graph"})
+    assert torch.equal(a, b)

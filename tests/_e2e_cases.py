@@ -938,3 +938,55 @@ def test_randomised_tuple_state_sweep_vs_oracle(dev, block):
         for g, r, sh in zip(got, ref, shapes):
             assert tuple(g.shape) == r.shape == (T,) + sh, tag
             assert P.parity_ok(g.cpu().numpy(), r, 1e-9, 1e-11), (tag, P.worst(g.cpu().numpy(), r, 1e-9, 1e-11))
+
+
+# ----------------------------------------------------------------------------------------------
+# fixed solvers: hipGraph pipeline (one captured step replayed over the grid)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,variant", [("euler", None), ("midpoint", None), ("rk4", "alt"), ("rk4", "classic"), ("adams", None)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_fixed_graph_pipeline_is_bitwise_equal_to_eager(dev, name, variant, dtype):
+    """options={"pipeline": "graph"}: same kernels on the same operands, dt and the stage times read from device memory
+    — bit-identical trajectory and the same NFE (Adams, whose step is data-dependent, silently stays eager; so does the
+    CPU double, which has nothing to capture)."""
+    from paddlexde_amd.xde import BaseODE
+
+    rng = np.random.RandomState(12)
+    y0 = torch.from_numpy(rng.uniform(-1, 1, size=(3, 2, 5))).to(dtype).to(dev)
+    t = torch.from_numpy(np.cumsum(rng.uniform(0.01, 0.04, size=37))).to(dtype)
+    w = torch.from_numpy(rng.uniform(-1, 1, size=(5,))).to(dtype).to(dev)
+
+    def f(t_, y):
+        return -0.5 * y - 0.1 * (y * y * y) + w * t_ + 0.25 * (y * w)
+
+    runs = {}
+    for pipeline in ("sync", "graph"):
+        kw = {"variant": variant} if variant else {}
+        with torch.no_grad():
+            s = FIXED[name](xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-3, atol=1e-4, norm=_rms_norm, pipeline=pipeline, **kw)
+            runs[pipeline] = (s.integrate(t), s.nfe)
+    assert runs["graph"][0].shape == (3, 37 * 2, 5)
+    assert torch.allclose(runs["sync"][0], runs["graph"][0], rtol=0, atol=0, equal_nan=True)  # bit for bit
+    assert torch.isfinite(runs["sync"][0]).all() or name == "adams"  # (high-order Adams on this uneven grid may blow up)
+    assert runs["sync"][1] == runs["graph"][1]
+
+
+def test_fixed_graph_pipeline_records_the_step_sizes_of_every_combine(dev):
+    from paddlexde_amd.xde import BaseODE
+
+    y0 = torch.zeros(1, 2, device=dev)
+    t = np.cumsum(np.random.RandomState(0).uniform(0.01, 0.04, size=9)).astype(np.float32)
+    dts = t[1:] - t[:-1]
+    expect = {
+        ("euler", None): [dts],
+        ("midpoint", None): [np.float32(0.5) * dts, dts],
+        ("rk4", "alt"): [dts * (1 / 3), dts, dts, dts],
+    }
+    for (name, variant), cols in expect.items():
+        kw = {"variant": variant} if variant else {}
+        s = FIXED[name](xde=BaseODE(lambda t_, y: y, y0=y0, t_span=torch.from_numpy(t)), y0=y0, rtol=1e-3, atol=1e-4, norm=_rms_norm, **kw)
+        got = s._record_combine_dts(dts)
+        assert len(got) == len(cols)
+        for g, c in zip(got, cols):
+            assert g.dtype == np.float64 and np.array_equal(g, c.astype(np.float64)), (name, variant)
+        assert s._rec is None and s._dt is None and s.nfe == 0
