@@ -237,6 +237,8 @@ def side_workload(args):
             if name == "dopri5":
                 opts["pipeline"] = args.pipeline
             aopts = {k: v for k, v in opts.items() if k != "norm"}
+            if name == "rk4":
+                opts["pipeline"] = "graph"  # forward: one captured RK4 step replayed over the 31 intervals
             if "pipeline" in aopts:
                 aopts["pipeline"] = "sync"  # adjoint intervals are 1-3 steps long: speculation would waste an attempt each
             if args.graph_func:

@@ -325,6 +325,15 @@ int xde_commit(const xde_ctrl_t* ctrl, void* y0_dst, const void* y1_src, void* f
                int64_t n, int dtype, void* stream);
 
 /*
+ * ROCm 7.2 work-around, for callers that capture this library's launches together with framework ops into a hipGraph:
+ * MEMSET nodes do not hold their place in a graph there (PyTorch's multi-block reductions capture one; replayed among
+ * ordinary stream work such a graph returns the previous replay's result in a large fraction of launches).  This call
+ * replaces every memset node of a captured, not yet instantiated hipGraph_t by an equivalent fill-kernel node with the same
+ * dependencies and dependents.  *n_replaced = how many there were.
+ */
+int xde_graph_replace_memsets(void* hip_graph, int* n_replaced);
+
+/*
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline figure).  xde_prof_enable(period): 0 = off; p >= 1 = every p-th launch of each kernel id is
  * launched with a start/stop event pair stamped by the dispatch itself (hipExtLaunchKernelGGL), so the

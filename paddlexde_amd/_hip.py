@@ -47,6 +47,7 @@ SYMBOLS = (
     "xde_commit",
     "xde_hermite_gather",
     "xde_scale_fanout",
+    "xde_graph_replace_memsets",
     "xde_prof_enable",
     "xde_prof_collect",
 )
@@ -198,6 +199,8 @@ def load_library():
         lib.xde_hermite_gather.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
         lib.xde_commit.restype = i32
         lib.xde_commit.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
+        lib.xde_graph_replace_memsets.restype = i32
+        lib.xde_graph_replace_memsets.argtypes = [vp, C.POINTER(C.c_int)]
         lib.xde_prof_enable.restype = i32
         lib.xde_prof_enable.argtypes = [i32]
         lib.xde_prof_collect.restype = i32
@@ -319,7 +322,7 @@ class HipBackend:
     def acquire_work(self, device, state_dtype):
         key = (device.index, state_dtype, self._stream_of(device))
         pool = self._work_pool.setdefault(key, [])
-        if pool:
+        if pool and os.environ.get("XDE_NO_POOL", "0") != "1":
             return pool.pop()
         w = _Work()
         w.key = key
@@ -506,13 +509,16 @@ class HipBackend:
 
     def capture(self, body, ctrl):
         """Record ``body()`` (kernels of this library + the framework ops of the user's func) into a hipGraph."""
-        g = torch.cuda.CUDAGraph()
+        from .utils.graphed import CapturedGraph
+
+        g = CapturedGraph()  # (replays of a graph that holds memset nodes are synchronised: see its docstring)
         self._capturing = True
         try:
-            with torch.cuda.graph(g):
+            with g.capture():
                 body()
         finally:
             self._capturing = False
+        g.finish()
         return HipBackend._Graph(self, g, ctrl)
 
     # -- profiling ---------------------------------------------------------------------------

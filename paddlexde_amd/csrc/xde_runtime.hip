@@ -50,7 +50,78 @@ hipEvent_t get_event() {
 
 using namespace xde;
 
+namespace {
+
+// Zero-fill (or pattern-fill) kernel that stands in for a hipGraph MEMSET node: same destination, element size, width,
+// height and pitch as the hipMemsetParams it replaces.
+__global__ void xde_graph_fill_kernel(unsigned char* dst, unsigned int value, unsigned int elem, size_t width, size_t height,
+                                      size_t pitch) {
+  const size_t total = width * height;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x) {
+    const size_t r = i / width, c = i - r * width;
+    unsigned char* p = dst + r * pitch + c * elem;
+    if (elem == 4)
+      *reinterpret_cast<unsigned int*>(p) = value;
+    else if (elem == 2)
+      *reinterpret_cast<unsigned short*>(p) = static_cast<unsigned short>(value);
+    else
+      *p = static_cast<unsigned char>(value);
+  }
+}
+
+}  // namespace
+
 extern "C" {
+
+int xde_graph_replace_memsets(void* graph_v, int* n_replaced) {
+  if (!graph_v || !n_replaced) return fail(XDE_EBADARG, "xde_graph_replace_memsets: null pointer");
+  hipGraph_t graph = static_cast<hipGraph_t>(graph_v);
+  *n_replaced = 0;
+  size_t n = 0;
+  HIP_TRY(hipGraphGetNodes(graph, nullptr, &n));
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n) HIP_TRY(hipGraphGetNodes(graph, nodes.data(), &n));
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType type;
+    HIP_TRY(hipGraphNodeGetType(nodes[i], &type));
+    if (type != hipGraphNodeTypeMemset) continue;
+    hipMemsetParams mp;
+    HIP_TRY(hipGraphMemsetNodeGetParams(nodes[i], &mp));
+    if (mp.elementSize != 1 && mp.elementSize != 2 && mp.elementSize != 4)
+      return fail(XDE_EBADARG, "xde_graph_replace_memsets: unsupported memset element size");
+    size_t nd = 0, nc = 0;
+    HIP_TRY(hipGraphNodeGetDependencies(nodes[i], nullptr, &nd));
+    std::vector<hipGraphNode_t> deps(nd);
+    if (nd) HIP_TRY(hipGraphNodeGetDependencies(nodes[i], deps.data(), &nd));
+    HIP_TRY(hipGraphNodeGetDependentNodes(nodes[i], nullptr, &nc));
+    std::vector<hipGraphNode_t> children(nc);
+    if (nc) HIP_TRY(hipGraphNodeGetDependentNodes(nodes[i], children.data(), &nc));
+
+    unsigned char* dst = static_cast<unsigned char*>(mp.dst);
+    unsigned int value = mp.value;
+    unsigned int elem = mp.elementSize;
+    size_t width = mp.width, height = mp.height ? mp.height : 1, pitch = mp.pitch;
+    void* args[] = {&dst, &value, &elem, &width, &height, &pitch};
+    const size_t total = width * height;
+    unsigned int blocks = static_cast<unsigned int>((total + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipKernelNodeParams kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.func = reinterpret_cast<void*>(xde_graph_fill_kernel);
+    kp.gridDim = dim3(blocks);
+    kp.blockDim = dim3(256);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = args;
+    kp.extra = nullptr;
+    hipGraphNode_t fill;
+    HIP_TRY(hipGraphAddKernelNode(&fill, graph, nd ? deps.data() : nullptr, nd, &kp));
+    for (size_t c = 0; c < nc; ++c) HIP_TRY(hipGraphAddDependencies(graph, &fill, &children[c], 1));
+    HIP_TRY(hipGraphDestroyNode(nodes[i]));
+    ++*n_replaced;
+  }
+  return XDE_OK;
+}
 
 const char* xde_last_error(void) { return g_last_error.c_str(); }
 int xde_abi_version(void) { return XDE_ABI_VERSION; }

@@ -259,9 +259,12 @@ class FixedSolver(metaclass=abc.ABCMeta):
         body()  # step 1, eagerly (warm-up of func and of the allocator)
         out.narrow(-2, L, L).copy_(y_cur)
         per_step = self.nfe - nfe0
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from ..utils.graphed import CapturedGraph
+
+        g = CapturedGraph()  # (replays of a graph that holds memset nodes are synchronised: see its docstring)
+        with g.capture():
             body()
+        g.finish()
         self.nfe = nfe0 + per_step  # recording executes nothing
         for i in range(1, n_steps):
             load(i)

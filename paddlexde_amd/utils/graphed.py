@@ -13,9 +13,91 @@ runtime, so off the main thread an unseen signature is simply evaluated eagerly.
 The adjoint's augmented dynamics (functional/odeint_adjoint.py:89-124: func + vjp through autograd) is the main
 customer: ``odeint_adjoint(..., adjoint_options={"graph_func": True})`` pre-captures it in ``forward``.
 """
+import ctypes as C
 import threading
 
 import torch
+
+# hipGraphNodeType
+_NODE_KERNEL, _NODE_MEMCPY, _NODE_MEMSET = 0, 1, 2
+_hip_rt = None
+
+
+def _node_types(graph):
+    """Node types of a captured (kept) graph, through the HIP runtime the process already has loaded."""
+    global _hip_rt
+    if _hip_rt is None:
+        _hip_rt = C.CDLL("libamdhip64.so")
+    raw = C.c_void_p(graph.raw_cuda_graph())
+    n = C.c_size_t(0)
+    if _hip_rt.hipGraphGetNodes(raw, None, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (C.c_void_p * max(n.value, 1))()
+    if _hip_rt.hipGraphGetNodes(raw, nodes, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    out = []
+    for i in range(n.value):
+        t = C.c_int(-1)
+        if _hip_rt.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(t)) != 0:
+            raise RuntimeError("hipGraphNodeGetType failed")
+        out.append(t.value)
+    return out
+
+
+class CapturedGraph:
+    """A captured HIP graph plus the one thing that has to be known about it before replaying it on ROCm 7.2:
+
+    hipGraph MEMSET nodes do not hold their place in the graph.  PyTorch's multi-block reductions zero a semaphore with
+    ``hipMemsetAsync`` (``x.sum(0)`` of an [8192, 50] tensor is [memset, kernel]); captured and replayed with ordinary stream
+    work around it, such a graph returns the PREVIOUS replay's result in a large fraction of launches (59-163 of 300 in a
+    two-node graph; an event recorded after the launch does not cover it, ``hipStreamSynchronize`` does).  In
+    ``odeint_adjoint(..., graph_func=True)`` that was a stale bias gradient, 3.6e-3 off, from the second call on.  Graphs of
+    kernel (and copy) nodes only — every graph this package's own kernels make — replay correctly by the thousand.
+
+    So: the node types are read back after capture (``hipGraphGetNodes``) and every memset node is replaced, before the graph
+    is instantiated, by a fill-KERNEL node with the same destination, pattern, dependencies and dependents
+    (``xde_graph_replace_memsets`` in libxde_hip.so).  Should that fail, or the nodes be out of reach (an older PyTorch), the
+    graph is replayed in safe mode: a stream synchronise after every launch."""
+
+    def __init__(self):
+        try:
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+            self._kept = True
+        except TypeError:  # an older PyTorch: no handle on the captured graph
+            self.graph = torch.cuda.CUDAGraph()
+            self._kept = False
+        self.safe_mode = True
+        self.node_types = None
+        self.memsets_replaced = 0
+
+    def capture(self, **kwargs):
+        """Context manager: ``with cg.capture(): ...`` records into the graph; call ``finish()`` afterwards."""
+        return torch.cuda.graph(self.graph, **kwargs)
+
+    def finish(self):
+        if self._kept:
+            try:
+                self.node_types = _node_types(self.graph)
+                if _NODE_MEMSET in self.node_types:
+                    # surgery: every memset node becomes a fill-kernel node with the same edges (xde_graph_replace_memsets)
+                    from .. import _hip
+
+                    n = C.c_int(0)
+                    lib = _hip.load_library()
+                    if lib.xde_graph_replace_memsets(C.c_void_p(self.graph.raw_cuda_graph()), C.byref(n)) != 0:
+                        raise RuntimeError(lib.xde_last_error().decode())
+                    self.memsets_replaced = n.value
+                    self.node_types = _node_types(self.graph)
+                self.safe_mode = _NODE_MEMSET in self.node_types
+            except Exception:
+                self.safe_mode = True
+            self.graph.instantiate()
+        return self
+
+    def replay(self):
+        self.graph.replay()
+        if self.safe_mode:
+            torch.cuda.current_stream().synchronize()
 
 
 def _map(x, fn):
@@ -37,6 +119,7 @@ class GraphedFunc:
         self.replays = 0
         self.captures = 0
         self.eager_calls = 0
+        self.safe_mode = False  # True once a capture holds a memset node (see CapturedGraph): replays are synchronised
 
     @staticmethod
     def _signature(t, y):
@@ -65,9 +148,11 @@ class GraphedFunc:
                     self.func(c.t, c.y)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            c.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(c.graph, capture_error_mode="thread_local"):
+            c.graph = CapturedGraph()
+            with c.graph.capture(capture_error_mode="thread_local"):
                 c.out = self.func(c.t, c.y)
+            c.graph.finish()
+            self.safe_mode = self.safe_mode or c.graph.safe_mode
         self._captures[key] = c
         self.captures += 1
         return c

@@ -990,3 +990,68 @@ def test_fixed_graph_pipeline_records_the_step_sizes_of_every_combine(dev):
         for g, c in zip(got, cols):
             assert g.dtype == np.float64 and np.array_equal(g, c.astype(np.float64)), (name, variant)
         assert s._rec is None and s._dt is None and s.nfe == 0
+
+
+def test_graphed_func_with_a_memset_node_replays_correctly(dev):
+    """ROCm 7.2: a hipGraph MEMSET node (PyTorch's multi-block reductions zero a semaphore with hipMemsetAsync) does not hold
+    its place in the graph — replayed among ordinary stream work, [memset, reduce kernel] returns the previous replay's
+    result in a large fraction of launches.  GraphedFunc reads the node types back after capture and replaces the memset
+    nodes by fill-kernel nodes (xde_graph_replace_memsets) before instantiating the graph."""
+    from paddlexde_amd.utils import GraphedFunc
+
+    w = torch.linspace(-1.0, 1.0, 50, device=dev)
+
+    def reducing(t, y):  # y [8192, 50]: the column sum is a two-stage reduction
+        return y * 0.5 + y.sum(0) * w
+
+    def plain(t, y):
+        return (y * 0.5 + w).tanh()
+
+    t = torch.zeros((), device=dev)
+    junk = torch.randn(8192, 64, device=dev)
+    for func, n_memsets in ((reducing, 1), (plain, 0)):
+        gf = GraphedFunc(func)
+        for i in range(200):
+            y = torch.randn(8192, 50, generator=torch.Generator().manual_seed(i)).to(dev)
+            got = gf(t, y)
+            junk.sum(1)  # ordinary stream work between replays
+            assert torch.equal(got, func(t, y)), (func.__name__, i)
+        if str(dev).startswith("cuda"):
+            cap = list(gf._captures.values())[0].graph
+            assert gf.replays >= 199 and not gf.safe_mode and cap.memsets_replaced == n_memsets and 2 not in cap.node_types
+
+
+def test_adjoint_graphed_dynamics_stays_correct_across_calls(dev):
+    """The captured augmented dynamics is cached per module and replayed by every later call; with a batch large enough for
+    PyTorch's bias-gradient reduction to go multi-block (its captured MEMSET node is what misbehaves on ROCm 7.2 — see
+    utils/graphed.py::CapturedGraph) the gradients of the 2nd, 3rd and 4th call, with an eager call in between, are bit for
+    bit those of the eager path."""
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(42)
+            self.net = nn.Sequential(nn.Linear(2, 50), nn.Tanh(), nn.Linear(50, 2))
+            for m in self.net:
+                if isinstance(m, nn.Linear):
+                    with torch.no_grad():
+                        m.weight.copy_(0.1 * torch.randn(m.weight.shape, generator=g))
+                        m.bias.zero_()
+
+        def forward(self, t, y):
+            return self.net(y**3)
+
+    f = Net().to(dev)
+    y0 = (torch.rand(8192, 2, generator=torch.Generator().manual_seed(0)) * 4 - 2).to(dev)
+    t = torch.linspace(0.0, 25.0, 1000)[:8].to(dev)
+
+    def grads(graph_func):
+        for p in f.parameters():
+            p.grad = None
+        pred = odeint_adjoint(f, y0, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm},
+                              adjoint_options={"graph_func": graph_func})
+        torch.mean(torch.abs(pred)).backward()
+        return torch.cat([p.grad.reshape(-1) for p in f.parameters()]).clone()
+
+    eager = grads(False)
+    for call, graph_func in enumerate((True, True, False, True, True)):
+        assert torch.equal(grads(graph_func), eager), (call, graph_func)
