@@ -291,7 +291,10 @@ def odeint_adjoint(
             cache = _GRAPH_CACHE.setdefault(func, {})
         t_rg = bool(t_span.requires_grad)
         fixed = _is_fixed(adjoint_solver)
-        key = ("aug-flat", tuple(y0.shape), y0.dtype, str(y0.device), t_rg, fixed, tuple(id(p) for p in adjoint_params))
+        # (the captured kernels address the parameters' storage: a parameter whose storage was swapped — `p.data = ...` —
+        # needs a new capture, an in-place update such as an optimiser step does not)
+        key = ("aug-flat", tuple(y0.shape), y0.dtype, str(y0.device), t_rg, fixed,
+               tuple((id(p), p.data_ptr()) for p in adjoint_params))
         graphed = cache.get(key)
         # the augmented state (adj_t, y, adj_y, *adj_params) in the flat, 16-byte-segment layout odeint() will use
         aug_example = [torch.zeros([], dtype=y0.dtype, device=y0.device), y0.detach(), torch.zeros_like(y0)]

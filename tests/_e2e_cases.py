@@ -1055,3 +1055,12 @@ def test_adjoint_graphed_dynamics_stays_correct_across_calls(dev):
     eager = grads(False)
     for call, graph_func in enumerate((True, True, False, True, True)):
         assert torch.equal(grads(graph_func), eager), (call, graph_func)
+    # an optimiser step updates the parameters in place: the cached capture reads the new values
+    with torch.no_grad():
+        for i, p in enumerate(f.parameters()):
+            p.add_(0.01 * torch.randn(p.shape, generator=torch.Generator().manual_seed(100 + i)).to(dev))
+    assert torch.equal(grads(True), grads(False))
+    # a parameter whose storage is swapped gets a fresh capture
+    with torch.no_grad():
+        f.net[0].bias.data = torch.full_like(f.net[0].bias, 0.05)
+    assert torch.equal(grads(True), grads(False))
