@@ -51,10 +51,10 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, 
   const int seg = find_segment(a.map, blockIdx.x);
   const int lb = blockIdx.x - a.map.seg_blk[seg];
   const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
-  T acc = T(0);
+  double acc = 0.0;
   int nf = 0;
   errnorm_dispatch<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf);
-  const bool last = block_reduce_store<NORM, true>(double(acc), double(nf), a.slot, seg);
+  const bool last = block_reduce_store<NORM, true>(acc, double(nf), a.slot, seg);
   if (!last) return;
   // ---- last arriver: every other workgroup's partial is in L2/memory (sc1 stores, drained before its ticket) ----
   if (threadIdx.x == 0) {

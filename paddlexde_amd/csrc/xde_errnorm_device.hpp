@@ -11,7 +11,7 @@ namespace xde {
 // ------------------------------------------------------------------------------------------
 template <typename T, int NK, int NORM, bool VEC, bool NT, bool PRE = false>
 __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0,
-                                             T dt, int seg, int lb, int nb, T& acc_out, int& nf_out) {
+                                             T dt, int seg, int lb, int nb, double& acc_out, int& nf_out) {
   const T* __restrict__ epre = static_cast<const T*>(a.e_pre);
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
@@ -30,6 +30,8 @@ __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restri
   const int64_t vbase = start / W;  // host guarantees start % W == 0 on the vector path
   const int64_t stride = int64_t(nb) * kBlock;
   T acc = T(0);
+  double acc64 = 0.0;  // the per-lane sum moves here every 64 iterations: huge N / small grids stay accurate
+  int it = 0;
   int nf = 0;
   auto one = [&](T e, T y0v, T y1v) {
     T tol = atol + rtol * fmax_(abs_(y0v), abs_(y1v));
@@ -61,6 +63,10 @@ __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restri
       for (int j = 1; j < NK; ++j) e = e + kk[j].v[w] * c[j];
       one(e, y0v.v[w], y1v.v[w]);
     }
+    if (NORM == XDE_NORM_RMS && (++it & 63) == 0) {
+      acc64 += double(acc);
+      acc = T(0);
+    }
   }
   if (VEC && lb == 0) {
     const int64_t i = start + nvec * W + threadIdx.x;
@@ -70,14 +76,14 @@ __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restri
       one(e, y0[i], y1[i]);
     }
   }
-  acc_out = acc;
+  acc_out = NORM == XDE_NORM_RMS ? acc64 + double(acc) : double(acc);
   nf_out = nf;
 }
 
 // operand count > 8 (Dopri8): runtime loop over operands, same arithmetic order
 template <typename T, int NORM, bool VEC>
 __device__ void errnorm_generic(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt, int seg,
-                                int lb, int nb, T& acc_out, int& nf_out) {
+                                int lb, int nb, double& acc_out, int& nf_out) {
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
   const int nk = a.nk;
@@ -89,6 +95,8 @@ __device__ void errnorm_generic(const ErrArgs& a, const T* __restrict__ y0, cons
   const int64_t vbase = start / W;
   const int64_t stride = int64_t(nb) * kBlock;
   T acc = T(0);
+  double acc64 = 0.0;  // the per-lane sum moves here every 64 iterations: huge N / small grids stay accurate
+  int it = 0;
   int nf = 0;
   auto one = [&](T e, T y0v, T y1v) {
     T tol = atol + rtol * fmax_(abs_(y0v), abs_(y1v));
@@ -113,6 +121,10 @@ __device__ void errnorm_generic(const ErrArgs& a, const T* __restrict__ y0, cons
     }
 #pragma unroll
     for (int w = 0; w < W; ++w) one(e.v[w], y0v.v[w], y1v.v[w]);
+    if (NORM == XDE_NORM_RMS && (++it & 63) == 0) {
+      acc64 += double(acc);
+      acc = T(0);
+    }
   }
   if (VEC && lb == 0) {
     const int64_t i = start + nvec * W + threadIdx.x;
@@ -126,13 +138,13 @@ __device__ void errnorm_generic(const ErrArgs& a, const T* __restrict__ y0, cons
       one(e, y0[i], y1[i]);
     }
   }
-  acc_out = acc;
+  acc_out = NORM == XDE_NORM_RMS ? acc64 + double(acc) : double(acc);
   nf_out = nf;
 }
 
 template <typename T, int NORM, bool VEC>
 __device__ __forceinline__ void errnorm_dispatch(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt,
-                                                 int seg, int lb, int nb, T& acc, int& nf) {
+                                                 int seg, int lb, int nb, double& acc, int& nf) {
   if (a.e_pre) {  // host guarantees nk == 1 in this mode: e = e_pre + k_last * (dt * c_last)
     if (a.nt) errnorm_body<T, 1, NORM, VEC, true, true>(a, y0, k0, dt, seg, lb, nb, acc, nf);
     else errnorm_body<T, 1, NORM, VEC, false, true>(a, y0, k0, dt, seg, lb, nb, acc, nf);

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
   const int seg = find_segment(a.map, blockIdx.x);
   const int lb = blockIdx.x - a.map.seg_blk[seg];
   const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
-  T acc = T(0);
+  double acc = 0.0;
   int nf = 0;
   errnorm_dispatch<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
     a.slot->n_seg = a.map.n_seg;
     a.slot->norm_kind = NORM;
   }
-  block_reduce_store<NORM>(double(acc), double(nf), a.slot, seg);
+  block_reduce_store<NORM>(acc, double(nf), a.slot, seg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -66,6 +66,8 @@ __global__ __launch_bounds__(kBlock) void xde_scalednorm_kernel(ScaledArgs s) {
   const int64_t vbase = start / W;
   const int64_t stride = int64_t(nb) * kBlock;
   T acc = T(0);
+  double acc64 = 0.0;  // (see errnorm_body)
+  int it = 0;
   int nf = 0;
   auto one = [&](T av, T bv, T yv) {
     T scale = atol + abs_(yv) * rtol;
@@ -85,6 +87,10 @@ __global__ __launch_bounds__(kBlock) void xde_scalednorm_kernel(ScaledArgs s) {
     if (DIFF) bv = P::load(b, vbase + i);
 #pragma unroll
     for (int w = 0; w < W; ++w) one(av.v[w], bv.v[w], yv.v[w]);
+    if (NORM == XDE_NORM_RMS && (++it & 63) == 0) {
+      acc64 += double(acc);
+      acc = T(0);
+    }
   }
   if (VEC && lb == 0) {
     const int64_t i = start + nvec * W + threadIdx.x;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void xde_scalednorm_kernel(ScaledArgs s) {
     s.slot->n_seg = s.map.n_seg;
     s.slot->norm_kind = NORM;
   }
-  block_reduce_store<NORM>(double(acc), double(nf), s.slot, seg);
+  block_reduce_store<NORM>(NORM == XDE_NORM_RMS ? acc64 + double(acc) : double(acc), double(nf), s.slot, seg);
 }
 
 __global__ __launch_bounds__(kBlock) void xde_finalize_kernel(const NormSlot* slot, double* sums_out) {
