@@ -514,7 +514,7 @@ class HipBackend:
         g = CapturedGraph()  # (replays of a graph that holds memset nodes are synchronised: see its docstring)
         self._capturing = True
         try:
-            with g.capture():
+            with g.capture(capture_error_mode="thread_local"):  # other host threads may keep using the device meanwhile
                 body()
         finally:
             self._capturing = False

@@ -262,7 +262,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
         from ..utils.graphed import CapturedGraph
 
         g = CapturedGraph()  # (replays of a graph that holds memset nodes are synchronised: see its docstring)
-        with g.capture():
+        with g.capture(capture_error_mode="thread_local"):
             body()
         g.finish()
         self.nfe = nfe0 + per_step  # recording executes nothing

@@ -1091,3 +1091,49 @@ def test_graph_pipelines_with_a_reducing_func(dev):
         a = odeint(f, y0f, tf.to(dev), solver=RK4, options={"norm": _rms_norm})
         b = odeint(f, y0f, tf.to(dev), solver=RK4, options={"norm": _rms_norm, "pipeline": "graph"})
     assert torch.equal(a, b)
+
+
+def test_two_threads_two_streams_run_independent_solves(dev):
+    """Thread-safety as INTEGRATION.md states it: distinct streams + distinct solver instances.  Two host threads, each on its
+    own stream, integrate different problems concurrently ("sync" and "lag"; a hipGraph capture needs the device to itself —
+    HIP refuses other threads' stream operations meanwhile — so "graph" is not a concurrent pipeline); each result is bit for
+    bit its sequential one."""
+    import threading
+
+    from paddlexde_amd.xde import BaseODE
+
+    if not str(dev).startswith("cuda"):
+        pytest.skip("streams are a device notion")
+    problems = []
+    for k in range(2):
+        A = P.skew_matrix(24, seed=10 + k).to(dev)
+        y0 = torch.randn(512, 24, generator=torch.Generator().manual_seed(k)).to(dev)
+        problems.append((A, y0, torch.linspace(0.0, 2.0 + k, 7)))
+
+    def solve(k, pipeline):
+        A, y0, t = problems[k]
+        s = Dopri5(xde=BaseODE(lambda t_, y: y @ A.T - 0.01 * y * y * y, y0=y0, t_span=t), y0=y0, rtol=1e-6, atol=1e-8, norm=_rms_norm,
+                   pipeline=pipeline)
+        return s.integrate(t)
+
+    for pipeline in ("sync", "lag"):
+        ref = [solve(k, pipeline) for k in range(2)]
+        torch.cuda.synchronize()
+        out, err = [None, None], []
+
+        def worker(k):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for _ in range(3):
+                        out[k] = solve(k, pipeline)
+                    st.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        assert not err, err
+        for k in range(2):
+            assert torch.equal(out[k], ref[k]), (pipeline, k)
