@@ -1137,3 +1137,59 @@ def test_two_threads_two_streams_run_independent_solves(dev):
         assert not err, err
         for k in range(2):
             assert torch.equal(out[k], ref[k]), (pipeline, k)
+
+
+@pytest.mark.parametrize("block", range(5))
+def test_randomised_adaptive_sweep_fp32(dev, block):
+    """The same option space in the DEFAULT precision (fp32 state, fp32 time-like scalars), free-running against the oracle at
+    the bar north_star states: max |got - ref| <= 1e-5 max |ref| (element-wise 1e-7 + 1e-5|ref| is out of reach of any two
+    fp32 implementations, see test_linear_dopri5_vs_oracle_fp32).  Tolerances are kept where fp32 error estimates are above
+    their own round-off (rtol >= 1e-5)."""
+    from paddlexde_amd.xde import BaseODE
+
+    rng = np.random.RandomState(7300 + block)
+    for case in range(8):
+        name = ("dopri5", "bosh3", "fehlberg2", "adaptive_heun")[rng.randint(4)]
+        pipeline = ("sync", "lag", "graph")[rng.randint(3)]
+        B, D = int(rng.randint(1, 33)), int(rng.randint(2, 33))
+        A = P.skew_matrix(D, seed=int(rng.randint(1, 100))).float()
+        y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(int(rng.randint(1 << 30))))
+        T = int(rng.randint(2, 8))
+        t = np.sort(rng.uniform(0.0, 1.5, size=T)).astype(np.float32)
+        if rng.rand() < 0.3:
+            t = t[::-1].copy()
+        rtol = float(10 ** rng.uniform(-5, -3))
+        atol = rtol * 1e-2
+        opts = {}
+        if rng.rand() < 0.3:
+            opts["first_step"] = float(rng.uniform(1e-3, 5e-2))
+        if rng.rand() < 0.3:
+            opts["max_step"] = float(rng.uniform(0.05, 0.3))
+        if rng.rand() < 0.3:
+            opts["safety"] = float(rng.uniform(0.7, 0.95))
+        linf = rng.rand() < 0.3
+        An, Ad = A.numpy(), A.to(dev)
+
+        def f_np(t_, y):
+            return y @ An.T - np.float32(0.05) * (y * y * y) + np.float32(0.3) * t_
+
+        def f_t(t_, y):
+            return y @ Ad.T - 0.05 * (y * y * y) + 0.3 * t_
+
+        tag = (block, case, name, pipeline, B, D, T, rtol, sorted(opts), linf)
+        failure = None
+        try:
+            ref = O.odeint(f_np, y0.numpy(), t, name, rtol=rtol, atol=atol, options=dict(opts, norm=O._linf_norm if linf else O._rms_norm))
+        except AssertionError as e:  # e.g. a step that ends a rounding error short of an output time: "underflow in dt"
+            failure = str(e).split(" ")[0]
+        s = ADAPTIVE[name](xde=BaseODE(f_t, y0=y0.to(dev), t_span=torch.from_numpy(t)), y0=y0.to(dev), rtol=rtol, atol=atol,
+                           norm=_linf_norm if linf else _rms_norm, pipeline=pipeline, **opts)
+        if failure is not None:
+            with pytest.raises(AssertionError, match=failure):
+                s.integrate(torch.from_numpy(t))
+            continue
+        got = s.integrate(torch.from_numpy(t)).cpu().numpy()
+        assert got.dtype == ref.dtype == np.float32 and got.shape == ref.shape, tag
+        # a decision flipped by fp32 round-off (accept/reject, or a step clipped at an output) gives two valid integrations:
+        # they agree to the integrator's own tolerance, so that is the fall-back bar
+        assert P.rel_err(got, ref) <= max(1e-5, 3 * rtol), (tag, P.rel_err(got, ref))
