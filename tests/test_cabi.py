@@ -79,3 +79,47 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, flags=re.M), os.path.join(dirpath, f)
                 assert "xde_oracle" not in src and "import_module(\"oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_every_entry_point_rejects_null_arguments():
+    """Argument validation precedes any HIP call: with null pointers every compute entry point returns XDE_EBADARG and names
+    itself in xde_last_error() — checked here without a GPU (nothing is launched)."""
+    import ctypes as C
+
+    from paddlexde_amd import _hip
+
+    lib = _hip.load_library()
+    P = _hip.XdeCtrlParams()
+    S = _hip.XdeSegments()
+    n = C.c_int(0)
+    calls = {
+        "xde_stage_combine": lambda: lib.xde_stage_combine(None, None, None, None, None, None, 1, 0, 1.0, 0.0, None, 8, 0, None, None, 0.0, 0, None),
+        "xde_error_norm_partial": lambda: lib.xde_error_norm_partial(None, None, None, 1, None, None, None, 1e-3, 1e-6, 0.0, None, C.byref(S), 0, 0,
+                                                                    None, None, None),
+        "xde_error_norm_control": lambda: lib.xde_error_norm_control(None, None, None, 1, None, None, None, C.byref(S), 0, None, None, None,
+                                                                    C.byref(P), None, None, None, None, None),
+        "xde_error_ratio": lambda: lib.xde_error_ratio(None, None, None, 1, None, None, 1e-3, 1e-6, 0.0, None, 8, 0, None),
+        "xde_scaled_norm_partial": lambda: lib.xde_scaled_norm_partial(None, None, None, 1e-3, 1e-6, C.byref(S), 0, 0, None, 0, None),
+        "xde_norm_finalize": lambda: lib.xde_norm_finalize(None, 0, None, None),
+        "xde_norm_result": lambda: lib.xde_norm_result(None, None, 1, 0, 0, None, None),
+        "xde_rk_control": lambda: lib.xde_rk_control(None, C.byref(P), None, None, None, None, None, None, None),
+        "xde_ctrl_init": lambda: lib.xde_ctrl_init(None, C.byref(P), 0.0, 0.1, 2, None, None, None, 0, None, None),
+        "xde_initial_step": lambda: lib.xde_initial_step(0, None, None, C.byref(P), 0.0, None, 0, None, None),
+        "xde_ctrl_read": lambda: lib.xde_ctrl_read(None, None, None),
+        "xde_host_alloc": lambda: lib.xde_host_alloc(0, None),
+        "xde_ctrl_wait": lambda: lib.xde_ctrl_wait(None, 0, 1.0, None),
+        "xde_dense_eval": lambda: lib.xde_dense_eval(None, None, None, None, 1, None, None, None, None, None, None, 0, 8, 0, -1, None),
+        "xde_commit": lambda: lib.xde_commit(None, None, None, None, None, 8, 0, None),
+        "xde_hermite_gather": lambda: lib.xde_hermite_gather(None, None, None, None, None, 1, 4, 2, 1, 0, None),
+        "xde_scale_fanout": lambda: lib.xde_scale_fanout(None, None, None, 1, None, 8, 0, None),
+        "xde_graph_replace_memsets": lambda: lib.xde_graph_replace_memsets(None, C.byref(n)),
+        "xde_prof_collect": lambda: lib.xde_prof_collect(None, None, None),
+    }
+    for name, call in calls.items():
+        rc = call()
+        msg = lib.xde_last_error().decode()
+        assert rc == _hip.XDE_EBADARG, (name, rc, msg)
+        assert msg and (name in msg or "segments" in msg), (name, msg)
+    covered = set(calls) | {"xde_last_error", "xde_abi_version", "xde_sizeof_ctrl", "xde_workspace_bytes", "xde_host_free", "xde_prof_enable"}
+    assert covered == set(_hip.SYMBOLS), set(_hip.SYMBOLS) ^ covered
+    assert lib.xde_host_free(None) == _hip.XDE_OK  # freeing nothing is fine
