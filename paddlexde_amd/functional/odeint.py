@@ -68,6 +68,15 @@ def _odeint_tuple(func, y0, t_span, solver, *, rtol, atol, options):
     dtype, segs, total = _segment_layout(y0)
     device = y0[0].device
     flat0 = _pack(y0, segs, total, dtype, device)
+    sol = _odeint_packed(func, flat0, segs, shapes, t_span, solver, rtol=rtol, atol=atol, options=options)
+    T = sol.shape[0]
+    return tuple(sol[:, st : st + n].reshape((T,) + shape) for (st, n), shape in zip(segs, shapes))
+
+
+def _odeint_packed(func, flat0, segs, shapes, t_span, solver, *, rtol, atol, options):
+    """Integrate a tuple state that is ALREADY in the flat padded layout of ``_segment_layout`` (pads zero); returns the
+    flat solution ``[T, total]``.  odeint_adjoint's backward keeps its augmented state in this form between intervals."""
+    dtype, device, total = flat0.dtype, flat0.device, flat0.numel()
     fixed = isinstance(solver, type) and issubclass(solver, FixedSolver)
     options = dict(options)
     # private hook (odeint_adjoint): a ready-made dynamics on the FLAT state with this exact layout, e.g. a
@@ -97,6 +106,4 @@ def _odeint_tuple(func, y0, t_span, solver, *, rtol, atol, options):
 
     xde = BaseODE(flat_func, y0=y_in, t_span=t_span)
     s = solver(xde=xde, y0=xde.y0, rtol=rtol, atol=atol, **opts)
-    sol = s.integrate(t_span)  # [T, total]
-    T = sol.shape[0]
-    return tuple(sol[:, st : st + n].reshape((T,) + shape) for (st, n), shape in zip(segs, shapes))
+    return s.integrate(t_span)  # [T, total]

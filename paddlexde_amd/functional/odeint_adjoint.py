@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ..solver.base_fixed_solver import FixedSolver
 from ..utils.ode_utils import _mixed_norm, _rms_norm, native_norm_spec
-from .odeint import _pack, _segment_layout, odeint
+from .odeint import _odeint_packed, _pack, _segment_layout, odeint
 
 
 def _is_fixed(solver):
@@ -161,8 +161,14 @@ class OdeintAdjointMethod(torch.autograd.Function):
             ##################################
             #      Set up initial state      #
             ##################################
+            # (adj_t, y, adj_y, *adj_params) — odeint_adjoint.py:85-87 — kept between intervals in the flat, 16-byte-segment
+            # layout the kernels integrate (the reference rebuilds the tuple each time; same values, ~15 launches fewer)
             aug_state = [torch.zeros([], dtype=y_ans.dtype, device=y_ans.device), y_ans[-1], grad_y[-1]]
             aug_state.extend([torch.zeros_like(param) for param in adjoint_params])
+            shapes = [tuple(x.shape) for x in aug_state]
+            adt, segs, total = _segment_layout(aug_state)
+            flat = _pack(aug_state, segs, total, adt, y_ans.device)
+            (s_t, _), (s_y, n_y), (s_a, n_a) = segs[0], segs[1], segs[2]
 
             ##################################
             #    Set up backward ODE func    #
@@ -170,8 +176,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
             augmented_dynamics = _make_augmented_dynamics(func, adjoint_params, t_requires_grad)
             solver_options = {k: v for k, v in adjoint_options.items() if k not in ("graph_func", "_graphed")}
             if adjoint_options.get("_graphed") is not None:
-                # the captured FLAT dynamics (same segment layout as odeint's tuple flattening) replaces the
-                # unpack -> dynamics -> pack wrapper: 2 input copies + 1 replay + 1 clone per evaluation
+                # the captured FLAT dynamics (same segment layout) replaces the unpack -> dynamics -> pack wrapper:
+                # 2 input copies + 1 replay + 1 clone per evaluation
                 solver_options["_xde_flat_func"] = adjoint_options["_graphed"]
 
             ##################################
@@ -187,23 +193,26 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 if t_requires_grad:
                     func_eval = func(t_span[i], y_ans[i])
                     dLd_cur_t = func_eval.reshape(-1).dot(grad_y[i].reshape(-1))
-                    aug_state[0] = aug_state[0] - dLd_cur_t
+                    flat[s_t] -= dLd_cur_t.to(adt)  # aug_state[0] = aug_state[0] - dLd_cur_t
                     grad_t_span[i] = dLd_cur_t
 
                 # Run the augmented system backwards in time.
-                aug = odeint(
-                    func=augmented_dynamics,
-                    y0=tuple(aug_state),
-                    t_span=t_host[i - 1 : i + 1].flip(0),
-                    solver=adjoint_method,
+                sol = _odeint_packed(
+                    augmented_dynamics,
+                    flat,
+                    segs,
+                    shapes,
+                    t_host[i - 1 : i + 1].flip(0),
+                    adjoint_method,
                     rtol=adjoint_rtol,
                     atol=adjoint_atol,
                     options=solver_options,
                 )
-                aug_state = [a[1] for a in aug]  # extract just the t[i - 1] value
-                aug_state[1] = y_ans[i - 1]  # use our forward-pass estimate of the state
-                aug_state[2] = aug_state[2] + grad_y[i - 1]  # gradients wrt state at this time point
+                flat = sol[1]  # extract just the t[i - 1] value (a fresh row: the solver never aliases its input)
+                flat[s_y : s_y + n_y].copy_(y_ans[i - 1].reshape(-1))  # use our forward-pass estimate of the state
+                flat[s_a : s_a + n_a].add_(grad_y[i - 1].reshape(-1))  # gradients wrt state at this time point
 
+            aug_state = [flat[s : s + n].view(shape) for (s, n), shape in zip(segs, shapes)]
             if t_requires_grad:
                 grad_t_span[0] = aug_state[0]
 
