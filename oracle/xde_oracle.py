@@ -205,6 +205,25 @@ def optimal_step_size(last_step, error_ratio, safety, ifactor, dfactor, order):
     return last_step * factor
 
 
+def optimal_step_size_pi(last_step, error_ratio, prev_ratio, safety, ifactor, dfactor, order, beta):
+    """NOT in the reference (its controller is the plain integral one above, D9).  CPU statement of the package's OPT-IN
+    ``controller="PI"`` (Hairer's dopri5 form: factor = safety * prev^beta / ratio^alpha, alpha = 1/order - 0.75 beta,
+    prev = error ratio of the last ACCEPTED step, floored at 1e-4) so that the device controller's PI branch is pinned to
+    something too; same special cases and clamps as ``optimal_step_size``."""
+    tt = type(last_step)
+    if error_ratio == 0:
+        return last_step * ifactor
+    if error_ratio < 1:
+        dfactor = tt(1)
+    error_ratio = tt(error_ratio)
+    beta = tt(beta)
+    alpha = tt(1) / tt(order) - tt(0.75) * beta
+    prev = tt(prev_ratio if prev_ratio > 1e-4 else 1e-4)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        factor = np.fmin(ifactor, np.fmax(safety * prev**beta / error_ratio**alpha, dfactor))
+    return last_step * factor
+
+
 # --------------------------------------------------------------------------------------
 # fixed-grid solvers                        (paddlexde/solver/base_fixed_solver.py etc.)
 # --------------------------------------------------------------------------------------
@@ -436,6 +455,8 @@ class AdaptiveRKSolver:
         max_num_steps=2**31 - 1,
         dtype=np.float32,
         reduce_hook=None,
+        controller="I",
+        pi_beta=0.04,
         **unused,
     ):
         """base_adaptive_solver_rk.py:32-79.  ``dtype`` is the dtype of time-like scalars."""
@@ -444,6 +465,7 @@ class AdaptiveRKSolver:
         self.func = func
         self.y0 = y0
         self.norm = norm
+        self.controller, self.pi_beta, self.ratio_prev = controller, float(pi_beta), 0.0
         self.order, tableau, mid = ADAPTIVE[method]
         tt = np.dtype(dtype).type
         self.tt = tt
@@ -600,7 +622,13 @@ class AdaptiveRKSolver:
             t_next = t0
             y_next = y0
             f_next = f0
-        dt_next = optimal_step_size(dt, error_ratio, self.safety, self.ifactor, self.dfactor, self.order)
+        if self.controller == "PI":  # opt-in extension, see optimal_step_size_pi
+            dt_next = optimal_step_size_pi(dt, error_ratio, self.ratio_prev, self.safety, self.ifactor, self.dfactor, self.order,
+                                           self.pi_beta)
+            if accept_step and error_ratio == error_ratio:
+                self.ratio_prev = float(error_ratio)
+        else:
+            dt_next = optimal_step_size(dt, error_ratio, self.safety, self.ifactor, self.dfactor, self.order)
         dt_next = self.tt(np.clip(dt_next, self.min_step, self.max_step))
         return RKState(y_next, f_next, t0, t_next, dt_next, interp_coeff)
 

@@ -1193,3 +1193,30 @@ def test_randomised_adaptive_sweep_fp32(dev, block):
         # a decision flipped by fp32 round-off (accept/reject, or a step clipped at an output) gives two valid integrations:
         # they agree to the integrator's own tolerance, so that is the fall-back bar
         assert P.rel_err(got, ref) <= max(1e-5, 3 * rtol), (tag, P.rel_err(got, ref))
+
+
+@pytest.mark.parametrize("pipeline", ["sync", "lag", "graph"])
+def test_pi_controller_vs_its_cpu_statement(dev, pipeline):
+    """The opt-in PI controller (not in the reference) against oracle.optimal_step_size_pi: same step sequence — every
+    (t0, dt, ratio, accept) — and the same solution, on a problem with rejections, fp64."""
+    from paddlexde_amd.xde import BaseODE
+
+    mu = 30.0
+    y0 = (torch.tensor([[2.0, 0.0]], dtype=torch.float64) + 0.01 * torch.randn(16, 2, generator=torch.Generator().manual_seed(0), dtype=torch.float64))
+    t = torch.linspace(0.0, 3.0, 5, dtype=torch.float64)
+    for beta in (0.04, 0.08):
+        ref, so = O.odeint(P.vdp_np(mu), y0.numpy(), t.numpy(), "dopri5", rtol=1e-7, atol=1e-9,
+                           options={"norm": O._rms_norm, "dtype": np.float64, "controller": "PI", "pi_beta": beta}, return_solver=True)
+        s = Dopri5(xde=BaseODE(P.vdp_torch(mu), y0=y0.to(dev), t_span=t), y0=y0.to(dev), rtol=1e-7, atol=1e-9, norm=_rms_norm, dtype=torch.float64,
+                   controller="PI", pi_beta=beta, pipeline=pipeline, record_trace=True)
+        got = s.integrate(t).cpu().numpy()
+        assert so.n_reject > 0
+        assert (s.stats["n_accept"], s.stats["n_reject"]) == (so.n_accept, so.n_reject)
+        assert P.parity_ok(got, ref, rtol=1e-9, atol=1e-11), P.worst(got, ref, 1e-9, 1e-11)
+        mine = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
+        theirs = np.asarray([[r.t0, r.dt, r.ratio, float(r.accept)] for r in so.trace])
+        assert mine.shape == theirs.shape
+        assert np.array_equal(mine[:, 3], theirs[:, 3])
+        assert np.allclose(mine[:, :2], theirs[:, :2], rtol=1e-8, atol=1e-12)
+        # (the error ratio is a cancellation: ulp differences between numpy's and the device's func show up at 1e-7)
+        assert np.allclose(mine[:, 2], theirs[:, 2], rtol=1e-6, atol=1e-12)
