@@ -9,6 +9,13 @@ from paddlexde_amd.xde import BaseDDE, HistoryIndex
 
 from . import problems as P
 
+def _blocks(n):
+    """Number of seeded blocks of a randomised sweep; XDE_SWEEP_SCALE=k runs k times as many (a soak, not the default)."""
+    import os
+
+    return n * int(os.environ.get("XDE_SWEEP_SCALE", "1"))
+
+
 SOLVERS = {"euler": Euler, "midpoint": Midpoint, "rk4": RK4, "adams": AdamsBashforthMoulton}
 
 
@@ -173,7 +180,7 @@ def test_dde_api_conventions(dev):
         HistoryIndex.apply(torch.zeros(1, device=dev), torch.from_numpy(his).to(dev), torch.from_numpy(ht).to(dev), "linear")
 
 
-@pytest.mark.parametrize("block", range(3))
+@pytest.mark.parametrize("block", range(_blocks(3)))
 def test_randomised_ddeint_sweep_vs_oracle(dev, block):
     """8 random configurations per block: solver, dtype, leading axes, history length and grid (uniform or not), number of
     lags (some outside the history span: clamped / extrapolated as the reference does), output grid.  The gathered delayed

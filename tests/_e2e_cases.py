@@ -17,6 +17,13 @@ from paddlexde_amd.utils import _linf_norm, _rms_norm
 from . import problems as P
 
 
+def _blocks(n):
+    """Number of seeded blocks of a randomised sweep; XDE_SWEEP_SCALE=k runs k times as many (a soak, not the default)."""
+    import os
+
+    return n * int(os.environ.get("XDE_SWEEP_SCALE", "1"))
+
+
 FIXED = {"euler": Euler, "midpoint": Midpoint, "rk4": RK4, "adams": AdamsBashforthMoulton}
 ADAPTIVE = {"dopri5": Dopri5, "bosh3": Bosh3, "fehlberg2": Fehlberg2, "adaptive_heun": AdaptiveHeun, "dopri8": Dopri8}
 
@@ -692,7 +699,7 @@ def test_config2_full_size_properties(dev):
 # ----------------------------------------------------------------------------------------------
 # seeded randomised sweep over the option space (fp64: tight bar, identical step decisions)
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("block", range(10))
+@pytest.mark.parametrize("block", range(_blocks(10)))
 def test_randomised_adaptive_sweep_vs_oracle(dev, block):
     """8 random configurations per block: tableau, pipeline, tolerances, number and spacing of output times, direction of
     time, norm, first_step / min_step / max_step / safety / ifactor / dfactor / max_num_steps, step_t, time-dependent cubic dynamics.  Solution to
@@ -758,6 +765,12 @@ def test_randomised_adaptive_sweep_vs_oracle(dev, block):
                 s.integrate(torch.from_numpy(t))
             continue
         got = s.integrate(torch.from_numpy(t)).cpu().numpy()
+        if not np.isfinite(ref).all():
+            # a forced-accept option (min_step) can drive the cubic problem to overflow: then it overflows here too, at
+            # the same entries, after the same number of steps
+            assert np.array_equal(np.isfinite(got), np.isfinite(ref)), tag
+            assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == (so.n_accept, so.n_reject, so.nfe), tag
+            continue
         if min(rec.ratio for rec in so.trace) < 1e-5:
             # a step whose error estimate is below the round-off of its own terms (err/tol ~ 1e-9: a high-order pair on a
             # short first step): the ratio, hence the next dt, is rounding noise in ANY implementation (oracle 4.01e-9 vs
@@ -769,7 +782,7 @@ def test_randomised_adaptive_sweep_vs_oracle(dev, block):
         assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == (so.n_accept, so.n_reject, so.nfe), tag
 
 
-@pytest.mark.parametrize("block", range(4))
+@pytest.mark.parametrize("block", range(_blocks(4)))
 def test_randomised_fixed_sweep_vs_oracle(dev, block):
     """10 random configurations per block: solver, state shape ``[..., L, D]`` (0-3 leading axes), dtype, non-uniform /
     reversed grids, ``interp``, Adams order / corrector, time-dependent cubic dynamics built from +, -, * only — the whole
@@ -826,7 +839,7 @@ class _SmallMLP(nn.Module):
         return torch.tanh((y * y * y) @ self.W1 + self.b1) @ self.W2 + self.b2 + 0.1 * t
 
 
-@pytest.mark.parametrize("block", range(6))
+@pytest.mark.parametrize("block", range(_blocks(6)))
 def test_randomised_adjoint_sweep_vs_oracle(dev, block):
     """6 random configurations per block (fp64): forward / adjoint solver pair, tolerances, adjoint tolerances, the adjoint's
     default norm or "seminorm", batch, width, number of output times, a random cotangent — solution, d/dy0 and every
@@ -898,7 +911,7 @@ def test_randomised_adjoint_sweep_vs_oracle(dev, block):
             assert P.rel_err(p_.grad.cpu().numpy(), g_) <= bar, (tag, i, P.rel_err(p_.grad.cpu().numpy(), g_))
 
 
-@pytest.mark.parametrize("block", range(3))
+@pytest.mark.parametrize("block", range(_blocks(3)))
 def test_randomised_tuple_state_sweep_vs_oracle(dev, block):
     """8 random configurations per block: a tuple state of 1-5 components of odd shapes (every segment start is padded to
     16 bytes inside the flat buffer the kernels see), coupled time-dependent dynamics, every tableau and pipeline, both
@@ -1139,7 +1152,7 @@ def test_two_threads_two_streams_run_independent_solves(dev):
             assert torch.equal(out[k], ref[k]), (pipeline, k)
 
 
-@pytest.mark.parametrize("block", range(5))
+@pytest.mark.parametrize("block", range(_blocks(5)))
 def test_randomised_adaptive_sweep_fp32(dev, block):
     """The same option space in the DEFAULT precision (fp32 state, fp32 time-like scalars), free-running against the oracle at
     the bar north_star states: max |got - ref| <= 1e-5 max |ref| (element-wise 1e-7 + 1e-5|ref| is out of reach of any two
