@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XDE_ABI_VERSION 1
+#define XDE_ABI_VERSION 2
 
 #define XDE_OK 0
 #define XDE_EBADARG 1
@@ -115,6 +115,13 @@ typedef struct xde_ctrl_params {
   double pi_beta;            /* PI only */
   double alpha[XDE_MAX_STAGE]; /* tableau.alpha in double */
   double seg_count[XDE_MAX_SEG]; /* GLOBAL element count of each segment (all ranks) */
+  /* Prescribed step sequence ("replay"): NULL, or n_replay pairs {dt_i, accept_i} of doubles on the DEVICE.  Attempt i
+   * then runs with the signed step dt_i and is accepted iff accept_i != 0, whatever its error ratio (which is still
+   * computed and recorded); after the table is exhausted the controller decides again.  This is how a parity harness
+   * holds two implementations of _adaptive_step (base_adaptive_solver_rk.py:183-284) to the same (dt, accept)
+   * sequence, so that their per-step y1 / error ratio can be compared free of accept/reject divergence. */
+  const double* replay;
+  int64_t n_replay;
 } xde_ctrl_params_t;
 
 /* Description of one state operand list + segment layout, shared by the norm kernels. */
@@ -249,6 +256,17 @@ int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_st
                   double first_step, int32_t n_out, const double* t_span_dev,
                   const double* step_t_dev, void* t_stage_out, int64_t seq0,
                   const double* first_step_dev, void* stream);
+
+/*
+ * Give a running solve a new list of output times — the device side of AdaptiveRKSolver.step(next_t)
+ * (solver/base_adaptive_solver_rk.py:116-127), which may be called with any time at or after the start of the last accepted
+ * step.  Rows of the new list that the last accepted step already covers are reported immediately in
+ * ctrl->out_begin..out_end (the reference's `while next_t > rk_state.t1` does not step for them; xde_dense_eval on the
+ * retained operands of that step produces them); the per-interval `max_num_steps` count restarts.  Counts as a controller
+ * launch for the host mirror (seq + 1).
+ */
+int xde_ctrl_retarget(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const double* t_span_dev, int32_t n_out,
+                      xde_ctrl_t* host_mirror, void* stream);
 
 /*
  * Scalar part of the initial-step heuristic on the device — AdaptiveSolver.select_initial_step

@@ -457,6 +457,7 @@ class AdaptiveRKSolver:
         reduce_hook=None,
         controller="I",
         pi_beta=0.04,
+        step_hook=None,
         **unused,
     ):
         """base_adaptive_solver_rk.py:32-79.  ``dtype`` is the dtype of time-like scalars."""
@@ -490,6 +491,7 @@ class AdaptiveRKSolver:
         self.mid = mid.astype(yd)
         self.nfe = 0
         self.trace = []  # StepRecord per attempted step (oracle-only instrumentation)
+        self.step_hook = step_hook  # oracle-only instrumentation: callable(index, y0, y1, error_ratio, accept) per attempt
         self.n_accept = 0
         self.n_reject = 0
 
@@ -607,6 +609,8 @@ class AdaptiveRKSolver:
         if dt <= self.min_step:
             accept_step = True
         self.trace.append(StepRecord(float(t0), float(dt), float(error_ratio), accept_step))
+        if self.step_hook is not None:
+            self.step_hook(len(self.trace) - 1, y0, y1, float(error_ratio), accept_step)
 
         if accept_step:
             self.n_accept += 1

@@ -14,6 +14,7 @@ import torch
 
 XDE_OK, XDE_EBADARG, XDE_EHIP, XDE_ETIMEOUT = 0, 1, 2, 3
 XDE_MIRROR_SLOTS = 4
+ABI_VERSION = 2
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
 COMBINE_RK, COMBINE_FUSE, COMBINE_WFUSE = 0, 1, 2
@@ -38,6 +39,7 @@ SYMBOLS = (
     "xde_norm_result",
     "xde_rk_control",
     "xde_ctrl_init",
+    "xde_ctrl_retarget",
     "xde_initial_step",
     "xde_ctrl_read",
     "xde_host_alloc",
@@ -109,6 +111,8 @@ class XdeCtrlParams(C.Structure):
         ("pi_beta", C.c_double),
         ("alpha", C.c_double * XDE_MAX_STAGE),
         ("seg_count", C.c_double * XDE_MAX_SEG),
+        ("replay", C.c_void_p),
+        ("n_replay", C.c_int64),
     ]
 
 
@@ -181,6 +185,8 @@ def load_library():
         lib.xde_rk_control.argtypes = [vp, C.POINTER(XdeCtrlParams), vp, vp, vp, vp, vp, vp, vp]
         lib.xde_ctrl_init.restype = i32
         lib.xde_ctrl_init.argtypes = [vp, C.POINTER(XdeCtrlParams), dbl, dbl, C.c_int32, vp, vp, vp, i64, vp, vp]
+        lib.xde_ctrl_retarget.restype = i32
+        lib.xde_ctrl_retarget.argtypes = [vp, C.POINTER(XdeCtrlParams), vp, C.c_int32, vp, vp]
         lib.xde_initial_step.restype = i32
         lib.xde_initial_step.argtypes = [i32, vp, vp, C.POINTER(XdeCtrlParams), dbl, vp, i32, vp, vp]
         lib.xde_host_alloc.restype = i32
@@ -205,7 +211,7 @@ def load_library():
         lib.xde_prof_enable.argtypes = [i32]
         lib.xde_prof_collect.restype = i32
         lib.xde_prof_collect.argtypes = [C.POINTER(C.c_int64), dp, dp]
-        if lib.xde_abi_version() != 1:
+        if lib.xde_abi_version() != ABI_VERSION:
             raise XdeError("libxde_hip.so ABI version mismatch")
         if lib.xde_sizeof_ctrl() != C.sizeof(XdeCtrl):
             raise XdeError("xde_ctrl_t layout mismatch between header and ctypes mirror")
@@ -259,7 +265,7 @@ class HipBackend:
         self._mirror_pool = []  # pinned host mirror rings, reused across solver instances
         self._mirrors = {}  # device ctrl pointer -> _Mirror
         self._work_pool = {}  # (device, state dtype, stream) -> free _Work sets
-        self._capturing = False
+        self._tls = threading.local()  # .capturing: this THREAD is recording a hipGraph (its launches do not execute)
 
     # -- host mirror ring of the control block (see xde_rk_control / xde_ctrl_wait) -------------
     class _Mirror:
@@ -283,6 +289,11 @@ class HipBackend:
             self._mirror_pool.append(m)
 
     # -- helpers -------------------------------------------------------------------------
+    def _is_capturing(self):
+        """True while THIS thread records a hipGraph through capture(): controller launches recorded there do not run, so
+        they must not advance the host's sequence number; other threads' launches do run and are counted as usual."""
+        return getattr(self._tls, "capturing", False)
+
     def _check(self, rc, who):
         if rc != XDE_OK:
             raise XdeError("{} failed (status {}): {}".format(who, rc, self.lib.xde_last_error().decode()))
@@ -379,7 +390,7 @@ class HipBackend:
             _ptr(step_t_dev), t_stage.data_ptr(), m.ptr if m is not None else None, self._stream(y0),
         )
         self._check(rc, "xde_error_norm_control")
-        if m is not None and not self._capturing:
+        if m is not None and not self._is_capturing():
             m.seq += 1
 
     def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None):
@@ -416,7 +427,7 @@ class HipBackend:
                                      _ptr(step_t_dev), t_stage.data_ptr(), m.ptr if m is not None else None,
                                      self._stream(ctrl))
         self._check(rc, "xde_rk_control")
-        if m is not None and not self._capturing:
+        if m is not None and not self._is_capturing():
             m.seq += 1
 
     def initial_step(self, phase, res, hs, params, t_start, t_probe, ctrl):
@@ -436,6 +447,16 @@ class HipBackend:
         self._check(rc, "xde_ctrl_init")
         if m is not None:
             m.seq0 = seq0
+
+    def ctrl_retarget(self, ctrl, params, t_span_dev, n_out):
+        """New output list for a running solve (the device side of AdaptiveRKSolver.step(next_t))."""
+        self._require_device(ctrl, t_span_dev)
+        m = self._mirrors.get(ctrl.data_ptr())
+        rc = self.lib.xde_ctrl_retarget(ctrl.data_ptr(), C.byref(params), t_span_dev.data_ptr(), int(n_out),
+                                        m.ptr if m is not None else None, self._stream(ctrl))
+        self._check(rc, "xde_ctrl_retarget")
+        if m is not None and not self._is_capturing():
+            m.seq += 1
 
     def ctrl_read(self, ctrl) -> XdeCtrl:
         """The newest control block.  With a host mirror: poll the pinned ring (no HIP call); else a blocking copy."""
@@ -512,12 +533,12 @@ class HipBackend:
         from .utils.graphed import CapturedGraph
 
         g = CapturedGraph()  # (replays of a graph that holds memset nodes are synchronised: see its docstring)
-        self._capturing = True
+        self._tls.capturing = True
         try:
             with g.capture(capture_error_mode="thread_local"):  # other host threads may keep using the device meanwhile
                 body()
         finally:
-            self._capturing = False
+            self._tls.capturing = False
         g.finish()
         return HipBackend._Graph(self, g, ctrl)
 

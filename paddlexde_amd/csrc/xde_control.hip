@@ -79,6 +79,7 @@ __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double 
   z.t1 = t_start;
   // device-resident first step (xde_initial_step): a magnitude, given the direction's sign here
   z.dt = first_step_dev ? double(p.direction) * fabs(*first_step_dev) : first_step;
+  if (p.replay && p.n_replay > 0) z.dt = p.replay[0];  // prescribed step sequence: the first attempt's step
   z.n_out = n_out;
   z.ratio_prev = 1e-4;
   // rows whose time equals the start time are y0 itself (the reference's `while next_t > t1` does not
@@ -103,6 +104,39 @@ __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double 
   else
     plan_next<double>(&z, p, step_t, t_stage_out);
   *c = z;
+}
+
+// New output list for a running solve (AdaptiveRKSolver.step(next_t), base_adaptive_solver_rk.py:116-127): rows of the new
+// list that the last ACCEPTED step already covers are reported at once (the reference's `while next_t > rk_state.t1` is
+// false for them and it interpolates in the retained step); the `max_num_steps` count restarts, as it does per step() call.
+__global__ __launch_bounds__(64) void xde_ctrl_retarget_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const double* t_span,
+                                                               int32_t n_out, xde_ctrl_t* mirror) {
+  __shared__ xde_ctrl_t zs;
+  constexpr int kWords = sizeof(xde_ctrl_t) / 8;
+  if (threadIdx.x < kWords) {
+    const uint64_t word = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
+    reinterpret_cast<uint64_t*>(&zs)[threadIdx.x] = word;
+    if (mirror && threadIdx.x == offsetof(xde_ctrl_t, seq) / 8) invalidate_slot(mirror, int64_t(word) + 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    xde_ctrl_t z = zs;
+    z.seq += 1;
+    const double dir = double(p.direction);
+    int e = 0;
+    if (z.accept && z.n_accept > 0)
+      while (e < n_out && dir * t_span[e] <= dir * z.t1) ++e;
+    z.n_out = n_out;
+    z.out_begin = 0;
+    z.out_end = e;
+    z.next_out = e;
+    z.done = (e >= n_out) ? 1 : 0;
+    z.steps_in_interval = 0;
+    if (z.status == XDE_STATUS_MAX_STEPS) z.status = XDE_STATUS_OK;
+    zs = z;
+  }
+  __syncthreads();
+  publish_block(c, zs, mirror);
 }
 
 // Hairer's initial-step heuristic, scalar part (solver/base_adaptive_solver.py:55-72), in the state dtype Y with the
@@ -238,6 +272,18 @@ int xde_ctrl_init(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, double t_st
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(xde_ctrl_init_kernel, dim3(1), dim3(64), 0, st, ctrl, *params, t_start, first_step, n_out,
                      t_span_dev, step_t_dev, t_stage_out, seq0, first_step_dev);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_ctrl_retarget(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const double* t_span_dev, int32_t n_out,
+                      xde_ctrl_t* host_mirror, void* stream) {
+  if (!ctrl || !t_span_dev) return fail(XDE_EBADARG, "xde_ctrl_retarget: null pointer");
+  int rc = check_params(params, "xde_ctrl_retarget");
+  if (rc != XDE_OK) return rc;
+  if (n_out < 1) return fail(XDE_EBADARG, "xde_ctrl_retarget: n_out must be >= 1");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(xde_ctrl_retarget_kernel, dim3(1), dim3(64), 0, st, ctrl, *params, t_span_dev, n_out, host_mirror);
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

@@ -101,6 +101,13 @@ __device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double r
     if (mag > max_step) mag = max_step;
     dt_next = (mag != mag) ? dt_next : dir * mag;
   }
+  // prescribed step sequence (xde_ctrl_params_t.replay): this attempt's verdict and the next attempt's step come from
+  // the table; the error ratio above is still what the kernels measured
+  if (p.replay && c->n_steps < p.n_replay) {
+    const int64_t i = c->n_steps;
+    accept = p.replay[2 * i + 1] != 0.0 ? 1 : 0;
+    if (i + 1 < p.n_replay) dt_next = TT(p.replay[2 * (i + 1)]);
+  }
 
   c->n_steps += 1;
   c->steps_in_interval += 1;
@@ -136,6 +143,36 @@ __device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double r
   plan_next<TT>(c, p, step_t, t_stage_out);
 }
 
+// The pinned host mirror slot of a control block is a seqlock (slot[seq % SLOTS]): its seq word is invalidated FIRST
+// (invalidate_slot — by one lane of wave 0, as early as the launch knows its sequence number, so that the store has long
+// landed when the payload is ready), the payload words follow, and the new seq is stored last after a system-scope
+// release.  A reader that sees the same valid seq before and after its copy has an untorn block (xde_ctrl_wait).
+__device__ inline void invalidate_slot(xde_ctrl_t* mirror, int64_t seq_next) {
+  __hip_atomic_store(&mirror[seq_next % XDE_MIRROR_SLOTS].seq, int64_t(-1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Write a finished control block back: one wave instruction to the device block, one to the mirror slot.  Called by all
+// threads of the block after `zs` is complete and visible in LDS and after invalidate_slot(mirror, zs.seq) by wave 0.
+__device__ inline void publish_block(xde_ctrl_t* c, const xde_ctrl_t& zs, xde_ctrl_t* mirror) {
+  constexpr int kWords = sizeof(xde_ctrl_t) / 8;
+  constexpr int kSeqWord = offsetof(xde_ctrl_t, seq) / 8;
+  static_assert(kWords <= 64, "the control block is published by ONE wave");
+  xde_ctrl_t* ms = mirror ? mirror + (zs.seq % XDE_MIRROR_SLOTS) : nullptr;
+  if (threadIdx.x < 64) {
+    if (mirror) __threadfence_system();  // the invalidation is ordered before the payload stores
+    if (threadIdx.x < kWords) {
+      const uint64_t word = reinterpret_cast<const uint64_t*>(&zs)[threadIdx.x];
+      reinterpret_cast<uint64_t*>(c)[threadIdx.x] = word;
+      if (mirror && threadIdx.x != kSeqWord)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(ms) + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (mirror) {  // the wave that wrote the words releases them, then publishes seq
+      __threadfence_system();
+      if (threadIdx.x == 0) __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // The controller workgroup: reduce the partials (or take finalised sums), run the controller on a register copy of
 // the control block, write it back to the device block and the pinned host mirror.  FUSED = called by the last
 // workgroup of the fused error-norm launch (partials were published write-through inside this launch).
@@ -147,11 +184,13 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
   __shared__ double seg_nf[XDE_MAX_SEG];
   __shared__ xde_ctrl_t zs;
   constexpr int kWords = sizeof(xde_ctrl_t) / 8;
-  constexpr int kSeqWord = offsetof(xde_ctrl_t, seq) / 8;
   // the control block is fetched by the first lanes while the partials are being reduced (it is written only by
   // controller launches, i.e. before this launch started)
-  if (threadIdx.x < kWords)
-    reinterpret_cast<uint64_t*>(&zs)[threadIdx.x] = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
+  if (threadIdx.x < kWords) {
+    const uint64_t word = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
+    reinterpret_cast<uint64_t*>(&zs)[threadIdx.x] = word;
+    if (mirror && threadIdx.x == offsetof(xde_ctrl_t, seq) / 8) invalidate_slot(mirror, int64_t(word) + 1);
+  }
   if (sums) {
     if (threadIdx.x < XDE_MAX_SEG) {
       seg_val[threadIdx.x] = sums[threadIdx.x];
@@ -189,23 +228,7 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
     zs = z;
   }
   __syncthreads();
-  // write-back: one wave instruction to the device block, one to the pinned host mirror slot
-  // (slot[seq % SLOTS]); the slot's seq word is stored last, after a system-scope release
-  if (threadIdx.x < kWords) {
-    const uint64_t word = reinterpret_cast<const uint64_t*>(&zs)[threadIdx.x];
-    reinterpret_cast<uint64_t*>(c)[threadIdx.x] = word;
-    if (mirror && threadIdx.x != kSeqWord) {
-      xde_ctrl_t* ms = mirror + (zs.seq % XDE_MIRROR_SLOTS);
-      __hip_atomic_store(reinterpret_cast<uint64_t*>(ms) + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  if (mirror && threadIdx.x < 64) {  // the wave that wrote the words releases them, then publishes seq
-    __threadfence_system();
-    if (threadIdx.x == 0) {
-      xde_ctrl_t* ms = mirror + (zs.seq % XDE_MIRROR_SLOTS);
-      __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+  publish_block(c, zs, mirror);
 }
 
 

@@ -29,7 +29,7 @@ import torch
 
 from .. import _hip
 from ..utils.ode_utils import native_norm_spec
-from ._common import as_operand, np_dtype, scalar, storage_ptr, upload
+from ._common import as_operand, np_dtype, scalar, storage_ptr, t_span_to_host, upload
 from .base_adaptive_solver import AdaptiveSolver
 
 _ButcherTableau = collections.namedtuple("_ButcherTableau", "alpha, beta, c_sol, c_error")
@@ -117,6 +117,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         pi_beta=0.04,
         process_group=None,
         record_trace=False,
+        _replay=None,
+        _step_hook=None,
         _xde_segments=None,
         _xde_segment_shapes=None,
         **kwargs,
@@ -152,6 +154,14 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self.process_group = process_group
         self.record_trace = bool(record_trace)
         self.trace = []  # (t0, dt, ratio, accept) per attempted step when record_trace is set
+        # parity harness: a prescribed (dt, accept) sequence the device controller follows (xde_ctrl_params_t.replay)
+        # and a callable(index, y0, y1, ks, ctrl) invoked after every attempt of the "sync" pipeline
+        self._replay = None if _replay is None else [(float(h), bool(a)) for h, a in _replay]
+        self._step_hook = _step_hook
+        if self._replay is not None and step_t is not None:
+            raise NotImplementedError("a prescribed step sequence and step_t clipping do not combine")
+        if _step_hook is not None and pipeline != "sync":
+            raise NotImplementedError("_step_hook observes attempts of pipeline='sync'")
         # XDE_FUSE_CONTROL=1: error norm + controller as ONE launch (xde_error_norm_control, last-workgroup-done).
         # Bit-identical, but measured no faster than two launches (the controller's latency chain just moves into
         # the tail of the norm kernel: 36.4 us vs 23.1 + 12 us on config 2), so it is off by default.
@@ -287,9 +297,14 @@ class AdaptiveRKSolver(AdaptiveSolver):
     # ------------------------------------------------------------------------------------------
     def _before_integrate(self, t_span):
         be = self.backend
-        y0 = self.y0
-        dev = y0.device
         tt = np_dtype(self.dtype)
+        if not isinstance(t_span, np.ndarray) or t_span.dtype != tt:  # direct callers (the step() API) pass tensors
+            t_span = t_span_to_host(t_span, tt)
+        self.y0 = y0 = as_operand(self.y0.detach())
+        be.require_device(y0)
+        dev = y0.device
+        self._base = None
+        self._kept = None  # step() API: operands of the last accepted step
         self._direction = -1 if t_span[1] < t_span[0] else 1
         self._t_host = t_span
         self._t_span_dev = upload(t_span.astype(np.float64), dev)
@@ -333,6 +348,11 @@ class AdaptiveRKSolver(AdaptiveSolver):
             p.alpha[i] = float(a)
         for i, c in enumerate(self._seg_count):
             p.seg_count[i] = float(c)
+        self._replay_dev = None
+        if self._replay:
+            tab = np.asarray([[d * abs(h), 1.0 if a else 0.0] for h, a in self._replay], dtype=np.float64)
+            self._replay_dev = upload(tab, dev)  # kept alive by the solver: params hold its raw pointer
+            p.replay, p.n_replay = self._replay_dev.data_ptr(), len(self._replay)
         self._params = p
 
         # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
@@ -521,6 +541,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
             c = be.ctrl_read(self._ctrl)  # the step's one host sync
             if self.record_trace:
                 self.trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
+            if self._step_hook is not None:
+                self._step_hook(self._n_attempts - 1, base[0], y1, ks, c)
             if c.accept:
                 if c.out_end > c.out_begin and self._solution is not None:
                     self._dense(self._solution, base, y1, ks)
@@ -533,6 +555,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
 
     GRAPH_WARMUP_ATTEMPTS = 2
     GRAPH_LOOKAHEAD = 2  # replays in flight before the host waits (ring has XDE_MIRROR_SLOTS = 4 slots)
+    assert GRAPH_LOOKAHEAD < _hip.XDE_MIRROR_SLOTS  # an unread block must never be overwritten (the slot is a seqlock too)
 
     def _advance_graph(self, max_attempts):
         be = self.backend
@@ -622,9 +645,57 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._last = c
         return c
 
-    # base_adaptive_solver_rk.py:116-127 — kept for API parity: advance to `next_t` and interpolate
+    # base_adaptive_solver_rk.py:116-127
     def step(self, next_t):
-        raise NotImplementedError(
-            "AdaptiveRKSolver.step(next_t) is folded into integrate(): the device controller tracks the next "
-            "output time (xde_ctrl_t.next_out) and the dense-output kernel writes solution rows directly"
-        )
+        """Advance the solve until an accepted step reaches ``next_t`` and return the dense-output value there — the
+        reference's public per-solver method (``while next_t > rk_state.t1: _adaptive_step``; then ``interp_evaluate``).
+        Call after ``_before_integrate(t_span)``; ``integrate`` is this loop with the output bookkeeping on the device
+        for ALL rows at once, and a manual ``step(t_i)`` loop gives the same rows bit for bit.  ``next_t`` may be any time
+        inside or after the last accepted step (several calls can land in one step: no new attempt is made for them).
+        Host-driven by nature: attempts are resolved one at a time whatever ``pipeline`` says."""
+        be = self.backend
+        if getattr(self, "_base", None) is None:
+            self._solution = None
+            self._base = (self.rk_state.y1, self.rk_state.f1)
+            self._pending = None
+            self._n_attempts = 0
+            self._last = None
+            self._graph = None
+        y0 = self.y0
+        d = self._direction
+        tt = np_dtype(self.dtype)
+        nt = tt(float(next_t))
+        # the controller and the dense-output kernel now look at this one-entry output list
+        self._t_span_dev = t_dev = upload(np.asarray([nt], dtype=np.float64), y0.device)
+        be.ctrl_retarget(self._ctrl, self._params, t_dev, 1)
+        c = be.ctrl_read(self._ctrl)
+        row = torch.empty((1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+        if c.out_end > c.out_begin:
+            # already covered by the retained step: interpolate there                              :127
+            # (ode_utils.py:65-67: the interpolant is valid on [t0, t1] of that step only)
+            assert d * tt(c.t0) <= d * nt, "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(c.t0, nt, c.t1)
+            self._dense(row, *self._kept)
+        else:
+            if not d * nt > d * tt(c.t1):
+                assert c.n_accept == 0, "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(c.t0, nt, c.t1)
+                # nothing stepped yet and next_t is the start time: the reference evaluates its initial interpolant
+                # ([y0]*5, base_adaptive_solver_rk.py:91) on the empty interval; the value there is y0
+                row[0] = y0
+                return row[0]
+            while True:
+                base = self._base
+                y1, ks = self._attempt(base)
+                self._n_attempts += 1
+                c = be.ctrl_read(self._ctrl)
+                if self.record_trace:
+                    self.trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
+                if c.accept:
+                    self._kept = (base, y1, ks)
+                    self._base = (y1, ks[-1])
+                self._raise_status(c)
+                if c.accept and c.out_end > c.out_begin:
+                    self._dense(row, base, y1, ks)
+                    break
+        self._last = c
+        self._finish(c, self._base)
+        return row[0]

@@ -264,6 +264,8 @@ class NumpyDoubleBackend:
         if first_step_dev is not None:
             first_step = float(params.direction) * abs(float(first_step_dev.numpy()[0]))
         c.dt = float(first_step)
+        if params.replay and params.n_replay > 0:
+            c.dt = float((C.c_double * 2).from_address(params.replay)[0])
         c.n_out = n_out
         c.ratio_prev = 1e-4
         d = float(params.direction)
@@ -281,6 +283,22 @@ class NumpyDoubleBackend:
             idx = min(idx, params.n_step_t - 1)
         c.next_step_index = idx
         self._plan_next(c, params, None if step_t_dev is None else step_t_dev.numpy(), t_stage)
+
+    def ctrl_retarget(self, ctrl, params, t_span_dev, n_out):
+        c = self._c(ctrl)
+        c.seq += 1
+        d = float(params.direction)
+        ts = t_span_dev.numpy()
+        e = 0
+        if c.accept and c.n_accept > 0:
+            while e < n_out and d * ts[e] <= d * c.t1:
+                e += 1
+        c.n_out = n_out
+        c.out_begin, c.out_end, c.next_out = 0, e, e
+        c.done = 1 if e >= n_out else 0
+        c.steps_in_interval = 0
+        if c.status == _hip.STATUS_MAX_STEPS:
+            c.status = _hip.STATUS_OK
 
     def rk_control(self, ctrl, params, ws, sums, t_span_dev, step_t_dev, t_stage):
         self.launches.append("control")
@@ -330,6 +348,11 @@ class NumpyDoubleBackend:
             if mag == mag:
                 mag = min(max(mag, min_step), max_step)
                 dt_next = d * mag
+        if p.replay and c.n_steps < p.n_replay:  # prescribed step sequence (xde_ctrl_params_t.replay)
+            tab = (C.c_double * (2 * p.n_replay)).from_address(p.replay)
+            accept = 1 if tab[2 * c.n_steps + 1] != 0.0 else 0
+            if c.n_steps + 1 < p.n_replay:
+                dt_next = TT(tab[2 * (c.n_steps + 1)])
         c.n_steps += 1
         c.steps_in_interval += 1
         if accept:

@@ -1241,3 +1241,62 @@ def test_pi_controller_vs_its_cpu_statement(dev, pipeline):
         assert np.allclose(mine[:, :2], theirs[:, :2], rtol=1e-8, atol=1e-12)
         # (the error ratio is a cancellation: ulp differences between numpy's and the device's func show up at 1e-7)
         assert np.allclose(mine[:, 2], theirs[:, 2], rtol=1e-6, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------------
+# AdaptiveRKSolver.step(next_t) — the reference's public per-solver method (base_adaptive_solver_rk.py:116-127)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["dopri5", "bosh3", "dopri8"])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_manual_step_loop_equals_integrate(dev, name, reverse):
+    """`_before_integrate(t)` + `step(t_i)` for every output time gives the rows of `integrate(t)` bit for bit (same attempts,
+    same dense-output arithmetic), with the same NFE and counts."""
+    from paddlexde_amd.xde import BaseODE
+
+    A, y0 = _linear(48, 24, torch.float32)
+    Ad = A.to(dev)
+    t = torch.linspace(0.0, 2.0, 9)
+    if reverse:
+        t = t.flip(0).contiguous()
+
+    def make(**kw):
+        y0d = y0.to(dev)
+        return ADAPTIVE[name](xde=BaseODE(lambda t_, y: y @ Ad.T, y0=y0d, t_span=t), y0=y0d, rtol=1e-5, atol=1e-7, norm=_rms_norm, **kw)
+
+    s1 = make()
+    want = s1.integrate(t)
+    s2 = make(record_trace=True)
+    s2._before_integrate(t)
+    rows = [y0.to(dev)] + [s2.step(ti) for ti in t[1:]]
+    s2._after_integrate()
+    got = torch.stack(rows)
+    assert torch.equal(got, want)
+    assert (s2.stats["n_accept"], s2.stats["n_reject"], s2.stats["nfe"]) == (s1.stats["n_accept"], s1.stats["n_reject"], s1.stats["nfe"])
+
+
+def test_step_at_arbitrary_times_vs_oracle(dev):
+    """step() takes any time at or after the start of the last accepted step: times that are not in t_span, several of them
+    inside one accepted step (no new attempt then), and the oracle's step() agrees; going back before the retained step is the
+    reference's `invalid interpolation` assertion (ode_utils.py:65-67)."""
+    from paddlexde_amd.xde import BaseODE
+
+    A, y0 = _linear(16, 8, torch.float64)
+    An, Ad = A.numpy(), A.to(dev)
+    t = np.array([0.0, 3.0])
+    so = O.AdaptiveRKSolver(lambda t_, y: y @ An.T, y0.numpy(), 1e-6, 1e-8, method="dopri5", norm=O._rms_norm, dtype=np.float64)
+    so._before_integrate(t)
+    y0d = y0.to(dev)
+    s = Dopri5(xde=BaseODE(lambda t_, y: y @ Ad.T, y0=y0d, t_span=torch.from_numpy(t)), y0=y0d, rtol=1e-6, atol=1e-8, norm=_rms_norm,
+               dtype=torch.float64)
+    s._before_integrate(torch.from_numpy(t))
+    times = [0.3, 0.31, 0.32, 1.234, 2.5, 2.5, 2.9999]
+    for x in times:
+        n0 = s.stats.get("n_steps", 0)
+        got = s.step(x).cpu().numpy()
+        ref = so.step(np.float64(x))
+        assert P.parity_ok(got, ref, rtol=1e-9, atol=1e-11), (x, P.worst(got, ref, 1e-9, 1e-11))
+        assert s.stats["n_steps"] == len(so.trace)  # attempts were made exactly when the oracle made them
+    assert s.stats["n_steps"] < len(times) + 10
+    with pytest.raises(AssertionError, match="invalid interpolation"):
+        s.step(0.1)
+    s._after_integrate()

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _hip.load_library()
     for sym in _declared():
         assert hasattr(lib, sym), sym
-    assert lib.xde_abi_version() == 1
+    assert lib.xde_abi_version() == _hip.ABI_VERSION == 2
 
 
 def test_struct_layouts_match():
