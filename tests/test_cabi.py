@@ -104,6 +104,7 @@ def test_every_entry_point_rejects_null_arguments():
         "xde_norm_result": lambda: lib.xde_norm_result(None, None, 1, 0, 0, None, None),
         "xde_rk_control": lambda: lib.xde_rk_control(None, C.byref(P), None, None, None, None, None, None, None),
         "xde_ctrl_init": lambda: lib.xde_ctrl_init(None, C.byref(P), 0.0, 0.1, 2, None, None, None, 0, None, None),
+        "xde_ctrl_retarget": lambda: lib.xde_ctrl_retarget(None, C.byref(P), None, 1, None, None),
         "xde_initial_step": lambda: lib.xde_initial_step(0, None, None, C.byref(P), 0.0, None, 0, None, None),
         "xde_ctrl_read": lambda: lib.xde_ctrl_read(None, None, None),
         "xde_host_alloc": lambda: lib.xde_host_alloc(0, None),
