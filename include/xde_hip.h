@@ -134,6 +134,8 @@ typedef struct xde_segments {
 const char* xde_last_error(void);
 int xde_abi_version(void);
 int64_t xde_sizeof_ctrl(void);
+/* sizeof(xde_ctrl_params_t): a binding that mirrors the struct by hand (ctypes, cgo) checks its layout against this */
+int64_t xde_sizeof_ctrl_params(void);
 /* bytes of scratch a norm launch needs (block partials + finalised per-segment sums) */
 int64_t xde_workspace_bytes(void);
 

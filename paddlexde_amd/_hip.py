@@ -29,6 +29,7 @@ SYMBOLS = (
     "xde_last_error",
     "xde_abi_version",
     "xde_sizeof_ctrl",
+    "xde_sizeof_ctrl_params",
     "xde_workspace_bytes",
     "xde_stage_combine",
     "xde_error_norm_partial",
@@ -165,6 +166,7 @@ def load_library():
         lib.xde_last_error.argtypes = []
         lib.xde_abi_version.restype = i32
         lib.xde_sizeof_ctrl.restype = i64
+        lib.xde_sizeof_ctrl_params.restype = i64
         lib.xde_workspace_bytes.restype = i64
         lib.xde_stage_combine.restype = i32
         lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, C.c_uint32, vp]
@@ -215,6 +217,8 @@ def load_library():
             raise XdeError("libxde_hip.so ABI version mismatch")
         if lib.xde_sizeof_ctrl() != C.sizeof(XdeCtrl):
             raise XdeError("xde_ctrl_t layout mismatch between header and ctypes mirror")
+        if lib.xde_sizeof_ctrl_params() != C.sizeof(XdeCtrlParams):
+            raise XdeError("xde_ctrl_params_t layout mismatch between header and ctypes mirror")
         _lib = lib
     return _lib
 

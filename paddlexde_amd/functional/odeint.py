@@ -27,6 +27,16 @@ def odeint(
     """Integrate ``dy/dt = func(t, y), y(t[0]) = y0`` and return y at every ``t_span`` point."""
     if not torch.is_tensor(t_span):
         t_span = torch.as_tensor(t_span)
+    if _wants_autograd(func, y0, t_span, solver):
+        # The reference's adaptive solvers are eager framework ops, so `odeint(..., solver=Dopri5)` + `loss.backward()`
+        # trains there.  Here the adaptive step kernels read dt from device memory and record no autograd graph; rather than
+        # hand back a silently detached result, the call is served by the adjoint method (gradients w.r.t. y0, func's
+        # parameters and t_span).  Deliberate deviation: continuous adjoint instead of back-propagation through the steps.
+        from .odeint_adjoint import odeint_adjoint
+
+        _warn_once_autograd_route()
+        params = None if isinstance(func, torch.nn.Module) else ()
+        return odeint_adjoint(func, y0, t_span, rtol=rtol, atol=atol, solver=solver, options=options, adjoint_params=params)
     if isinstance(y0, (tuple, list)):
         return _odeint_tuple(func, tuple(y0), t_span, solver, rtol=rtol, atol=atol, options=options)
 
@@ -38,6 +48,34 @@ def odeint(
     solution = xde.format(solution)
 
     return solution
+
+
+_ROUTE_WARNED = False
+
+
+def _warn_once_autograd_route():
+    global _ROUTE_WARNED
+    if not _ROUTE_WARNED:
+        _ROUTE_WARNED = True
+        import warnings
+
+        warnings.warn(
+            "paddlexde_amd: odeint() with an adaptive solver was called with gradients enabled on y0 / func's parameters / "
+            "t_span; the adaptive kernels record no autograd graph, so the call is served by odeint_adjoint (continuous "
+            "adjoint). Call odeint_adjoint directly to choose its options, or wrap inference in torch.no_grad().",
+            stacklevel=4)
+
+
+def _wants_autograd(func, y0, t_span, solver):
+    """An adaptive solve whose result the caller may differentiate: grad mode is on and y0, t_span or a parameter of func
+    requires grad.  (Fixed solvers record their own graph, solver/_autograd.py; tuple states go through untouched.)"""
+    if not torch.is_grad_enabled() or not torch.is_tensor(y0):
+        return False
+    if isinstance(solver, type) and issubclass(solver, FixedSolver):
+        return False
+    if y0.requires_grad or t_span.requires_grad:
+        return True
+    return isinstance(func, torch.nn.Module) and any(p.requires_grad for p in func.parameters())
 
 
 def _segment_layout(tensors):

@@ -33,9 +33,33 @@ def _time_first(x, y0_shape, T, fixed):
     return x.reshape(lead + (T, L, D)).movedim(len(lead), 0)
 
 
-def _make_augmented_dynamics(func, adjoint_params, t_requires_grad):
+def _group_sum(tensors, pg):
+    """Sum a list of small tensors over the batch-sharding process group with ONE all-reduce; returns new tensors."""
+    import torch.distributed as dist
+
+    group = None if pg is True else pg
+    tensors = [x.contiguous() for x in tensors]
+    flat = torch.cat([x.reshape(-1) for x in tensors]) if len(tensors) != 1 else tensors[0].reshape(-1).clone()
+    staged = flat.is_cuda and dist.get_backend(group) == "gloo"  # rehearsal transport: gloo reduces on the host
+    buf = flat.cpu() if staged else flat
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if staged:
+        flat.copy_(buf)
+    outs, off = [], 0
+    for x in tensors:
+        outs.append(flat[off : off + x.numel()].view(x.shape))
+        off += x.numel()
+    return outs
+
+
+def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, reduce_params=False):
     """odeint_adjoint.py:89-124: dynamics of the original system augmented with the adjoint wrt y and an integrator
-    wrt t and the parameters.  ``y_aug = (adj_t, y, adj_y, *adj_params)``; only y and adj_y are read."""
+    wrt t and the parameters.  ``y_aug = (adj_t, y, adj_y, *adj_params)``; only y and adj_y are read.
+
+    Batch-sharded run (``pg``): ``vjp_y`` and ``f`` are per-row quantities of this rank's rows, but ``vjp_t`` and the
+    ``vjp_params`` are sums over rows.  Where the step control looks at them — ``adj_t`` when time gradients are wanted,
+    the parameter adjoints under the default adjoint norm (``reduce_params``) — they are summed over the group here, so
+    that every rank integrates the GLOBAL ``adj_t`` / ``adj_params`` and the all-reduced norm is exactly the unsharded one."""
 
     def augmented_dynamics(t, y_aug):
         y = y_aug[1]
@@ -55,6 +79,13 @@ def _make_augmented_dynamics(func, adjoint_params, t_requires_grad):
         vjp_params = [
             torch.zeros_like(param) if vjp_param is None else vjp_param for param, vjp_param in zip(adjoint_params, vjp_params)
         ]
+        if pg is not None and (t_requires_grad or (reduce_params and vjp_params)):
+            if t_requires_grad and reduce_params:
+                vjp_t, *vjp_params = _group_sum([vjp_t] + vjp_params, pg)
+            elif t_requires_grad:
+                (vjp_t,) = _group_sum([vjp_t], pg)
+            else:
+                vjp_params = _group_sum(vjp_params, pg)
         return (vjp_t, func_eval.detach(), vjp_y, *vjp_params)
 
     return augmented_dynamics
@@ -75,15 +106,22 @@ def _make_functional_dynamics(func, adjoint_params, t_requires_grad):
             "adjoint_options['graph_func'] needs func to be an nn.Module and adjoint_params to be (a subset of) its parameters"
         )
 
+    # the capture cache is keyed weakly by the module (_GRAPH_CACHE): what it stores must not keep the module alive
+    func_ref = weakref.ref(func)
+    del func
+
     def augmented_dynamics(t, y_aug):
         y = y_aug[1]
         adj_y = y_aug[2]
+        module = func_ref()
+        if module is None:
+            raise RuntimeError("the module this captured dynamics was built for no longer exists")
         with torch.enable_grad():
             t_ = t.detach()
             t = t_.clone().requires_grad_(True)
             y = y.detach().clone().requires_grad_(True)
             ps = tuple(p.detach().requires_grad_(True) for p in adjoint_params)  # aliases, no copy
-            func_eval = torch.func.functional_call(func, dict(zip(order, ps)), (t if t_requires_grad else t_, y))
+            func_eval = torch.func.functional_call(module, dict(zip(order, ps)), (t if t_requires_grad else t_, y))
             vjp_t, vjp_y, *vjp_params = torch.autograd.grad(func_eval, (t, y) + ps, -adj_y, allow_unused=True)
         vjp_t = torch.zeros_like(t) if vjp_t is None else vjp_t
         vjp_y = torch.zeros_like(y) if vjp_y is None else vjp_y
@@ -173,7 +211,21 @@ class OdeintAdjointMethod(torch.autograd.Function):
             ##################################
             #    Set up backward ODE func    #
             ##################################
-            augmented_dynamics = _make_augmented_dynamics(func, adjoint_params, t_requires_grad)
+            # batch-sharded backward: which of the row-summed adjoints are kept global during the solve (see
+            # _make_augmented_dynamics); the others are per-rank partial sums until the one all-reduce at the end
+            pg = adjoint_options.get("process_group")
+            spec = native_norm_spec(adjoint_options.get("norm"))
+            reduce_params = (pg is not None and not _is_fixed(adjoint_method)  # (a fixed grid has no step control)
+                             and not (spec is not None and spec[0] == "mixed" and spec[1] is not None))
+            if pg is not None and spec is None and not _is_fixed(adjoint_method):
+                raise NotImplementedError(
+                    "a batch-sharded odeint_adjoint needs the default adjoint norm or \"seminorm\" (a user norm callable "
+                    "cannot be all-reduced)")
+            if pg is not None and adjoint_options.get("_graphed") is not None and (reduce_params or t_requires_grad):
+                raise NotImplementedError(
+                    "adjoint_options['graph_func'] with a process_group needs the \"seminorm\" adjoint norm and no time "
+                    "gradients (the captured dynamics cannot hold the per-evaluation all-reduce)")
+            augmented_dynamics = _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg, reduce_params)
             solver_options = {k: v for k, v in adjoint_options.items() if k not in ("graph_func", "_graphed")}
             if adjoint_options.get("_graphed") is not None:
                 # the captured FLAT dynamics (same segment layout) replaces the unpack -> dynamics -> pack wrapper:
@@ -193,6 +245,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
                 if t_requires_grad:
                     func_eval = func(t_span[i], y_ans[i])
                     dLd_cur_t = func_eval.reshape(-1).dot(grad_y[i].reshape(-1))
+                    if pg is not None:  # a sum over rows: global, like adj_t itself
+                        (dLd_cur_t,) = _group_sum([dLd_cur_t], pg)
                     flat[s_t] -= dLd_cur_t.to(adt)  # aug_state[0] = aug_state[0] - dLd_cur_t
                     grad_t_span[i] = dLd_cur_t
 
@@ -218,6 +272,10 @@ class OdeintAdjointMethod(torch.autograd.Function):
 
             adj_y = aug_state[2].reshape(ctx.y0_shape)  # D6: returned (the reference drops it)
             adj_params = aug_state[3:]
+            if pg is not None and not reduce_params and len(adj_params):
+                # per-rank partial sums so far ("seminorm" never looks at them): ONE all-reduce makes them the gradient of
+                # the global loss, identical on every rank — the same thing the default norm's path returns
+                adj_params = _group_sum(list(adj_params), pg)
 
         return (None, adj_y, grad_t_span, None, None, None, None, None, None, None, None, None, None, *adj_params)
 

@@ -195,6 +195,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
                 raise TypeError("options['norm'] must be callable")
             if pipeline != "sync":
                 raise NotImplementedError("custom norm callables run with pipeline='sync' only")
+            if process_group is not None:
+                raise NotImplementedError("a user norm callable cannot be all-reduced over a process_group; use _rms_norm / "
+                                          "_linf_norm (or, for odeint_adjoint, the default adjoint norm or \"seminorm\")")
             self._norm_kind = _hip.NORM_LINF
             self._norm_segs = [(0, n)]
             self._seg_count_local = [1.0]
@@ -211,9 +214,20 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._seg_count_local = [float(l) for _, l in self._norm_segs]
         else:
             raise ValueError("unknown native norm spec {!r}".format(spec))
+        # One norm launch reduces up to XDE_MAX_SEG segments.  A tuple state with more of them (odeint_adjoint's default norm
+        # has one segment per parameter tensor: a module with > 13 of them) is reduced in chunks of XDE_MAX_SEG segments —
+        # one partial + finalize + result launch per chunk, each over its own segments only, so nothing is read twice — and
+        # the chunk results are max-combined on the device; the controller then takes that scalar the way it takes a custom
+        # norm's (a 1-segment "linf" value).  Same value as the single launch: max over segments of the per-segment RMS.
+        self._chunks = None
+        self._ctrl_norm_kind = self._norm_kind
         if len(self._norm_segs) > _hip.XDE_MAX_SEG:
-            raise NotImplementedError("at most {} segments take part in a native norm".format(_hip.XDE_MAX_SEG))
-        self._xsegs = _hip.make_segments(self._norm_segs)
+            m = _hip.XDE_MAX_SEG
+            self._chunks = [(i, _hip.make_segments(self._norm_segs[i : i + m])) for i in range(0, len(self._norm_segs), m)]
+            self._xsegs = self._chunks[0][1]
+            self._ctrl_norm_kind = _hip.NORM_LINF
+        else:
+            self._xsegs = _hip.make_segments(self._norm_segs)
 
     # ------------------------------------------------------------------------------------------
     # framework call
@@ -282,15 +296,41 @@ class AdaptiveRKSolver(AdaptiveSolver):
             scale = float(atol) + y0.abs() * float(rtol)
             vals = [self._user_norm(((a - b) if b is not None else a) / scale) for a, b in pairs]
             return torch.stack(vals).tolist()
-        be = self.backend
         res = torch.empty(len(pairs), dtype=torch.float64, device=y0.device)
-        sdt = _hip.dtype_code(y0.dtype)
         for i, (a, b) in enumerate(pairs):
-            be.scaled_norm_partial(a, b, y0, float(rtol), float(atol), self._xsegs, self._norm_kind, self._ws, 0)
+            self._scaled_norm_into(a, b, y0, rtol, atol, res[i : i + 1])
+        return res.tolist()
+
+    def _reduce_chunks(self, launch_partial, out, nonfinite_out=None):
+        """Run one norm over all segments: ``launch_partial(xsegs)`` enqueues the partial kernel for one chunk of segments;
+        the scalar norm (max over every segment) lands in ``out`` (device double[1])."""
+        be = self.backend
+        sdt = _hip.dtype_code(self.y0.dtype)
+        m = _hip.XDE_MAX_SEG
+        if self._chunks is None:
+            launch_partial(self._xsegs)
             be.norm_finalize(self._ws, 0, self._sums)
             self._allreduce_sums(self._sums)
-            be.norm_result(self._sums, self._seg_count, self._norm_kind, sdt, res[i : i + 1])
-        return res.tolist()
+            be.norm_result(self._sums, self._seg_count, self._norm_kind, sdt, out)
+            return
+        cres = torch.empty(len(self._chunks), dtype=torch.float64, device=self.y0.device)
+        nf = None
+        for ci, (first, xs) in enumerate(self._chunks):
+            launch_partial(xs)
+            be.norm_finalize(self._ws, 0, self._sums)
+            self._allreduce_sums(self._sums)
+            be.norm_result(self._sums, self._seg_count[first : first + xs.n_seg], self._norm_kind, sdt, cres[ci : ci + 1])
+            if nonfinite_out is not None:
+                part = self._sums[m : m + xs.n_seg].sum()
+                nf = part if nf is None else nf + part
+        out.copy_(cres.max().reshape(out.shape))  # torch.max propagates NaN, like the kernels' max over segments
+        if nonfinite_out is not None:
+            nonfinite_out.copy_(nf.reshape(nonfinite_out.shape))
+
+    def _scaled_norm_into(self, a, b, y0, rtol, atol, out):
+        be = self.backend
+        self._reduce_chunks(
+            lambda xs: be.scaled_norm_partial(a, b, y0, float(rtol), float(atol), xs, self._norm_kind, self._ws, 0), out)
 
     # ------------------------------------------------------------------------------------------
     # base_adaptive_solver_rk.py:81-114
@@ -312,6 +352,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._t_stage, self._ctrl, self._ws, self._sums = w.t_stage, w.ctrl, w.ws, w.sums
         self._t_views = [self._t_stage[i] for i in range(self._n_stage)]  # the 0-dim stage times handed to func
         self._seg_count = self._global_counts()
+        self._csums = be.new_sums(dev) if self._chunks is not None else None  # the controller's input in chunked mode
         self._scratch = torch.empty_like(y0)
         # the partial error sum of the last stage goes into the stage scratch buffer: by then the previous stage's
         # input it held has been consumed by func (one buffer less in the step's working set)
@@ -338,15 +379,15 @@ class AdaptiveRKSolver(AdaptiveSolver):
         p.time_dtype = _hip.dtype_code(self.dtype)
         p.state_dtype = _hip.dtype_code(y0.dtype)
         p.direction = d
-        p.norm_kind = self._norm_kind
+        p.norm_kind = self._ctrl_norm_kind
         p.n_stage = self._n_stage
-        p.n_seg = len(self._norm_segs)
+        p.n_seg = 1 if self._chunks is not None else len(self._norm_segs)
         p.n_step_t = len(step_t)
         p.pi_controller = 1 if self.controller == "PI" else 0
         p.pi_beta = self.pi_beta
         for i, a in enumerate(self.tableau.alpha):
             p.alpha[i] = float(a)
-        for i, c in enumerate(self._seg_count):
+        for i, c in enumerate([1.0] if self._chunks is not None else self._seg_count):
             p.seg_count[i] = float(c)
         self._replay_dev = None
         if self._replay:
@@ -388,10 +429,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         hs = torch.zeros(4, dtype=torch.float64, device=dev)
 
         def norm_into(a, b, out):
-            be.scaled_norm_partial(a, b, y0, float(self.rtol), float(self.atol), self._xsegs, self._norm_kind, self._ws, 0)
-            be.norm_finalize(self._ws, 0, self._sums)
-            self._allreduce_sums(self._sums)
-            be.norm_result(self._sums, self._seg_count, self._norm_kind, sdt, out)
+            self._scaled_norm_into(a, b, y0, self.rtol, self.atol, out)
 
         norm_into(y0, None, res[0:1])
         norm_into(f0, None, res[1:2])
@@ -443,6 +481,19 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._sums[0] = self._user_norm(r)
             self._sums[_hip.XDE_MAX_SEG] = (~torch.isfinite(y0)).sum()
             be.rk_control(ctrl, self._params, None, self._sums, self._t_span_dev, self._step_t_dev, self._t_stage)
+            return y1, ks
+        if self._chunks is not None:
+            def partial(xs):
+                if fuse:
+                    be.error_norm_partial([ks[-1]], [coef[-1]], y0, y1, float(self.rtol), float(self.atol), xs, self._norm_kind,
+                                          self._ws, ctrl=ctrl, y0_alt=y0_alt, e_pre=self._ebuf)
+                else:
+                    be.error_norm_partial([ks[j] for j in idx], coef, y0, y1, float(self.rtol), float(self.atol), xs,
+                                          self._norm_kind, self._ws, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
+
+            m = _hip.XDE_MAX_SEG
+            self._reduce_chunks(partial, self._csums[0:1], nonfinite_out=self._csums[m : m + 1])
+            be.rk_control(ctrl, self._params, None, self._csums, self._t_span_dev, self._step_t_dev, self._t_stage)
             return y1, ks
         if self.process_group is None and self._fuse_control:
             # single GPU: error norm + controller in ONE launch (the last workgroup to arrive runs the controller)

@@ -110,6 +110,51 @@ class _Capture:
     __slots__ = ("graph", "t", "y", "out")
 
 
+class _AutogradTargetProbe:
+    """While active, notes whether ``torch.autograd.grad`` / ``backward`` (and so ``Tensor.backward``) is asked to
+    differentiate with respect to — or accumulate into — real ``nn.Parameter`` leaves.
+
+    That is the one thing a func must not do inside a stream capture on ROCm 7.2 / torch 2.10: once a ``loss.backward()``
+    has run, parameter leaves own ``AccumulateGrad`` nodes bound to the default stream; the engine then synchronises the
+    capturing stream with the default stream at the end of the pass ("AccumulateGrad node's stream does not match" is the
+    warning it prints) and ``hipStreamEndCapture`` takes the process down with a segmentation fault — no Python error to
+    catch.  Differentiating w.r.t. fresh detached aliases (``p.detach().requires_grad_()`` + ``torch.func.functional_call``,
+    what ``odeint_adjoint(graph_func=True)`` does) is safe: they have no accumulator."""
+
+    def __init__(self):
+        self.hit = None
+
+    def _note(self, what, tensors):
+        if tensors is None:
+            self.hit = self.hit or (what + " without explicit inputs (accumulates into every parameter leaf)")
+            return
+        ts = tensors if isinstance(tensors, (tuple, list)) else (tensors,)
+        for x in ts:
+            if isinstance(x, torch.nn.Parameter):
+                self.hit = self.hit or (what + " with respect to an nn.Parameter leaf")
+                return
+
+    def __enter__(self):
+        ag = torch.autograd
+        self._grad, self._backward = ag.grad, ag.backward
+        probe = self
+
+        def grad(outputs, inputs, *a, **k):
+            probe._note("torch.autograd.grad", inputs)
+            return probe._grad(outputs, inputs, *a, **k)
+
+        def backward(tensors, grad_tensors=None, retain_graph=None, create_graph=False, grad_variables=None, inputs=None):
+            probe._note("backward()", inputs)
+            return probe._backward(tensors, grad_tensors, retain_graph, create_graph, grad_variables, inputs)
+
+        ag.grad, ag.backward = grad, backward
+        return self
+
+    def __exit__(self, *exc):
+        torch.autograd.grad, torch.autograd.backward = self._grad, self._backward
+        return False
+
+
 class GraphedFunc:
     def __init__(self, func, warmup=3, clone_outputs=True):
         self.func = func
@@ -120,6 +165,7 @@ class GraphedFunc:
         self.captures = 0
         self.eager_calls = 0
         self.safe_mode = False  # True once a capture holds a memset node (see CapturedGraph): replays are synchronised
+        self.refused = {}  # signature -> why this func is evaluated eagerly instead of being captured
 
     @staticmethod
     def _signature(t, y):
@@ -134,9 +180,25 @@ class GraphedFunc:
         key = self._signature(t, y)
         if key in self._captures:
             return self._captures[key]
+        if key in self.refused:
+            return None
         c = _Capture()
         c.t = t.detach().clone()
         c.y = _map(y, lambda a: a.detach().clone())
+        # Guard (see _AutogradTargetProbe): one eager evaluation tells whether func differentiates w.r.t. real parameter
+        # leaves; if it does, it is never captured — the failure mode would be a segmentation fault inside
+        # hipStreamEndCapture, not an exception — and this signature is evaluated eagerly from now on (same results).
+        with _AutogradTargetProbe() as probe:
+            self.func(c.t, c.y)
+        if probe.hit is not None:
+            import warnings
+
+            self.refused[key] = probe.hit
+            warnings.warn(
+                "paddlexde_amd.GraphedFunc: func is not captured into a HIP graph because it calls " + probe.hit + "; "
+                "it is evaluated eagerly instead. Differentiate with respect to detached aliases of the parameters "
+                "(torch.func.functional_call) to make it capturable.", stacklevel=3)
+            return None
         # func may differentiate (the adjoint's vjp): keep the autograd engine on THIS thread while warming up and
         # capturing — a backward pass executed by the engine's device thread would issue HIP calls from a second
         # thread into a stream that is being captured (observed to crash hipStreamEndCapture intermittently)
@@ -167,6 +229,9 @@ class GraphedFunc:
                 self.eager_calls += 1
                 return self.func(t, y)
             c = self.prepare(t, y)
+            if c is None:  # refused by the capture guard
+                self.eager_calls += 1
+                return self.func(t, y)
         c.t.copy_(t)
         if isinstance(y, (tuple, list)):
             for dst, src in zip(c.y, y):

@@ -1300,3 +1300,157 @@ def test_step_at_arbitrary_times_vs_oracle(dev):
     with pytest.raises(AssertionError, match="invalid interpolation"):
         s.step(0.1)
     s._after_integrate()
+
+
+def test_adaptive_odeint_with_grad_is_served_by_the_adjoint(dev):
+    """The reference's script `odeint(func, y0, t, solver=Dopri5)` + `loss.backward()` trains (its solvers are eager ops).  Here
+    the adaptive kernels record no graph, so odeint() hands such a call to odeint_adjoint: same forward values, and gradients
+    (dL/dy0 and every parameter) equal to calling odeint_adjoint directly — never a silently detached result."""
+    dtype = torch.float64
+    m = ODEFunc(dtype).to(dev)
+    y0 = (torch.rand(32, 2, generator=torch.Generator().manual_seed(0), dtype=dtype) * 4 - 2).to(dev)
+    t = torch.linspace(0.0, 1.0, 4, dtype=dtype).to(dev)
+    opts = {"norm": _rms_norm, "dtype": dtype}
+
+    def run(entry):
+        for p_ in m.parameters():
+            p_.grad = None
+        y = y0.clone().requires_grad_(True)
+        sol = entry(y)
+        sol.abs().mean().backward()
+        return sol.detach(), y.grad.clone(), [p_.grad.clone() for p_ in m.parameters()]
+
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = run(lambda y: odeint(m, y, t, solver=Dopri5, rtol=1e-7, atol=1e-9, options=opts))
+    b = run(lambda y: odeint_adjoint(m, y, t, solver=Dopri5, rtol=1e-7, atol=1e-9, options=opts))
+    assert a[0].requires_grad is False and torch.equal(a[0], b[0])
+    assert torch.equal(a[1], b[1])
+    for ga, gb in zip(a[2], b[2]):
+        assert torch.equal(ga, gb)
+    # a plain callable: only y0 can need a gradient
+    y = y0.clone().requires_grad_(True)
+    W = torch.eye(2, dtype=dtype, device=dev) * -0.5
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sol = odeint(lambda t_, x: x @ W, y, t, solver=Dopri5, rtol=1e-8, atol=1e-10, options=opts)
+    sol[-1].sum().backward()
+    assert torch.allclose(y.grad, torch.full_like(y, float(np.exp(-0.5))), rtol=1e-6)
+    # inference under no_grad is the plain forward path (no adjoint bookkeeping)
+    with torch.no_grad():
+        plain = odeint(m, y0, t, solver=Dopri5, rtol=1e-7, atol=1e-9, options=opts)
+    assert torch.equal(plain, b[0])
+
+
+def test_graphed_func_refuses_to_capture_a_vjp_wrt_parameter_leaves(dev):
+    """Regression for the process-killing path the round-1 logs show (segmentation fault in hipStreamEndCapture): after a
+    user's loss.backward() the parameter leaves own AccumulateGrad nodes bound to the default stream, and a func that calls
+    torch.autograd.grad with respect to those leaves must never be stream-captured.  GraphedFunc finds that out with one eager
+    probe evaluation, warns, and evaluates such a func eagerly from then on — same values, no capture, no crash.  The same
+    func written against detached aliases (functional_call) is captured."""
+    import warnings
+
+    from paddlexde_amd.utils import GraphedFunc
+
+    m = ODEFunc(torch.float32).to(dev)
+    y = (torch.rand(64, 2, generator=torch.Generator().manual_seed(0)) * 4 - 2).to(dev)
+    t = torch.zeros((), device=dev)
+    m(t, y).sum().backward()  # the user's earlier training step: every parameter leaf now owns an AccumulateGrad node
+    params = tuple(m.parameters())
+
+    def vjp_wrt_leaves(t_, y_):
+        with torch.enable_grad():
+            out = m(t_, y_)
+            gs = torch.autograd.grad(out, params, torch.ones_like(out))
+        return torch.cat([g.reshape(-1) for g in gs])
+
+    names = [n for n, _ in m.named_parameters()]
+
+    def vjp_wrt_aliases(t_, y_):
+        with torch.enable_grad():
+            ps = tuple(p.detach().requires_grad_(True) for p in params)
+            out = torch.func.functional_call(m, dict(zip(names, ps)), (t_, y_))
+            gs = torch.autograd.grad(out, ps, torch.ones_like(out))
+        return torch.cat([g.reshape(-1) for g in gs])
+
+    want = vjp_wrt_leaves(t, y)
+    gf = GraphedFunc(vjp_wrt_leaves)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = [gf(t, y) for _ in range(3)]
+    assert all(torch.equal(g, want) for g in got)
+    if str(dev).startswith("cuda"):
+        assert gf.captures == 0 and gf.replays == 0 and gf.eager_calls == 3 and len(gf.refused) == 1
+        assert any("nn.Parameter leaf" in str(x.message) for x in w)
+        gf2 = GraphedFunc(vjp_wrt_aliases)
+        got2 = [gf2(t, y) for _ in range(3)]
+        assert gf2.captures == 1 and gf2.replays == 3 and not gf2.refused
+        assert all(torch.allclose(g, want, rtol=1e-5, atol=1e-6) for g in got2)
+    assert torch.autograd.grad is not None and torch.autograd.grad.__module__.startswith("torch")  # the probe unpatched itself
+
+
+# ----------------------------------------------------------------------------------------------
+# the adjoint of a module with MANY parameter tensors (> XDE_MAX_SEG norm segments)
+# ----------------------------------------------------------------------------------------------
+class DeepFunc(nn.Module):
+    """n_layers Linear layers with tanh between them: 2 * n_layers parameter tensors."""
+
+    def __init__(self, n_layers, width, dtype):
+        super().__init__()
+        g = torch.Generator().manual_seed(7)
+        dims = [2] + [width] * (n_layers - 1) + [2]
+        self.layers = nn.ModuleList([nn.Linear(a, b, dtype=dtype) for a, b in zip(dims[:-1], dims[1:])])
+        for lin in self.layers:
+            lin.weight.data = 0.3 * torch.randn(lin.weight.shape, generator=g, dtype=dtype)
+            lin.bias.data = 0.05 * torch.randn(lin.bias.shape, generator=g, dtype=dtype)
+
+    def forward(self, t, y):
+        for i, lin in enumerate(self.layers):
+            y = lin(y)
+            if i + 1 < len(self.layers):
+                y = torch.tanh(y)
+        return y
+
+
+@pytest.mark.parametrize("n_layers", [6, 7, 20])
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+def test_adjoint_default_norm_with_many_parameter_tensors(dev, n_layers, pipeline):
+    """The default adjoint norm (functional/odeint_adjoint.py:284-287) has one segment per parameter tensor and the reference
+    has no limit on their number.  One norm launch reduces up to XDE_MAX_SEG = 16 segments; beyond that (7 Linear layers =
+    14 tensors + adj_t, y, adj_y = 17 segments; 20 layers = 43) the reduction runs in chunks and the chunk results are
+    max-combined on the device.  Against the oracle's adjoint with the same default norm: solution, dL/dy0 and EVERY parameter
+    gradient, fp64."""
+    dtype = torch.float64
+    m_cpu = DeepFunc(n_layers, 8, dtype)
+    params_cpu = list(m_cpu.parameters())
+    assert len(params_cpu) == 2 * n_layers
+
+    def fn(t_, y):  # the oracle's func / vjp callables, evaluated with torch on the host (test infrastructure)
+        with torch.no_grad():
+            return m_cpu(None, torch.from_numpy(np.ascontiguousarray(y))).numpy()
+
+    def vjp(t_, y, cot):
+        yt = torch.from_numpy(np.ascontiguousarray(y)).requires_grad_(True)
+        out = m_cpu(None, yt)
+        gs = torch.autograd.grad(out, [yt] + params_cpu, torch.from_numpy(np.ascontiguousarray(cot)))
+        return gs[0].numpy(), [g.numpy() for g in gs[1:]]
+
+    y0 = torch.rand(64, 2, generator=torch.Generator().manual_seed(0), dtype=dtype) * 2 - 1
+    t = torch.linspace(0.0, 1.5, 4, dtype=dtype)
+    tol = dict(rtol=1e-7, atol=1e-9)
+    ans, bw = O.odeint_adjoint(fn, vjp, [p_.detach().numpy() for p_ in params_cpu], y0.numpy(), t.numpy(), "dopri5",
+                               options={"norm": O._rms_norm, "dtype": np.float64}, **tol)
+    gy0, gps = bw(np.sign(ans) / ans.size)
+
+    import copy
+
+    m = copy.deepcopy(m_cpu).to(dev)
+    y0g = y0.clone().to(dev).requires_grad_(True)
+    sol = odeint_adjoint(m, y0g, t.to(dev), solver=Dopri5, options={"norm": _rms_norm, "dtype": dtype, "pipeline": pipeline}, **tol)
+    sol.abs().mean().backward()
+    assert P.rel_err(sol.detach().cpu().numpy(), ans) <= 1e-9
+    assert P.rel_err(y0g.grad.cpu().numpy(), gy0) <= 1e-7, P.rel_err(y0g.grad.cpu().numpy(), gy0)
+    for p_, g_ in zip(m.parameters(), gps):
+        assert P.rel_err(p_.grad.cpu().numpy(), g_) <= 1e-7, P.rel_err(p_.grad.cpu().numpy(), g_)

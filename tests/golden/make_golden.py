@@ -66,6 +66,34 @@ def tableaus_f64():
     return out
 
 
+def _linear_full(B, D, n_rows):
+    """BASELINE.json configs 2 / 4 at FULL size on the numpy oracle: dy/dt = A y, A = U - U^T (U = 0.1 randn, seed 1), y0 =
+    randn(B, D) seed 0 (both from torch's CPU generator: reproducible on the GPU box), Dopri5 rtol 1e-5 / atol 1e-7, fp32.
+    Stored: every attempt's (t0, dt, ratio, accept), the counts, and `n_rows` sampled rows of the solution at t = 0.5, 1."""
+    import torch
+
+    A = P.skew_matrix(D).float().numpy()
+    y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(0)).numpy()
+    t = np.array([0.0, 0.5, 1.0], dtype=np.float32)
+    sol, s = O.odeint(lambda t_, y: y @ A.T, y0, t, "dopri5", rtol=1e-5, atol=1e-7, return_solver=True)
+    rows = np.sort(np.random.RandomState(11).choice(B, size=n_rows, replace=False))
+    return {"B": np.asarray(B), "D": np.asarray(D), "t": t, "rows": rows, "y0_rows": y0[rows], "sol_rows": sol[:, rows, :],
+            "trace": _trace(s), "counts": np.asarray([s.n_accept, s.n_reject, s.nfe]),
+            "sol_abs_max": np.asarray(float(np.abs(sol).max()))}
+
+
+def config2_full():
+    return _linear_full(65536, 128, 48)
+
+
+def config4_full():
+    """Config 4's GLOBAL problem (524288 x 64; rank r of 8 owns rows [r*65536, (r+1)*65536)): the step sequence every rank
+    must follow, and sampled rows from every shard."""
+    return _linear_full(524288, 64, 64)
+
+
+FULL_CASES = {"config2_full": config2_full, "config4_full": config4_full}  # minutes of CPU time: `--full`
+
 CASES = {
     "spiral_rk4": spiral_rk4,
     "spiral_fixed_small": spiral_fixed_small,
@@ -76,6 +104,8 @@ CASES = {
 
 
 if __name__ == "__main__":
-    for name, fn in CASES.items():
+    import sys
+
+    for name, fn in (FULL_CASES if "--full" in sys.argv else CASES).items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **fn())
         print("wrote", name)

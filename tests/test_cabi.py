@@ -32,6 +32,7 @@ def test_library_loads_and_exports_every_symbol():
 def test_struct_layouts_match():
     lib = _hip.load_library()
     assert lib.xde_sizeof_ctrl() == C.sizeof(_hip.XdeCtrl) == 288
+    assert lib.xde_sizeof_ctrl_params() == C.sizeof(_hip.XdeCtrlParams)
     assert _hip.XdeCtrl.seq.offset % 8 == 0
     assert lib.xde_workspace_bytes() > 0
     # constants mirrored from the header
@@ -121,6 +122,6 @@ def test_every_entry_point_rejects_null_arguments():
         msg = lib.xde_last_error().decode()
         assert rc == _hip.XDE_EBADARG, (name, rc, msg)
         assert msg and (name in msg or "segments" in msg), (name, msg)
-    covered = set(calls) | {"xde_last_error", "xde_abi_version", "xde_sizeof_ctrl", "xde_workspace_bytes", "xde_host_free", "xde_prof_enable"}
+    covered = set(calls) | {"xde_last_error", "xde_abi_version", "xde_sizeof_ctrl", "xde_sizeof_ctrl_params", "xde_workspace_bytes", "xde_host_free", "xde_prof_enable"}
     assert covered == set(_hip.SYMBOLS), set(_hip.SYMBOLS) ^ covered
     assert lib.xde_host_free(None) == _hip.XDE_OK  # freeing nothing is fine

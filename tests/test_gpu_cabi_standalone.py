@@ -27,7 +27,8 @@ class Params(C.Structure):  # xde_ctrl_params_t
     _fields_ = [(n, C.c_double) for n in ("rtol", "atol", "min_step", "max_step", "safety", "ifactor", "dfactor", "order")] + [
         ("max_num_steps", C.c_int64)] + [(n, C.c_int32) for n in ("time_dtype", "state_dtype", "direction", "norm_kind", "n_stage",
                                                                  "n_seg", "n_step_t", "pi_controller")] + [
-        ("pi_beta", C.c_double), ("alpha", C.c_double * MAX_STAGE), ("seg_count", C.c_double * MAX_SEG)]
+        ("pi_beta", C.c_double), ("alpha", C.c_double * MAX_STAGE), ("seg_count", C.c_double * MAX_SEG),
+        ("replay", C.c_void_p), ("n_replay", C.c_int64)]
 
 
 class Segs(C.Structure):  # xde_segments_t
@@ -47,7 +48,10 @@ def test_dopri5_through_raw_c_abi():
     lib.xde_ctrl_init.argtypes = [vp, C.POINTER(Params), dbl, dbl, C.c_int32, vp, vp, vp, i64, vp, vp]
     lib.xde_ctrl_read.argtypes = [vp, C.POINTER(Ctrl), vp]
     lib.xde_dense_eval.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i64, vp]
+    lib.xde_sizeof_ctrl_params.restype = i64
+    assert lib.xde_abi_version() == 2
     assert lib.xde_sizeof_ctrl() == C.sizeof(Ctrl)
+    assert lib.xde_sizeof_ctrl_params() == C.sizeof(Params)  # a hand-written mirror must be checked before it is passed
 
     def ok(rc):
         assert rc == 0, lib.xde_last_error().decode()

@@ -1,0 +1,130 @@
+"""BASELINE.json configs 2 and 4 at FULL size against committed oracle fixtures (tests/golden/config{2,4}_full.npz, made by
+`python -m tests.golden.make_golden --full` from oracle/xde_oracle.py at 65536 x 128 and 524288 x 64): every attempt's
+(t0, dt, ratio, accept), the counts, and sampled rows of the solution.
+
+Free-running: identical decisions, dt to 1e-6, rows at max|d| <= 1e-5 max|ref| (fp32).  Replayed (the controller takes the
+fixture's (dt, accept) sequence): the sampled rows element-wise at north_star's `1e-7 + 1e-5 |ref|`.
+Config 4 additionally as a SHARDED run of the real kernels: two processes on cuda:0, each with half of the 524288 rows, the
+global error norm all-reduced per attempt — both ranks must follow the fixture's (global) step sequence."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from . import problems as P
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden(name):
+    return np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+def _problem(z):
+    B, D = int(z["B"]), int(z["D"])
+    A = P.skew_matrix(D).float()
+    y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(0))
+    assert np.array_equal(y0[torch.from_numpy(z["rows"])].numpy(), z["y0_rows"])  # same seeded inputs as the fixture's
+    return A, y0
+
+
+def _solve(A, y0, t, pipeline, **kw):
+    from paddlexde_amd import Dopri5
+    from paddlexde_amd.utils import _rms_norm
+    from paddlexde_amd.xde import BaseODE
+
+    s = Dopri5(xde=BaseODE(lambda t_, y: y @ A.T, y0=y0, t_span=t), y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=pipeline,
+               record_trace=True, **kw)
+    return s.integrate(t), s
+
+
+def _trace(s):
+    return np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
+
+
+def _check_free_running(z, sol_rows, s):
+    tr, ref = _trace(s), z["trace"]
+    assert tr.shape == ref.shape, (tr.shape, ref.shape)
+    assert np.array_equal(tr[:, 3], ref[:, 3])  # identical accept/reject decisions
+    assert np.allclose(tr[:, 1], ref[:, 1], rtol=1e-6, atol=0), np.abs(tr[:, 1] / ref[:, 1] - 1).max()  # dt
+    assert np.allclose(tr[:, 0], ref[:, 0], rtol=1e-6, atol=0)  # t0
+    # the ratio is a cancellation of GEMM results (func = y @ A.T, hipBLASLt vs numpy): 1e-2 relative + the first steps' noise floor
+    assert np.allclose(tr[:, 2], ref[:, 2], rtol=2e-2, atol=1e-4), np.abs(tr[:, 2] - ref[:, 2]).max()
+    assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == tuple(int(x) for x in z["counts"])
+    assert np.abs(sol_rows - z["sol_rows"]).max() <= 1e-5 * float(z["sol_abs_max"]), np.abs(sol_rows - z["sol_rows"]).max()
+
+
+@pytest.mark.parametrize("pipeline", ["sync", "lag", "graph"])
+@pytest.mark.parametrize("name", ["config2_full", "config4_full"])
+def test_full_size_free_running_vs_golden(name, pipeline):
+    z = _golden(name)
+    A, y0 = _problem(z)
+    dev = "cuda:0"
+    sol, s = _solve(A.to(dev), y0.to(dev), torch.from_numpy(z["t"]), pipeline)
+    rows = torch.from_numpy(z["rows"]).to(dev)
+    _check_free_running(z, sol[:, rows].cpu().numpy(), s)
+
+
+@pytest.mark.parametrize("name", ["config2_full", "config4_full"])
+def test_full_size_replayed_vs_golden(name):
+    z = _golden(name)
+    A, y0 = _problem(z)
+    dev = "cuda:0"
+    replay = [(float(r[1]), bool(r[3])) for r in z["trace"]]
+    sol, s = _solve(A.to(dev), y0.to(dev), torch.from_numpy(z["t"]), "lag", _replay=replay)
+    tr = _trace(s)
+    assert np.array_equal(tr[:, 1], z["trace"][:, 1]) and np.array_equal(tr[:, 3], z["trace"][:, 3])
+    got = sol[:, torch.from_numpy(z["rows"]).to(dev)].cpu().numpy()
+    assert P.parity_ok(got, z["sol_rows"], rtol=1e-5, atol=1e-7), P.worst(got, z["sol_rows"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _shard_worker(rank, world, port, out_dir, pipeline):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # RCCL refuses two ranks on one device; gloo carries 32 doubles
+    try:
+        z = _golden("config4_full")
+        A, y0 = _problem(z)
+        B = y0.shape[0]
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        dev = "cuda:0"
+        sol, s = _solve(A.to(dev), y0[lo:hi].contiguous().to(dev), torch.from_numpy(z["t"]), pipeline, process_group=True)
+        mine = [(i, int(r) - lo) for i, r in enumerate(z["rows"]) if lo <= r < hi]
+        idx = torch.tensor([r for _, r in mine], device=dev)
+        np.savez(os.path.join(out_dir, "shard{}.npz".format(rank)), trace=_trace(s), which=np.asarray([i for i, _ in mine]),
+                 sol_rows=sol[:, idx].cpu().numpy(), counts=np.asarray([s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+def test_config4_sharded_two_ranks_on_one_gpu_vs_golden(tmp_path, pipeline):
+    world = 2
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path), pipeline), nprocs=world, join=True)
+    z = _golden("config4_full")
+    rs = [np.load(tmp_path / "shard{}.npz".format(r)) for r in range(world)]
+    assert np.array_equal(rs[0]["trace"], rs[1]["trace"])  # lock-step, bit for bit
+    ref = z["trace"]
+    for r in rs:
+        tr = r["trace"]
+        assert tr.shape == ref.shape and np.array_equal(tr[:, 3], ref[:, 3])
+        assert np.allclose(tr[:, 1], ref[:, 1], rtol=1e-6, atol=0)
+        assert tuple(r["counts"]) == tuple(int(x) for x in z["counts"])
+    got = np.empty_like(z["sol_rows"])
+    for r in rs:
+        got[:, r["which"]] = r["sol_rows"]
+    assert np.abs(got - z["sol_rows"]).max() <= 1e-5 * float(z["sol_abs_max"])

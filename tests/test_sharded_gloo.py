@@ -124,25 +124,37 @@ class _Net(torch.nn.Module):
         return torch.tanh(y @ self.W1) @ self.W2 - 0.1 * y
 
 
-def _adjoint_run(y0, pg):
+def _adjoint_run(y0, pg, norm="seminorm", t_grad=False, trace=None):
     from paddlexde_amd import Dopri5, odeint_adjoint
     from paddlexde_amd.utils import _rms_norm
 
     m = _Net()
     y0 = y0.clone().requires_grad_(True)
-    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64)
+    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64).requires_grad_(t_grad)
     opts = {"norm": _rms_norm, "dtype": torch.float64}
     if pg:
         opts["process_group"] = True
-    # "seminorm": the adjoint's step control looks at (y, adj_y) only — quantities every rank holds a shard of, so the
-    # all-reduced norm is exactly the unsharded one (parameter adjoints are per-rank partial sums)
-    sol = odeint_adjoint(m, y0, t, solver=Dopri5, rtol=1e-7, atol=1e-9, options=opts,
-                         adjoint_options={"norm": "seminorm", "dtype": torch.float64, **({"process_group": True} if pg else {})})
+    # "seminorm": the adjoint's step control looks at (adj_t, y, adj_y) only; the parameter adjoints stay per-rank partial sums
+    # until ONE all-reduce at the end.  default: the step control also looks at every parameter adjoint, so those are summed
+    # over the group at every evaluation of the augmented dynamics.  Either way the all-reduced norm is the unsharded one.
+    adj = {"dtype": torch.float64, **({"process_group": True} if pg else {})}
+    if norm == "seminorm":
+        adj["norm"] = "seminorm"
+    if trace is not None:
+        adj["_step_hook"] = lambda i, y0_, y1_, ks, c: trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
+    sol = odeint_adjoint(m, y0, t, solver=Dopri5, rtol=1e-7, atol=1e-9, options=opts, adjoint_options=adj)
     w = torch.linspace(-1.0, 1.0, sol.numel(), dtype=torch.float64).reshape(sol.shape)
-    return m, y0, sol, w
+    return m, y0, sol, w, t
 
 
-def _adjoint_worker(rank, world, port, out_dir):
+def _adjoint_problem():
+    B = 12
+    y_all = torch.randn(B, 4, generator=torch.Generator().manual_seed(11), dtype=torch.float64)
+    y_all[B // 2 :] *= 4.0
+    return B, y_all
+
+
+def _adjoint_worker(rank, world, port, out_dir, norm, t_grad):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -153,32 +165,54 @@ def _adjoint_worker(rank, world, port, out_dir):
 
         _hip._set_backend_for_testing(NumpyDoubleBackend())
         torch.set_num_threads(1)
-        B = 12
-        y_all = torch.randn(B, 4, generator=torch.Generator().manual_seed(11), dtype=torch.float64)
-        y_all[B // 2 :] *= 4.0
+        B, y_all = _adjoint_problem()
         rows = slice(rank * B // world, (rank + 1) * B // world)
-        m, y0, sol, _ = _adjoint_run(y_all[rows].contiguous(), True)
+        trace = []
+        m, y0, sol, _, t = _adjoint_run(y_all[rows].contiguous(), True, norm, t_grad, trace)
         w_all = torch.linspace(-1.0, 1.0, 4 * B * 4, dtype=torch.float64).reshape(4, B, 4)
         (sol * w_all[:, rows]).sum().backward()
         np.savez(os.path.join(out_dir, "adj{}.npz".format(rank)), sol=sol.detach().numpy(), gy=y0.grad.numpy(),
-                 gW1=m.W1.grad.numpy(), gW2=m.W2.grad.numpy())
+                 gW1=m.W1.grad.numpy(), gW2=m.W2.grad.numpy(), gt=t.grad.numpy() if t_grad else np.zeros(0),
+                 trace=np.asarray([[a, b, c, float(d)] for a, b, c, d in trace]))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_adjoint(tmp_path, cpu_double):
-    """Forward AND adjoint backward batch-sharded over two ranks: solution rows and d/dy0 rows equal the unsharded run's,
-    the per-rank parameter gradients SUM to the unsharded ones (what DDP's gradient all-reduce does)."""
-    world = 2
+@pytest.mark.parametrize("norm,t_grad,world", [("seminorm", False, 2), ("default", False, 2), ("default", True, 2), ("seminorm", True, 2),
+                                              ("default", False, 3)])
+def test_sharded_adjoint_equals_unsharded(tmp_path, cpu_double, norm, t_grad, world):
+    """Forward AND adjoint backward batch-sharded over the ranks, under the default adjoint norm (odeint_adjoint.py:284-287: it
+    looks at every parameter adjoint, which is a sum over ALL rows) and under "seminorm": every rank takes the unsharded run's
+    backward step sequence, solution rows and d/dy0 rows equal the unsharded run's, and EVERY rank ends with the parameter (and
+    time) gradients of the global loss."""
     port = _free_port()
-    mp.spawn(_adjoint_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_adjoint_worker, args=(world, port, str(tmp_path), norm, t_grad), nprocs=world, join=True)
     rs = [np.load(tmp_path / "adj{}.npz".format(r)) for r in range(world)]
-    B = 12
-    y_all = torch.randn(B, 4, generator=torch.Generator().manual_seed(11), dtype=torch.float64)
-    y_all[B // 2 :] *= 4.0
-    m, y0, sol, w = _adjoint_run(y_all, False)
+    B, y_all = _adjoint_problem()
+    trace = []
+    m, y0, sol, w, t = _adjoint_run(y_all, False, norm, t_grad, trace)
     (sol * w).sum().backward()
+    tr = np.asarray([[a, b, c, float(d)] for a, b, c, d in trace])
+    for r in rs:
+        # lock-step with each other (bit for bit) and with the unsharded run (same decisions, same steps to rounding)
+        assert np.array_equal(r["trace"], rs[0]["trace"])
+        assert r["trace"].shape == tr.shape and np.array_equal(r["trace"][:, 3], tr[:, 3])
+        assert np.allclose(r["trace"][:, :2], tr[:, :2], rtol=1e-6, atol=1e-12)  # t0, dt (row sums are ordered differently)
+        # (the first attempts' error estimates are rounding noise, ratio ~1e-7: absolute floor there)
+        assert np.allclose(r["trace"][:, 2], tr[:, 2], rtol=1e-6, atol=1e-9)
+        assert P.rel_err(r["gW1"], m.W1.grad.numpy()) <= 1e-8
+        assert P.rel_err(r["gW2"], m.W2.grad.numpy()) <= 1e-8
+        if t_grad:
+            assert P.rel_err(r["gt"], t.grad.numpy()) <= 1e-8
     assert P.rel_err(np.concatenate([r["sol"] for r in rs], axis=1), sol.detach().numpy()) <= 1e-9
     assert P.rel_err(np.concatenate([r["gy"] for r in rs], axis=0), y0.grad.numpy()) <= 1e-8
-    assert P.rel_err(sum(r["gW1"] for r in rs), m.W1.grad.numpy()) <= 1e-8
-    assert P.rel_err(sum(r["gW2"] for r in rs), m.W2.grad.numpy()) <= 1e-8
+
+
+def test_sharded_solver_refuses_a_user_norm(cpu_double):
+    from paddlexde_amd import Dopri5
+    from paddlexde_amd.xde import BaseODE
+
+    y0 = torch.ones(4, 2)
+    with pytest.raises(NotImplementedError, match="cannot be all-reduced"):
+        Dopri5(xde=BaseODE(lambda t_, y: -y, y0=y0, t_span=torch.tensor([0.0, 1.0])), y0=y0, rtol=1e-5, atol=1e-7,
+               norm=lambda x: x.abs().max(), process_group=True)
