@@ -216,3 +216,36 @@ def test_sharded_solver_refuses_a_user_norm(cpu_double):
     with pytest.raises(NotImplementedError, match="cannot be all-reduced"):
         Dopri5(xde=BaseODE(lambda t_, y: -y, y0=y0, t_span=torch.tensor([0.0, 1.0])), y0=y0, rtol=1e-5, atol=1e-7,
                norm=lambda x: x.abs().max(), process_group=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# the production transport: torch.distributed "nccl" (= RCCL) carrying the norm all-reduce
+# ----------------------------------------------------------------------------------------------
+def _nccl_worker(rank, world, port, out_dir, pipeline):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        B, D = 4096, 64
+        A, y0 = _problem(B, D)
+        sol, s = _solve(y0.to("cuda:0"), A.to("cuda:0"), True, "rms", pipeline)
+        np.savez(os.path.join(out_dir, "nccl.npz"), sol=sol.cpu().numpy(), trace=np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+def test_rccl_backend_world_size_one(tmp_path, pipeline):
+    """`process_group=True` over the nccl backend (RCCL) with one rank: xde_error_norm_partial -> xde_norm_finalize ->
+    all_reduce on the device (no host staging) -> xde_rk_control(sums) — the exact per-attempt sequence of the 8-GPU run.  The
+    result equals the unsharded run bit for bit (same fixed-order reduction, the all-reduce of one rank is the identity)."""
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path), pipeline), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl.npz")
+    B, D = 4096, 64
+    A, y0 = _problem(B, D)
+    full, s = _solve(y0.to("cuda:0"), A.to("cuda:0"), None, "rms", pipeline)
+    tr = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
+    assert np.array_equal(tr, r["trace"])
+    assert np.array_equal(full.cpu().numpy(), r["sol"])
