@@ -360,14 +360,16 @@ int xde_graph_replace_memsets(void* hip_graph, int* n_replaced);
  * measured time is the kernel's own duration.  xde_prof_collect() synchronises and returns, per kernel
  * id, the number of SAMPLED launches, their summed milliseconds and their summed algorithmic bytes.
  */
-#define XDE_KID_COMBINE 0
+#define XDE_KID_COMBINE 0 /* xde_stage_combine, mode RK (adaptive stages); xde_scale_fanout */
 #define XDE_KID_ERRNORM 1
 #define XDE_KID_CONTROL 2
 #define XDE_KID_DENSE 3
 #define XDE_KID_SCALEDNORM 4
 #define XDE_KID_FINALIZE 5
 #define XDE_KID_COMMIT 6
-#define XDE_KID_COUNT 7
+#define XDE_KID_COMBINE_FUSE 7  /* xde_stage_combine, mode FUSE (fixed-step stage inputs) */
+#define XDE_KID_COMBINE_WFUSE 8 /* xde_stage_combine, mode WFUSE (fixed-step final combine) */
+#define XDE_KID_COUNT 9
 int xde_prof_enable(int on);
 int xde_prof_collect(int64_t* counts_out, double* ms_out, double* bytes_out);
 

@@ -20,7 +20,7 @@ XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
 COMBINE_RK, COMBINE_FUSE, COMBINE_WFUSE = 0, 1, 2
 NORM_RMS, NORM_LINF = 0, 1
 STATUS_OK, STATUS_DT_UNDERFLOW, STATUS_NONFINITE, STATUS_MAX_STEPS = 0, 1, 2, 3
-KID_NAMES = ("combine", "errnorm", "control", "dense", "scalednorm", "finalize", "commit")
+KID_NAMES = ("combine", "errnorm", "control", "dense", "scalednorm", "finalize", "commit", "combine_fuse", "combine_wfuse")
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libxde_hip.so")
 

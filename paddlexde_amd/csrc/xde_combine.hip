@@ -316,7 +316,8 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   if (blocks < 1) blocks = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double elt = dtype == XDE_F32 ? 4.0 : 8.0;
-  ProfScope prof(XDE_KID_COMBINE, double(nk + 2 + (out2 ? 1 : 0)) * double(n) * elt);
+  const int kid = mode == XDE_COMBINE_RK ? XDE_KID_COMBINE : (mode == XDE_COMBINE_FUSE ? XDE_KID_COMBINE_FUSE : XDE_KID_COMBINE_WFUSE);
+  ProfScope prof(kid, double(nk + 2 + (out2 ? 1 : 0)) * double(n) * elt);
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
 #define LAUNCH_COMBINE(T, MODE)                                                     \
   do {                                                                              \

@@ -19,6 +19,12 @@ Pipelines (``options["pipeline"]``):
   "lag"   speculative: attempt n+1 is enqueued before the host knows whether attempt n was accepted; its
           kernels pick (y0, f0) between the two candidates from ctrl->accept on the device.  The GPU never
           waits for the host.  One extra (discarded) attempt runs after the last output.
+  "graph" one whole attempted step captured into a hipGraph and replayed (launch-bound small states).
+  "auto"  (default) picks among them per solve: "sync" for a user norm callable; "lag" when an operand is larger than
+          AUTO_GRAPH_MAX_BYTES (the step is bandwidth-bound; also with a process_group); otherwise it starts in "sync" and,
+          if the solve is still running after AUTO_GRAPH_AFTER attempts, captures the step and continues as "graph" —
+          provided the capture is safe (main thread, no capture in progress, func does not differentiate with respect to
+          parameter leaves) and succeeds; else it stays in "sync".  Results are bit-identical whatever is picked.
 """
 import bisect
 import collections
@@ -112,7 +118,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         dfactor=0.2,
         max_num_steps=2**31 - 1,
         dtype=torch.float32,
-        pipeline="sync",
+        pipeline="auto",
         controller="I",
         pi_beta=0.04,
         process_group=None,
@@ -126,8 +132,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         super().__init__(xde=xde, dtype=dtype, y0=y0, **kwargs)
         if jump_t is not None:
             raise NotImplementedError("jump_t calls a non-existent self.func in the reference (SURVEY D7)")
-        if pipeline not in ("sync", "lag", "graph"):
-            raise ValueError("pipeline must be 'sync', 'lag' or 'graph'")
+        if pipeline not in ("auto", "sync", "lag", "graph"):
+            raise ValueError("pipeline must be 'auto', 'sync', 'lag' or 'graph'")
         if controller not in ("I", "PI"):
             raise ValueError("controller must be 'I' (reference) or 'PI' (opt-in)")
         if dtype not in (torch.float32, torch.float64):
@@ -160,8 +166,10 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._step_hook = _step_hook
         if self._replay is not None and step_t is not None:
             raise NotImplementedError("a prescribed step sequence and step_t clipping do not combine")
-        if _step_hook is not None and pipeline != "sync":
-            raise NotImplementedError("_step_hook observes attempts of pipeline='sync'")
+        if _step_hook is not None:
+            if pipeline not in ("auto", "sync"):
+                raise NotImplementedError("_step_hook observes attempts of pipeline='sync'")
+            pipeline = "sync"
         # XDE_FUSE_CONTROL=1: error norm + controller as ONE launch (xde_error_norm_control, last-workgroup-done).
         # Bit-identical, but measured no faster than two launches (the controller's latency chain just moves into
         # the tail of the norm kernel: 36.4 us vs 23.1 + 12 us on config 2), so it is off by default.
@@ -193,8 +201,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
             # as framework ops on it and its scalar feeds the device controller (as a 1-segment "linf" value)
             if not callable(self.norm):
                 raise TypeError("options['norm'] must be callable")
-            if pipeline != "sync":
+            if pipeline not in ("auto", "sync"):
                 raise NotImplementedError("custom norm callables run with pipeline='sync' only")
+            pipeline = "sync"
             if process_group is not None:
                 raise NotImplementedError("a user norm callable cannot be all-reduced over a process_group; use _rms_norm / "
                                           "_linf_norm (or, for odeint_adjoint, the default adjoint norm or \"seminorm\")")
@@ -345,6 +354,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         dev = y0.device
         self._base = None
         self._kept = None  # step() API: operands of the last accepted step
+        self._auto_state = None  # what pipeline='auto' resolved to
+        self._graph_warmup = None
         self._direction = -1 if t_span[1] < t_span[0] else 1
         self._t_host = t_span
         self._t_span_dev = upload(t_span.astype(np.float64), dev)
@@ -413,7 +424,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
 
     def _after_integrate(self):
         w, self._work = getattr(self, "_work", None), None
-        if w is not None and self.pipeline != "graph":  # a captured graph keeps addressing its buffers
+        if w is not None and self.pipeline != "graph" and self._auto_state != "graph":  # a captured graph keeps addressing its buffers
             self.backend.release_work(w)
 
     def _select_initial_step_device(self, t0, y0):
@@ -557,6 +568,68 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._solution = None
         self._graph = None  # releases the captured graph and its private memory pool
 
+    AUTO_GRAPH_MAX_BYTES = 8 << 20  # per state operand; above it the step is bandwidth-bound and "lag" wins
+    AUTO_GRAPH_AFTER = 16  # attempts made eagerly before a capture is worth its ~2 ms
+
+    def _auto_pick(self):
+        """The pipeline `auto` resolves to for this solve (see the module docstring)."""
+        y0 = self.y0
+        if self.process_group is not None or y0.numel() * y0.element_size() > self.AUTO_GRAPH_MAX_BYTES:
+            return "lag"
+        return "sync-then-graph" if y0.is_cuda else "sync"
+
+    def _auto_may_capture(self):
+        import threading
+
+        return (threading.current_thread() is threading.main_thread() and self.y0.is_cuda
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _advance_auto(self, max_attempts):
+        to_end = max_attempts is None
+        if self._auto_state is None:
+            self._auto_state = self._auto_pick()
+        if self._auto_state == "lag":
+            return self._advance_lag(max_attempts)
+        if self._auto_state == "graph":
+            return self._advance_graph(max_attempts)
+        if self._auto_state == "sync":
+            return self._advance_sync(max_attempts)
+        # "sync-then-graph": eager attempts first; short solves (the adjoint's 1-3 step intervals) end here
+        done = 0
+        left = self.AUTO_GRAPH_AFTER - self._n_attempts
+        if left > 1:
+            n = left - 1 if to_end else min(left - 1, max_attempts)
+            c = self._advance_sync(n, stop_on_done=to_end)
+            done += n
+            if (to_end and c.done) or (not to_end and done >= max_attempts):
+                return c
+        # one more eager attempt under the capture guard: does func differentiate w.r.t. parameter leaves?
+        from ..utils.graphed import _AutogradTargetProbe
+
+        with _AutogradTargetProbe() as probe:
+            c = self._advance_sync(1, stop_on_done=to_end)
+        done += 1
+        if probe.hit is not None or not self._auto_may_capture():
+            self._auto_state = "sync"
+        else:
+            self._auto_state = "graph"
+            self._graph_warmup = 0
+        if (to_end and c.done) or (not to_end and done >= max_attempts):
+            return c
+        rest = None if to_end else max_attempts - done
+        if self._auto_state == "graph":
+            nfe0 = self.nfe
+            try:
+                return self._advance_graph(rest)
+            except AssertionError:
+                raise  # the solver's own status errors
+            except Exception:  # the capture failed (func syncs with the host, allocates pinned memory, ...): stay eager
+                if getattr(self, "_graph", None) is not None:
+                    raise  # the failure came after a successful capture: not ours to hide
+                self.nfe = nfe0
+                self._auto_state = "sync"
+        return self._advance_sync(rest)
+
     def advance(self, max_attempts=None):
         """Run attempted steps until every output is produced (``max_attempts=None``) or exactly
         ``max_attempts`` attempts were made.  Returns the last control block read from the device.
@@ -569,7 +642,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._n_attempts = 0
             self._last = None
             self._graph = None
-        if self.pipeline == "lag":
+        if self.pipeline == "auto":
+            c = self._advance_auto(max_attempts)
+        elif self.pipeline == "lag":
             c = self._advance_lag(max_attempts)
         elif self.pipeline == "graph":
             c = self._advance_graph(max_attempts)
@@ -614,11 +689,13 @@ class AdaptiveRKSolver(AdaptiveSolver):
         done = 0
         if getattr(self, "_graph", None) is None:
             # eager warm-up (also lets short integrations finish without paying for a capture)
-            n_warm = self.GRAPH_WARMUP_ATTEMPTS if to_end else min(self.GRAPH_WARMUP_ATTEMPTS, max_attempts)
-            c = self._advance_sync(n_warm, stop_on_done=to_end)
-            done += n_warm
-            if (to_end and c.done) or (not to_end and done >= max_attempts):
-                return c
+            warm = self.GRAPH_WARMUP_ATTEMPTS if self._graph_warmup is None else self._graph_warmup
+            n_warm = warm if to_end else min(warm, max_attempts)
+            if n_warm > 0:
+                c = self._advance_sync(n_warm, stop_on_done=to_end)
+                done += n_warm
+                if (to_end and c.done) or (not to_end and done >= max_attempts):
+                    return c
             y0, f0 = self._base
             self._gbase = (y0.clone(), f0.clone())  # static operands of the captured step
 

@@ -710,6 +710,8 @@ def test_randomised_adaptive_sweep_vs_oracle(dev, block):
     for case in range(8):
         name = list(ADAPTIVE)[rng.randint(len(ADAPTIVE))]
         pipeline = ("sync", "lag", "graph")[rng.randint(3)]
+        if case % 4 == 3:
+            pipeline = "auto"  # the default: resolves per solve (no extra random draw: the other cases stay what they were)
         B, D = int(rng.randint(1, 9)), int(rng.randint(2, 17))
         A = P.skew_matrix(D, seed=int(rng.randint(1, 100))).to(torch.float64)
         y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(int(rng.randint(1 << 30))), dtype=torch.float64)
@@ -931,6 +933,8 @@ def test_randomised_tuple_state_sweep_vs_oracle(dev, block):
         if name == "dopri8":
             name = "dopri5"  # its noise regime is the subject of test_randomised_adaptive_sweep_vs_oracle
         pipeline = ("sync", "lag", "graph")[rng.randint(3)]
+        if case % 4 == 3:
+            pipeline = "auto"  # the default: resolves per solve (no extra random draw: the other cases stay what they were)
         ncomp = int(rng.randint(1, 6))
         shapes = [shapes_pool[rng.randint(len(shapes_pool))] for _ in range(ncomp)]
         y0 = [rng.uniform(-1.0, 1.0, size=sh) for sh in shapes]
@@ -1172,6 +1176,8 @@ def test_randomised_adaptive_sweep_fp32(dev, block):
     for case in range(8):
         name = ("dopri5", "bosh3", "fehlberg2", "adaptive_heun")[rng.randint(4)]
         pipeline = ("sync", "lag", "graph")[rng.randint(3)]
+        if case % 4 == 3:
+            pipeline = "auto"  # the default: resolves per solve (no extra random draw: the other cases stay what they were)
         B, D = int(rng.randint(1, 33)), int(rng.randint(2, 33))
         A = P.skew_matrix(D, seed=int(rng.randint(1, 100))).float()
         y0 = torch.randn(B, D, generator=torch.Generator().manual_seed(int(rng.randint(1 << 30))))

