@@ -9,8 +9,11 @@ controller — exactly what ``paddlexde_amd.odeint(..., solver=Dopri5)`` runs pe
 
 Workload (N=1): BASELINE.json configs[1] — linear ODE dy/dt = A y, A = U - U^T (seed 1), batch 65536 x dim
 128 fp32, y0 = randn (seed 0), rtol 1e-5 / atol 1e-7, inputs resident in HBM before the timed region.
-N>1 (weak scaling): every rank owns 65536 rows; the only collective is the all-reduce of the error norm's
-partial sums (32 doubles) per attempted step over RCCL.
+N>1: BASELINE.json configs[3] — the same ODE at GLOBAL batch 524288 x dim 64, rows split evenly over the N ranks
+(rank r owns rows [r*B/N, (r+1)*B/N): 65536 x 64 per GPU at N=8); the total work is the same for every N > 1
+("scaling": "strong"); the only collective is the all-reduce of the error norm's partial sums (32 doubles) per
+attempted step over RCCL.  `--batch` (rows PER GPU) / `--dim` override either default (then "weak").
+`--workload rk4`: the bandwidth-bound fixed-step line (reference RK4 variant, 65536 x 128, 18 N 4 B per step).
 
 value = states/sec = (global batch * dim) / (wall time per attempted step), whole job.
 roofline: algorithmic bytes of the stage-combine kernel (sum over the 6 stages of (operands + 2) *
@@ -66,14 +69,14 @@ def _cpu_share():
     return max(1, min(n, int(os.environ.get("XDE_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(D, budget_s=12.0):
-    """The oracle ("port") on a bounded sample: batch 8192 x dim D, attempted Dopri5 steps for ~budget_s, on every
-    host core (oracle/xde_oracle_torch.py: the reference's eager op sequence on torch-CPU tensors, checked against the
-    numpy oracle by tests/test_oracle_pinning.py).  The first step size comes from the numpy oracle's heuristic."""
+def cpu_baseline(B, D, budget_s=15.0):
+    """The oracle ("port") on a bounded sample of the SAME workload: batch B x dim D (the GPU run's own size), attempted
+    Dopri5 steps for ~budget_s, on every granted host core (oracle/xde_oracle_torch.py: the reference's eager op sequence
+    on torch-CPU tensors, checked against the numpy oracle by tests/test_oracle_pinning.py).  The first step size is the
+    numpy oracle's (Hairer's heuristic on the same inputs)."""
     from oracle import xde_oracle as O
     from oracle import xde_oracle_torch as OT
 
-    B = 8192
     g = torch.Generator().manual_seed(1)
     U = 0.1 * torch.randn(D, D, generator=g)
     A = (U - U.T).contiguous()
@@ -93,7 +96,7 @@ def cpu_baseline(D, budget_s=12.0):
         tw.step()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 2000:
+        if (el > budget_s and n >= 8) or n >= 2000:
             break
     return {
         "value": B * D * n / el,
@@ -258,18 +261,80 @@ def side_workload(args):
                       "tunable_op": bool(args.tunable_op), "results": res}))
 
 
+def rk4_workload(args):
+    """The bandwidth-bound fixed-step line: the reference's RK4 (`rk4_alt_step_func`, solver/base_fixed_solver.py:166-197) on
+    config 2's state (65536 x 128 fp32, func = torch matmul).  One step = 4 func calls + 3 FUSE stage combines (3, 4, 5
+    arrays) + the WFUSE final combine (6 arrays, written straight into the output slice): 18 N 4 B = 604 MB algorithmic."""
+    from paddlexde_amd import RK4, _hip, odeint
+    from paddlexde_amd.utils import _rms_norm
+
+    dev = torch.device("cuda", 0)
+    B = 65536 if args.batch is None else args.batch
+    D = 128 if args.dim is None else args.dim
+    A, y0 = make_problem(B, D, 0, dev)
+    AT = A.T.contiguous()
+    func = lambda t, y: y @ AT  # noqa: E731
+    K, W = args.steps, args.warmup
+    t = torch.linspace(0.0, 0.05 * K, K + 1, device=dev)
+    be = _hip.get_backend()
+    with torch.no_grad():
+        for _ in range(max(1, -(-W // K))):  # >= W untimed steps, with the timed pass's own shapes (allocator warm)
+            odeint(func, y0, t, solver=RK4, options={"norm": _rms_norm})
+        torch.cuda.synchronize()
+        if not args.no_kernel_events:
+            be.prof_enable(args.event_period if args.event_period != 5 else 3)  # 3 FUSE launches per step: sample all stages
+        t0 = time.perf_counter()
+        sol = odeint(func, y0, t, solver=RK4, options={"norm": _rms_norm})
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_kernel_events:
+        prof = be.prof_collect()
+        be.prof_enable(False)
+    N = B * D
+    out = {
+        "metric": "integrated states/sec (batch*dim/step_time) rk4 (reference variant), fixed step",
+        "value": N * K / elapsed, "unit": "states/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "linear ODE dy/dt=Ay, RK4 reference variant (rk4_alt_step_func), batch={} x dim={}, {} fixed steps, "
+                               "func = torch matmul".format(B, D, K), "global_batch": B, "dim": D},
+        "finite": bool(torch.isfinite(sol[-B:]).all()),
+    }
+    if prof is not None:
+        kern = {}
+        for name in ("combine_fuse", "combine_wfuse"):
+            rec = prof[name]
+            if rec["launches"]:
+                us = 1e3 * rec["ms"] / rec["launches"]
+                gbs = rec["bytes"] / (rec["ms"] * 1e-3) / 1e9
+                kern[name] = {"launches": rec["launches"], "avg_us": us, "algorithmic_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+                              "bytes_per_launch": rec["bytes"] / rec["launches"]}
+        out["kernels"] = kern
+        ms = prof["combine_fuse"]["ms"] + prof["combine_wfuse"]["ms"]
+        by = prof["combine_fuse"]["bytes"] + prof["combine_wfuse"]["bytes"]
+        if ms > 0:
+            a = by / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "xde_combine_kernel<float, FUSE|WFUSE, vec> (3 + 1 launches per step)",
+                               "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None}
+            if kern:
+                per_step = 3 * kern.get("combine_fuse", {}).get("avg_us", 0.0) + kern.get("combine_wfuse", {}).get("avg_us", 0.0)
+                out["solver_kernel_ms_per_step"] = per_step * 1e-3
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=65536, help="rows per GPU")
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--pipeline", default="lag", choices=["sync", "lag", "graph"])
+    ap.add_argument("--batch", type=int, default=None, help="rows PER GPU (default: 65536 at N=1 = config 2; 524288/N at N>1 = config 4)")
+    ap.add_argument("--dim", type=int, default=None, help="default: 128 at N=1 (config 2), 64 at N>1 (config 4)")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "sync", "lag", "graph"],
+                    help="auto = the library default (resolves to 'lag' at the headline size)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="state dtype (the headline metric is quoted on f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-func", action="store_true", help="c3: replay the augmented dynamics from a captured HIP graph")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "rk4"],
                     help="c1: configs[0], the demo's 1000-point spiral with RK4 (plumbing); c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
                          "batch 8192 (latency-bound, reports ms per fwd+bwd and per attempted step); c5: stiff Van der Pol "
                          "mu=1000 batch 4096 (step-rejection stress, reports accepted/rejected and us per step)")
@@ -283,6 +348,8 @@ def main():
     args = ap.parse_args()
     args.tunable_op = enable_tunable_op(not args.no_tunable_op)
 
+    if args.workload == "rk4":
+        return rk4_workload(args)
     if args.workload != "c2":
         return side_workload(args)
 
@@ -319,7 +386,17 @@ def main():
     from paddlexde_amd.utils import _rms_norm
     from paddlexde_amd.xde import BaseODE
 
-    B, D = args.batch, args.dim
+    # N = 1: config 2 (65536 x 128).  N > 1: config 4 (524288 x 64 GLOBAL, split over the ranks).
+    GLOBAL_C4, DIM_C4 = 524288, 64
+    explicit = args.batch is not None or args.dim is not None
+    if world > 1 and not explicit:
+        if GLOBAL_C4 % world:
+            raise SystemExit("config 4's 524288 rows do not split evenly over {} ranks; pass --batch".format(world))
+        B, D, scaling, cfg_name = GLOBAL_C4 // world, DIM_C4, "strong", "BASELINE.json configs[3]"
+    else:
+        B = 65536 if args.batch is None else args.batch
+        D = (128 if world == 1 else DIM_C4) if args.dim is None else args.dim
+        scaling, cfg_name = "weak", ("BASELINE.json configs[1]" if (B, D) == (65536, 128) else "custom size")
     A, y0 = make_problem(B, D, rank, device)
     if args.dtype == "f64":
         A, y0 = A.double(), y0.double()
@@ -340,6 +417,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # pipeline="auto" on a small state starts eagerly and captures its hipGraph after AUTO_GRAPH_AFTER attempts: let it settle
+    # (setup, like the GEMM tuning) before the W warm-up steps, so that no capture falls into the timed region
+    settle = 0
+    while args.pipeline == "auto" and solver._auto_state in (None, "sync-then-graph") and settle < 64:
+        solver.advance(4)
+        settle += 4
     solver.advance(args.warmup)
     barrier()
     if not args.no_kernel_events:
@@ -372,20 +455,22 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": "linear ODE dy/dt=Ay, dopri5 adaptive (rtol 1e-5, atol 1e-7), batch={} x dim={} per GPU, {} GPU(s), "
-                        "func = torch matmul{}".format(B, D, world, " (framework GEMM picked by PyTorch TunableOp)" if args.tunable_op else ""),
+            "workload": "{}: linear ODE dy/dt=Ay, dopri5 adaptive (rtol 1e-5, atol 1e-7), global batch={} x dim={} = {} rows per GPU "
+                        "x {} GPU(s), func = torch matmul{}".format(cfg_name, B * world, D, B, world,
+                                                                  " (framework GEMM picked by PyTorch TunableOp)" if args.tunable_op else ""),
             "global_batch": B * world,
+            "rows_per_gpu": B,
             "dim": D,
-            "pipeline": args.pipeline,
+            "pipeline": args.pipeline if args.pipeline != "auto" else "auto -> " + str(solver._auto_state),
             "parallelism": "batch-sharded x{} (error-norm all-reduce only)".format(world) if world > 1 else "single GPU",
         },
         "solver": {"n_steps": int(c.n_steps), "n_accept": int(c.n_accept), "n_reject": int(c.n_reject), "t": float(c.t1),
-                   "dt": float(c.dt)},
+                   "dt": float(c.dt), "settle_steps": settle},
     }
     if prof is not None:
         kern = {}
@@ -402,7 +487,7 @@ def main():
         achieved = comb["bytes"] / (comb["ms"] * 1e-3) / 1e9 if comb["ms"] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_combine.json")
-        if os.path.exists(tpath) and (B, D, args.dtype) == (65536, 128, "f32"):  # the PMC passes were taken at the default workload size
+        if os.path.exists(tpath) and (B, D, args.dtype) == (65536, 128, "f32") and world == 1:  # the PMC passes were taken at the default workload size
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -430,7 +515,7 @@ def main():
         out["solver_only_states_per_s"] = N_local / (solver_ms * 1e-3) if solver_ms > 0 else None
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
-        out["cpu_baseline"] = cpu_baseline(D)
+        out["cpu_baseline"] = cpu_baseline(B, D)
 
     if dist is not None:
         dist.barrier()

@@ -24,8 +24,17 @@ namespace {
 __global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const NormSlot* slot,
                                                              const double* sums, const double* t_span,
                                                              const double* step_t, void* t_stage_out,
-                                                             xde_ctrl_t* mirror) {
-  control_block<false>(c, p, slot, sums, t_span, step_t, t_stage_out, mirror, 0, 0);
+                                                             xde_ctrl_t* mirror, int flags, int partial_cap) {
+  control_block<false>(c, p, slot, sums, t_span, step_t, t_stage_out, mirror, 0, 0, flags, partial_cap);
+}
+
+// XDE_CTRL_FLAGS: see publish_block (xde_control_device.hpp)
+inline int ctrl_flags() {
+  static int v = [] {
+    const char* e = getenv("XDE_CTRL_FLAGS");
+    return (e && *e) ? atoi(e) : 7;
+  }();
+  return v;
 }
 
 // Controller arguments of the fused launch
@@ -255,8 +264,10 @@ int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void
   if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_rk_control: n_step_t > 0 without step_t_dev");
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_CONTROL, 0.0);
+  int cap = grid_cap() + XDE_MAX_SEG;  // the largest grid a norm launch uses (build_segmap: the cap + one block per segment)
+  if (cap > XDE_MAX_PARTIALS) cap = XDE_MAX_PARTIALS;
   XDE_LAUNCH(xde_control_kernel, dim3(1), dim3(kBlock), st, prof, ctrl, *params, ws ? slot_ptr(ws, 0) : nullptr, sums,
-             t_span_dev, step_t_dev, t_stage_out, host_mirror);
+             t_span_dev, step_t_dev, t_stage_out, host_mirror, ctrl_flags(), cap);
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

@@ -19,17 +19,36 @@ template <typename TT> __device__ inline TT fmax__(TT a, TT b);
 template <> __device__ inline float fmax__<float>(float a, float b) { return fmaxf(a, b); }
 template <> __device__ inline double fmax__<double>(double a, double b) { return fmax(a, b); }
 
+// The two time-table entries the controller is about to need, fetched by spare lanes while the partials are being reduced
+// (each is otherwise a dependent global load on lane 0's critical path).
+struct TimePrefetch {
+  int out_idx;      // t_span[out_idx], t_span[out_idx + 1]
+  double out_t[2];
+  int step_idx;     // step_t[step_idx], step_t[step_idx + 1]
+  double step_v[2];
+};
+
+__device__ __forceinline__ double table_at(const double* table, int i, const TimePrefetch* pf, bool is_span) {
+  if (pf) {
+    const int base = is_span ? pf->out_idx : pf->step_idx;
+    if (i == base) return is_span ? pf->out_t[0] : pf->step_v[0];
+    if (i == base + 1) return is_span ? pf->out_t[1] : pf->step_v[1];
+  }
+  return table[i];
+}
+
 // Plan the pending attempt: step_t clipping (base_adaptive_solver_rk.py:209-215), the underflow and
 // max_num_steps assertions (:200, :120-122) and the stage times of _runge_kutta_step (:159-164).
 template <typename TT>
-__device__ void plan_next(xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* step_t, void* t_stage_out) {
+__device__ void plan_next(xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* step_t, void* t_stage_out,
+                          const TimePrefetch* pf = nullptr) {
   const TT dir = TT(p.direction);
   TT t0 = TT(c->t1);
   TT dt = TT(c->dt);
   TT t1 = t0 + dt;
   int on = 0;
   if (p.n_step_t > 0 && step_t) {
-    TT nxt = TT(step_t[c->next_step_index]);
+    TT nxt = TT(table_at(step_t, c->next_step_index, pf, false));
     if (dir * t0 < dir * nxt && dir * nxt < dir * (t0 + dt)) {
       on = 1;
       t1 = nxt;
@@ -59,7 +78,7 @@ __device__ void plan_next(xde_ctrl_t* c, const xde_ctrl_params_t& p, const doubl
 
 template <typename TT>
 __device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double ratio_d, double nonfinite,
-                             const double* t_span, const double* step_t, void* t_stage_out) {
+                             const double* t_span, const double* step_t, void* t_stage_out, const TimePrefetch* pf = nullptr) {
   const TT dir = TT(p.direction);
   const TT t0 = TT(c->t1);
   const TT dt = TT(c->dt);
@@ -130,7 +149,7 @@ __device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double r
   int b = c->next_out;
   int e = b;
   if (accept) {
-    while (e < c->n_out && dir * TT(t_span[e]) <= dir * t1) ++e;
+    while (e < c->n_out && dir * TT(table_at(t_span, e, pf, true)) <= dir * t1) ++e;
   }
   c->out_begin = b;
   c->out_end = e;
@@ -140,7 +159,7 @@ __device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double r
 
   if (accept && c->on_step_t && c->next_step_index != p.n_step_t - 1) c->next_step_index += 1;  // :263-265
 
-  plan_next<TT>(c, p, step_t, t_stage_out);
+  plan_next<TT>(c, p, step_t, t_stage_out, pf);
 }
 
 // The pinned host mirror slot of a control block is a seqlock (slot[seq % SLOTS]): its seq word is invalidated FIRST
@@ -153,22 +172,40 @@ __device__ inline void invalidate_slot(xde_ctrl_t* mirror, int64_t seq_next) {
 
 // Write a finished control block back: one wave instruction to the device block, one to the mirror slot.  Called by all
 // threads of the block after `zs` is complete and visible in LDS and after invalidate_slot(mirror, zs.seq) by wave 0.
-__device__ inline void publish_block(xde_ctrl_t* c, const xde_ctrl_t& zs, xde_ctrl_t* mirror) {
+// XDE_CTRL_FLAGS bits (kernel argument `flags`; all variants publish the same block and keep the same ordering contract):
+//   1  light ordering of the mirror stores: the invalidation, the payload and the new seq are write-through system-scope
+//      stores to fine-grained host memory issued by ONE wave, separated by `s_waitcnt vmcnt(0)` (each group is acknowledged
+//      before the next is issued) instead of full system-scope release fences, whose L2 write-back has nothing to do with
+//      these stores
+//   2  header and partial records in one memory round trip (reduce_partials_speculative)
+//   4  the next output time / forced step time prefetched by spare lanes (TimePrefetch)
+constexpr int kCtrlLightPublish = 1, kCtrlSpecPartials = 2, kCtrlPrefetchTimes = 4;
+
+__device__ inline void publish_block(xde_ctrl_t* c, const xde_ctrl_t& zs, xde_ctrl_t* mirror, int flags = 0) {
   constexpr int kWords = sizeof(xde_ctrl_t) / 8;
   constexpr int kSeqWord = offsetof(xde_ctrl_t, seq) / 8;
   static_assert(kWords <= 64, "the control block is published by ONE wave");
   xde_ctrl_t* ms = mirror ? mirror + (zs.seq % XDE_MIRROR_SLOTS) : nullptr;
+  const bool light = (flags & kCtrlLightPublish) != 0;
   if (threadIdx.x < 64) {
-    if (mirror) __threadfence_system();  // the invalidation is ordered before the payload stores
+    if (mirror) {  // the invalidation (issued by this wave long ago) is ordered before the payload stores
+      if (light) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else __threadfence_system();
+    }
     if (threadIdx.x < kWords) {
       const uint64_t word = reinterpret_cast<const uint64_t*>(&zs)[threadIdx.x];
       reinterpret_cast<uint64_t*>(c)[threadIdx.x] = word;
       if (mirror && threadIdx.x != kSeqWord)
         __hip_atomic_store(reinterpret_cast<uint64_t*>(ms) + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (mirror) {  // the wave that wrote the words releases them, then publishes seq
-      __threadfence_system();
-      if (threadIdx.x == 0) __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (mirror) {  // the wave that wrote the words waits for them to be acknowledged, then publishes seq
+      if (light) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        __threadfence_system();
+        if (threadIdx.x == 0) __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -179,11 +216,26 @@ __device__ inline void publish_block(xde_ctrl_t* c, const xde_ctrl_t& zs, xde_ct
 template <bool FUSED>
 __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const NormSlot* slot, const double* sums,
                               const double* t_span, const double* step_t, void* t_stage_out, xde_ctrl_t* mirror,
-                              int nblocks, int norm_kind) {
+                              int nblocks, int norm_kind, int flags = 0, int partial_cap = XDE_MAX_PARTIALS) {
   __shared__ double seg_val[XDE_MAX_SEG];
   __shared__ double seg_nf[XDE_MAX_SEG];
   __shared__ xde_ctrl_t zs;
+  __shared__ TimePrefetch pfs;
   constexpr int kWords = sizeof(xde_ctrl_t) / 8;
+  const bool prefetch = (flags & kCtrlPrefetchTimes) != 0;
+  if (prefetch && threadIdx.x == 64) {  // a lane of wave 1: two dependent loads, off lane 0's critical path
+    const int i = c->next_out;
+    pfs.out_idx = i;
+    pfs.out_t[0] = i < c->n_out ? t_span[i] : 0.0;
+    pfs.out_t[1] = i + 1 < c->n_out ? t_span[i + 1] : 0.0;
+  }
+  if (prefetch && threadIdx.x == 128) {
+    const int i = c->next_step_index;
+    pfs.step_idx = i;
+    const bool has = p.n_step_t > 0 && step_t;
+    pfs.step_v[0] = has && i < p.n_step_t ? step_t[i] : 0.0;
+    pfs.step_v[1] = has && i + 1 < p.n_step_t ? step_t[i + 1] : 0.0;
+  }
   // the control block is fetched by the first lanes while the partials are being reduced (it is written only by
   // controller launches, i.e. before this launch started)
   if (threadIdx.x < kWords) {
@@ -205,6 +257,8 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
     __syncthreads();
     if (FUSED)
       reduce_partials<true>(slot, seg_val, seg_nf, nblocks, p.n_seg, norm_kind);
+    else if (flags & kCtrlSpecPartials)
+      reduce_partials_speculative(slot, seg_val, seg_nf, partial_cap);
     else
       reduce_partials<false>(slot, seg_val, seg_nf);
   }
@@ -220,15 +274,16 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
       double ratio = norm_from_sums(seg_val, p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, z.ratio_seg);
       double nf = 0.0;
       for (int s = 0; s < p.n_seg; ++s) nf += seg_nf[s];
+      const TimePrefetch* pf = prefetch ? &pfs : nullptr;  // (visible: every path above ends in a __syncthreads)
       if (p.time_dtype == XDE_F32)
-        control_step<float>(&z, p, ratio, nf, t_span, step_t, t_stage_out);
+        control_step<float>(&z, p, ratio, nf, t_span, step_t, t_stage_out, pf);
       else
-        control_step<double>(&z, p, ratio, nf, t_span, step_t, t_stage_out);
+        control_step<double>(&z, p, ratio, nf, t_span, step_t, t_stage_out, pf);
     }
     zs = z;
   }
   __syncthreads();
-  publish_block(c, zs, mirror);
+  publish_block(c, zs, mirror, flags);
 }
 
 

@@ -81,6 +81,9 @@ __device__ __forceinline__ int find_segment(const SegMap& m, int b) {
 // ------------------------------------------------------------------------------------------
 // fixed-order reduction of block partials → per-segment sums (one workgroup)
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reduce_records(const double* rv, const double* rf, const int* rs, int n_seg, bool rms,
+                                               double* seg_val, double* seg_nf);
+
 template <bool SC1 = false>
 __device__ void reduce_partials(const NormSlot* slot, double* seg_val, double* seg_nf, int nblocks_known = -1,
                                 int n_seg_known = 0, int norm_kind_known = 0) {
@@ -90,8 +93,6 @@ __device__ void reduce_partials(const NormSlot* slot, double* seg_val, double* s
   // strided per-thread order -> wave64 shuffle tree -> 4 wave results summed in order.  Fixed order, so
   // the value is bit-reproducible from launch to launch and identical on every rank.
   constexpr int kPer = XDE_MAX_PARTIALS / kBlock;
-  __shared__ double w_val[kWaves];
-  __shared__ double w_nf[kWaves];
   // (the fused launch knows its own grid; it must not read the header other workgroups are not ordered with)
   const int nblocks = nblocks_known >= 0 ? nblocks_known : slot->nblocks;
   const int n_seg = nblocks_known >= 0 ? n_seg_known : slot->n_seg;
@@ -119,6 +120,49 @@ __device__ void reduce_partials(const NormSlot* slot, double* seg_val, double* s
       rs[i] = -1;
     }
   }
+  reduce_records(rv, rf, rs, n_seg, rms, seg_val, seg_nf);
+}
+
+// `speculative` form of the load phase: the header (nblocks) and the records are fetched in ONE memory round trip — every
+// lane pulls its records of the whole partial array (it is allocated at full size; stale records are masked afterwards)
+// instead of waiting for nblocks first.  Same reduction order, same result.
+__device__ __forceinline__ void reduce_partials_speculative(const NormSlot* slot, double* seg_val, double* seg_nf, int cap) {
+  constexpr int kPer = XDE_MAX_PARTIALS / kBlock;
+  double rv[kPer], rf[kPer];
+  int rs[kPer];
+  const int per = (cap + kBlock - 1) / kBlock;  // wave-uniform: records beyond the largest grid any launch uses are skipped
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    if (i < per) {
+      Partial rec = slot->p[threadIdx.x + i * kBlock];
+      rv[i] = rec.val;
+      rf[i] = rec.nf;
+      rs[i] = rec.seg;
+    } else {
+      rv[i] = 0.0;
+      rf[i] = 0.0;
+      rs[i] = -1;
+    }
+  }
+  const int nblocks = slot->nblocks;
+  const int n_seg = slot->n_seg;
+  const bool rms = slot->norm_kind == XDE_NORM_RMS;
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    if (threadIdx.x + i * kBlock >= nblocks) {
+      rv[i] = 0.0;
+      rf[i] = 0.0;
+      rs[i] = -1;
+    }
+  }
+  reduce_records(rv, rf, rs, n_seg, rms, seg_val, seg_nf);
+}
+
+__device__ __forceinline__ void reduce_records(const double* rv, const double* rf, const int* rs, int n_seg, bool rms,
+                                               double* seg_val, double* seg_nf) {
+  constexpr int kPer = XDE_MAX_PARTIALS / kBlock;
+  __shared__ double w_val[kWaves];
+  __shared__ double w_nf[kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int s = 0; s < n_seg; ++s) {
     double v = 0.0, f = 0.0;

@@ -31,7 +31,8 @@ def test_bench_json_contract():
     assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"]
     assert j["unit"] == "states/s" and j["value"] > 0 and j["ms_per_step"] > 0
     assert abs(j["value"] - 4096 * 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6  # value = states per step / step time
-    assert j["solver"]["n_steps"] == 8  # warmup + steps attempted, nothing skipped
+    # warmup + steps attempted, nothing skipped (+ the untimed settle attempts after which pipeline="auto" has captured its graph)
+    assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"]
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["achieved"] > 0

