@@ -81,9 +81,9 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, 
 __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
                                      int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
                                      int64_t seq0, const double* first_step_dev) {
+  __shared__ xde_ctrl_t z;  // (LDS, not a private copy: no scratch)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  xde_ctrl_t z;
-  memset(&z, 0, sizeof(z));
+  for (int i = 0; i < int(sizeof(xde_ctrl_t) / 8); ++i) reinterpret_cast<uint64_t*>(&z)[i] = 0;
   z.t0 = t_start;
   z.t1 = t_start;
   // device-resident first step (xde_initial_step): a magnitude, given the direction's sign here
@@ -112,7 +112,7 @@ __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double 
     plan_next<float>(&z, p, step_t, t_stage_out);
   else
     plan_next<double>(&z, p, step_t, t_stage_out);
-  *c = z;
+  for (int i = 0; i < int(sizeof(xde_ctrl_t) / 8); ++i) reinterpret_cast<uint64_t*>(c)[i] = reinterpret_cast<const uint64_t*>(&z)[i];
 }
 
 // New output list for a running solve (AdaptiveRKSolver.step(next_t), base_adaptive_solver_rk.py:116-127): rows of the new
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void xde_ctrl_retarget_kernel(xde_ctrl_t* c, xd
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    xde_ctrl_t z = zs;
+    xde_ctrl_t& z = zs;  // in place, in LDS (no scratch: see control_block)
     z.seq += 1;
     const double dir = double(p.direction);
     int e = 0;
@@ -142,7 +142,6 @@ __global__ __launch_bounds__(64) void xde_ctrl_retarget_kernel(xde_ctrl_t* c, xd
     z.done = (e >= n_out) ? 1 : 0;
     z.steps_in_interval = 0;
     if (z.status == XDE_STATUS_MAX_STEPS) z.status = XDE_STATUS_OK;
-    zs = z;
   }
   __syncthreads();
   publish_block(c, zs, mirror);

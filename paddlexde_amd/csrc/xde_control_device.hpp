@@ -40,7 +40,7 @@ __device__ __forceinline__ double table_at(const double* table, int i, const Tim
 // Plan the pending attempt: step_t clipping (base_adaptive_solver_rk.py:209-215), the underflow and
 // max_num_steps assertions (:200, :120-122) and the stage times of _runge_kutta_step (:159-164).
 template <typename TT>
-__device__ void plan_next(xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* step_t, void* t_stage_out,
+__device__ __forceinline__ void plan_next(xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* step_t, void* t_stage_out,
                           const TimePrefetch* pf = nullptr) {
   const TT dir = TT(p.direction);
   TT t0 = TT(c->t1);
@@ -77,7 +77,7 @@ __device__ void plan_next(xde_ctrl_t* c, const xde_ctrl_params_t& p, const doubl
 }
 
 template <typename TT>
-__device__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double ratio_d, double nonfinite,
+__device__ __forceinline__ void control_step(xde_ctrl_t* c, const xde_ctrl_params_t& p, double ratio_d, double nonfinite,
                              const double* t_span, const double* step_t, void* t_stage_out, const TimePrefetch* pf = nullptr) {
   const TT dir = TT(p.direction);
   const TT t0 = TT(c->t1);
@@ -263,7 +263,10 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
       reduce_partials<false>(slot, seg_val, seg_nf);
   }
   if (threadIdx.x == 0) {
-    xde_ctrl_t z = zs;  // all controller arithmetic runs on registers
+    // The controller works on the LDS copy in place.  (A private copy of the 288-byte block — it has arrays indexed at run
+    // time — lives in SCRATCH memory: every field access is a memory round trip and, worse, a dispatch that needs scratch
+    // costs microseconds more to launch.  This kernel uses no scratch.)
+    xde_ctrl_t& z = zs;
     z.seq += 1;
     if (z.done) {
       // an attempt enqueued past the last output (speculative / graph replay) is a no-op: nothing to commit,
@@ -280,7 +283,6 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
       else
         control_step<double>(&z, p, ratio, nf, t_span, step_t, t_stage_out, pf);
     }
-    zs = z;
   }
   __syncthreads();
   publish_block(c, zs, mirror, flags);

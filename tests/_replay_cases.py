@@ -82,11 +82,11 @@ def test_replay_config2_shape_fp32(dev, pipeline):
     ref, so, ref_states = _oracle_run(lambda t_, y: y @ An.T, y0, t, rtol=1e-5, atol=1e-7)
     got, s, states = _replay_run(lambda t_, y: y @ Ad.T, y0, t, so, dev, rtol=1e-5, atol=1e-7, pipeline=pipeline)
     # func is a 128-term GEMM: numpy's and the device's summation orders differ by ulps in every k_j.  Relative part of the
-    # bar: 1e-5, strictly.  Absolute part (elements passing through zero; the state is O(4)): 1 ulp of the state's scale for
+    # bar: 1e-5, strictly.  Absolute part (elements passing through zero; the state is O(4)): 2 ulp of the state's scale for
     # every step's y1, 4 ulp for the emitted rows — the dense-output quartic (ode_utils.py:28-49) forms its coefficients from
     # differences like 18 y0 + 14 y1 - 32 y_mid, which amplify a last-bit difference of their inputs (P.ulp_atol).
     _check(got, s, states, ref, so, ref_states, ratio_rtol=2e-2, ratio_atol=1e-4, pipeline=pipeline,
-           y_atol=P.ulp_atol(ref, 1), dense_atol=P.ulp_atol(ref, 4))
+           y_atol=P.ulp_atol(ref, 2), dense_atol=P.ulp_atol(ref, 4))
 
 
 @pytest.mark.parametrize("controller", ["I", "PI"])

@@ -22,7 +22,7 @@ def _run(*extra):
 
 
 def test_bench_json_contract():
-    j = _run()
+    j = _run("--pipeline", "lag")  # (per-kernel HIP events need eager launches; "auto" replays a hipGraph at this small size)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in j, key
@@ -32,6 +32,12 @@ def test_bench_json_contract():
     assert j["unit"] == "states/s" and j["value"] > 0 and j["ms_per_step"] > 0
     assert abs(j["value"] - 4096 * 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6  # value = states per step / step time
     # warmup + steps attempted, nothing skipped (+ the untimed settle attempts after which pipeline="auto" has captured its graph)
+    assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"] and j["solver"]["settle_steps"] == 0
+
+
+def test_bench_default_pipeline_settles_before_the_timed_region():
+    j = _run("--no-cpu-baseline")
+    assert j["config"]["pipeline"] == "auto -> graph" and j["solver"]["settle_steps"] >= 16
     assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"]
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
