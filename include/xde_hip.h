@@ -354,6 +354,31 @@ int xde_commit(const xde_ctrl_t* ctrl, void* y0_dst, const void* y1_src, void* f
 int xde_graph_replace_memsets(void* hip_graph, int* n_replaced);
 
 /*
+ * One-shot peer-to-peer exchange of the norm sums between the GPUs of ONE node (new; the reference has no multi-GPU
+ * integrator — what it replaces is the all-reduce the batch-sharded solve needs because `_rms_norm` reduces over the
+ * whole batch, utils/ode_utils.py:8-9,80-82).  Every rank owns a small mailbox in uncached device memory
+ * (xde_p2p_alloc), exports it (xde_p2p_export: a 64-byte IPC handle the host framework ships to the other ranks, e.g.
+ * with all_gather_object) and maps every peer's (xde_p2p_import).  xde_p2p_exchange then replaces
+ * `all_reduce(sums)` between xde_norm_finalize and xde_rk_control / xde_norm_result: ONE launch stores the caller's
+ * 2*XDE_MAX_SEG doubles into every peer's mailbox over xGMI, waits (bounded by spin_limit polls; on expiry the sums are
+ * made to stop the solve and xde_p2p_error reports the exchange number) until every peer's vector has arrived, and
+ * overwrites sums_dev with their sum (XDE_NORM_LINF: max for the first XDE_MAX_SEG entries) taken in RANK ORDER —
+ * bit-identical on every rank.  Ranks must call it the same number of times (lock-step, as the solver's ranks are).
+ *   peer_mailboxes: host array of `world` device pointers, peer_mailboxes[rank] == local_mailbox.
+ */
+#define XDE_P2P_MAX_RANKS 16
+#define XDE_P2P_HANDLE_BYTES 64
+int64_t xde_p2p_mailbox_bytes(void);
+int xde_p2p_alloc(void** ptr_out);
+int xde_p2p_free(void* ptr);
+int xde_p2p_export(void* ptr, void* handle_out);
+int xde_p2p_import(const void* handle, void** ptr_out);
+int xde_p2p_close(void* ptr);
+int xde_p2p_exchange(double* sums_dev, void* local_mailbox, void* const* peer_mailboxes, int world, int rank,
+                     int norm_kind, int64_t spin_limit, void* stream);
+int xde_p2p_error(const void* local_mailbox, int64_t* error_out, void* stream);
+
+/*
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline figure).  xde_prof_enable(period): 0 = off; p >= 1 = every p-th launch of each kernel id is
  * launched with a start/stop event pair stamped by the dispatch itself (hipExtLaunchKernelGGL), so the

@@ -17,6 +17,7 @@ XDE_MIRROR_SLOTS = 4
 ABI_VERSION = 2
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
+XDE_P2P_MAX_RANKS, XDE_P2P_HANDLE_BYTES = 16, 64
 COMBINE_RK, COMBINE_FUSE, COMBINE_WFUSE = 0, 1, 2
 NORM_RMS, NORM_LINF = 0, 1
 STATUS_OK, STATUS_DT_UNDERFLOW, STATUS_NONFINITE, STATUS_MAX_STEPS = 0, 1, 2, 3
@@ -51,6 +52,14 @@ SYMBOLS = (
     "xde_hermite_gather",
     "xde_scale_fanout",
     "xde_graph_replace_memsets",
+    "xde_p2p_mailbox_bytes",
+    "xde_p2p_alloc",
+    "xde_p2p_free",
+    "xde_p2p_export",
+    "xde_p2p_import",
+    "xde_p2p_close",
+    "xde_p2p_exchange",
+    "xde_p2p_error",
     "xde_prof_enable",
     "xde_prof_collect",
 )
@@ -209,6 +218,21 @@ def load_library():
         lib.xde_commit.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
         lib.xde_graph_replace_memsets.restype = i32
         lib.xde_graph_replace_memsets.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.xde_p2p_mailbox_bytes.restype = i64
+        lib.xde_p2p_alloc.restype = i32
+        lib.xde_p2p_alloc.argtypes = [C.POINTER(C.c_void_p)]
+        lib.xde_p2p_free.restype = i32
+        lib.xde_p2p_free.argtypes = [vp]
+        lib.xde_p2p_export.restype = i32
+        lib.xde_p2p_export.argtypes = [vp, vp]
+        lib.xde_p2p_import.restype = i32
+        lib.xde_p2p_import.argtypes = [vp, C.POINTER(C.c_void_p)]
+        lib.xde_p2p_close.restype = i32
+        lib.xde_p2p_close.argtypes = [vp]
+        lib.xde_p2p_exchange.restype = i32
+        lib.xde_p2p_exchange.argtypes = [vp, vp, vpp, i32, i32, i32, i64, vp]
+        lib.xde_p2p_error.restype = i32
+        lib.xde_p2p_error.argtypes = [vp, C.POINTER(C.c_int64), vp]
         lib.xde_prof_enable.restype = i32
         lib.xde_prof_enable.argtypes = [i32]
         lib.xde_prof_collect.restype = i32

@@ -1,0 +1,189 @@
+// libxde_hip.so — one-shot peer-to-peer exchange of the error-norm sums between the GPUs of one node.
+//
+// The batch-sharded solve has ONE coupling: the global error norm (reference: utils/ode_utils.py:8-9,80-82 reduce over every
+// element of the batch), i.e. 32 doubles per attempted step that every rank must sum identically.  A ring all-reduce pays
+// 2(N-1) dependent hops for them; xGMI is point-to-point, so each GPU can instead STORE its 32 doubles straight into a
+// mailbox in every peer's memory (IPC-mapped, uncached) and then sum the N vectors it received — in fixed rank order, so
+// every rank computes the bit-identical result and the controllers stay in lock-step.  One launch, no host involvement, no
+// collective library on the path; usable under speculative enqueue and inside hipGraph replay (the exchange counter lives in
+// device memory, not in kernel arguments).
+//
+// Protocol of exchange number q (q = ++local.xseq, the same on every rank because ranks run in lock-step):
+//   post   rank r stores its vector into peer[p].slot[q % S].data[r] for every p (self included), waits until the stores
+//          are acknowledged, then stores q into peer[p].slot[q % S].flag[r];
+//   wait   rank p polls its own slot[q % S].flag[0..N) until all equal q (bounded: a peer that never arrives raises an
+//          error flag instead of hanging the GPU);
+//   sum    data[0] (+|max) data[1] ... data[N-1], left to right.
+// A rank can be at most one exchange ahead of another (it needs everybody's vector q to finish exchange q), so a ring of
+// S >= 2 slots is never overwritten while it is still being read; S = 4.
+
+#include "xde_common.hpp"
+
+using namespace xde;
+
+namespace {
+
+constexpr int kP2PSlots = 4;
+constexpr int kVec = 2 * XDE_MAX_SEG;  // [value(seg 0..15), nonfinite(seg 0..15)] — the layout of xde_norm_finalize
+
+struct P2PSlot {
+  double data[XDE_P2P_MAX_RANKS][kVec];
+  int64_t flag[XDE_P2P_MAX_RANKS];
+};
+
+struct P2PMailbox {
+  int64_t xseq;   // exchanges started by the owner (device-resident so that a replayed hipGraph advances it)
+  int64_t error;  // exchange number of the first timeout, 0 = none (sticky)
+  int64_t pad[14];
+  P2PSlot slot[kP2PSlots];
+};
+
+struct Peers {
+  P2PMailbox* p[XDE_P2P_MAX_RANKS];
+};
+
+__global__ __launch_bounds__(64) void xde_p2p_exchange_kernel(double* sums, P2PMailbox* local, Peers peers, int world,
+                                                              int rank, int norm_kind, int64_t spin_limit) {
+  __shared__ int64_t s_seq;
+  __shared__ int s_timeout;
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    const int64_t q = local->xseq + 1;
+    local->xseq = q;
+    s_seq = q;
+    s_timeout = 0;
+  }
+  __syncthreads();
+  const int64_t q = s_seq;
+  const int sl = int(q % kP2PSlots);
+
+  // ---- post: 32 lanes x N peers write-through stores over xGMI (uncached destination) ----
+  if (lane < kVec) {
+    const uint64_t bits = uint64_t(__double_as_longlong(sums[lane]));
+    for (int p = 0; p < world; ++p)
+      __hip_atomic_store(reinterpret_cast<uint64_t*>(&peers.p[p]->slot[sl].data[rank][lane]), bits, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();  // wave-wide: every lane's data stores are acknowledged before any flag store is issued
+  if (lane < world)
+    __hip_atomic_store(&peers.p[lane]->slot[sl].flag[rank], q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+
+  // ---- wait: lane r polls the flag of rank r in the LOCAL mailbox; bounded ----
+  if (lane < world) {
+    int64_t spins = 0;
+    while (__hip_atomic_load(&local->slot[sl].flag[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != q) {
+      if (++spins > spin_limit) {
+        s_timeout = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+
+  // ---- sum in rank order ----
+  if (lane < kVec) {
+    double acc;
+    if (s_timeout) {
+      // a peer never arrived: make the controller stop the solve (non-finite count > 0 -> XDE_STATUS_NONFINITE); the host
+      // finds the mailbox's error flag and reports the exchange, not the state
+      acc = lane < XDE_MAX_SEG ? 0.0 : 1.0;
+    } else {
+      const bool is_max = norm_kind == XDE_NORM_LINF && lane < XDE_MAX_SEG;
+      acc = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const uint64_t*>(&local->slot[sl].data[0][lane]),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      for (int r = 1; r < world; ++r) {
+        const double v = __longlong_as_double((long long)__hip_atomic_load(
+            reinterpret_cast<const uint64_t*>(&local->slot[sl].data[r][lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        acc = is_max ? nanmax_(acc, v) : acc + v;
+      }
+    }
+    sums[lane] = acc;
+  }
+  if (lane == 0 && s_timeout && local->error == 0) local->error = q;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t xde_p2p_mailbox_bytes(void) { return int64_t(sizeof(P2PMailbox)); }
+
+int xde_p2p_alloc(void** ptr_out) {
+  if (!ptr_out) return fail(XDE_EBADARG, "xde_p2p_alloc: null pointer");
+  void* p = nullptr;
+  // uncached: peers' stores must be visible to this GPU's polling loads without cache maintenance
+  hipError_t e = hipExtMallocWithFlags(&p, sizeof(P2PMailbox), hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(hipExtMallocWithFlags(&p, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
+  }
+  HIP_TRY(hipMemset(p, 0, sizeof(P2PMailbox)));
+  HIP_TRY(hipDeviceSynchronize());
+  *ptr_out = p;
+  return XDE_OK;
+}
+
+int xde_p2p_free(void* ptr) {
+  if (!ptr) return XDE_OK;
+  HIP_TRY(hipFree(ptr));
+  return XDE_OK;
+}
+
+int xde_p2p_export(void* ptr, void* handle_out) {
+  if (!ptr || !handle_out) return fail(XDE_EBADARG, "xde_p2p_export: null pointer");
+  static_assert(sizeof(hipIpcMemHandle_t) == XDE_P2P_HANDLE_BYTES, "IPC handle size");
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, ptr));
+  memcpy(handle_out, &h, sizeof(h));
+  return XDE_OK;
+}
+
+int xde_p2p_import(const void* handle, void** ptr_out) {
+  if (!handle || !ptr_out) return fail(XDE_EBADARG, "xde_p2p_import: null pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void* p = nullptr;
+  HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  *ptr_out = p;
+  return XDE_OK;
+}
+
+int xde_p2p_close(void* ptr) {
+  if (!ptr) return XDE_OK;
+  HIP_TRY(hipIpcCloseMemHandle(ptr));
+  return XDE_OK;
+}
+
+int xde_p2p_exchange(double* sums_dev, void* local_mailbox, void* const* peer_mailboxes, int world, int rank, int norm_kind,
+                     int64_t spin_limit, void* stream) {
+  if (!sums_dev || !local_mailbox || !peer_mailboxes) return fail(XDE_EBADARG, "xde_p2p_exchange: null pointer");
+  if (world < 1 || world > XDE_P2P_MAX_RANKS) return fail(XDE_EBADARG, "xde_p2p_exchange: world out of range");
+  if (rank < 0 || rank >= world) return fail(XDE_EBADARG, "xde_p2p_exchange: rank out of range");
+  if (norm_kind != XDE_NORM_RMS && norm_kind != XDE_NORM_LINF) return fail(XDE_EBADARG, "xde_p2p_exchange: bad norm");
+  if (spin_limit <= 0) return fail(XDE_EBADARG, "xde_p2p_exchange: spin_limit must be positive (the wait is bounded)");
+  Peers peers;
+  memset(&peers, 0, sizeof(peers));
+  for (int p = 0; p < world; ++p) {
+    if (!peer_mailboxes[p]) return fail(XDE_EBADARG, "xde_p2p_exchange: null peer mailbox");
+    peers.p[p] = static_cast<P2PMailbox*>(peer_mailboxes[p]);
+  }
+  if (peer_mailboxes[rank] != local_mailbox) return fail(XDE_EBADARG, "xde_p2p_exchange: peer_mailboxes[rank] must be the local mailbox");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_FINALIZE, 0.0);
+  XDE_LAUNCH(xde_p2p_exchange_kernel, dim3(1), dim3(64), st, prof, sums_dev, static_cast<P2PMailbox*>(local_mailbox), peers, world,
+             rank, norm_kind, spin_limit);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_p2p_error(const void* local_mailbox, int64_t* error_out, void* stream) {
+  if (!local_mailbox || !error_out) return fail(XDE_EBADARG, "xde_p2p_error: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(error_out, &static_cast<const P2PMailbox*>(local_mailbox)->error, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return XDE_OK;
+}
+
+}  // extern "C"

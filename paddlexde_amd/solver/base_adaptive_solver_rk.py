@@ -122,6 +122,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         controller="I",
         pi_beta=0.04,
         process_group=None,
+        norm_exchange=None,
         record_trace=False,
         _replay=None,
         _step_hook=None,
@@ -158,6 +159,11 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self.controller = controller
         self.pi_beta = float(pi_beta)
         self.process_group = process_group
+        # how the per-attempt norm sums travel between the ranks of `process_group`: None = torch.distributed.all_reduce
+        # (RCCL), or a utils.PeerExchange (one-shot peer-to-peer stores into IPC-mapped mailboxes, rank-ordered sum)
+        self.norm_exchange = norm_exchange
+        if norm_exchange is not None and process_group is None:
+            raise ValueError("norm_exchange needs a process_group (it replaces that group's all-reduce)")
         self.record_trace = bool(record_trace)
         self.trace = []  # (t0, dt, ratio, accept) per attempted step when record_trace is set
         # parity harness: a prescribed (dt, accept) sequence the device controller follows (xde_ctrl_params_t.replay)
@@ -261,6 +267,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
     # ------------------------------------------------------------------------------------------
     def _allreduce_sums(self, sums):
         if self.process_group is None:
+            return
+        if self.norm_exchange is not None and sums.is_cuda:
+            self.norm_exchange.exchange(sums, self._norm_kind)
             return
         import torch.distributed as dist
 
@@ -541,6 +550,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
         if c.status == _hip.STATUS_DT_UNDERFLOW:
             raise AssertionError(_STATUS_MSG[c.status].format(c.dt))
         if c.status == _hip.STATUS_NONFINITE:
+            if self.norm_exchange is not None and self.norm_exchange.error():
+                raise _hip.XdeError("peer-to-peer norm exchange {} timed out: a rank of the process group did not arrive "
+                                    "(died, or fell out of lock-step)".format(self.norm_exchange.error()))
             raise AssertionError(_STATUS_MSG[c.status].format("{} non-finite element(s)".format(int(c.nonfinite))))
         if c.status == _hip.STATUS_MAX_STEPS:
             raise AssertionError(_STATUS_MSG[c.status].format(c.steps_in_interval, self.max_num_steps))

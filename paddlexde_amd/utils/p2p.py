@@ -1,0 +1,86 @@
+"""One-shot peer-to-peer exchange of the error-norm sums between the GPUs of one node (libxde_hip.so: xde_p2p_*).
+
+``PeerExchange(group)`` gives every rank a mailbox in uncached device memory, ships the 64-byte IPC handles around with
+``torch.distributed.all_gather_object`` (set-up only) and maps the peers' mailboxes; ``exchange(sums, norm_kind)`` then
+stands in for ``all_reduce(sums)`` in the batch-sharded solve: ONE kernel launch per attempted step, xGMI stores straight
+into the peers' memory, the sum taken in rank order on every GPU — no collective library and no host on the step's path, so
+it also works under the speculative ("lag") pipeline.  Pass it to a solver as ``options={"process_group": ...,
+"norm_exchange": PeerExchange(...)}``; ``torch.distributed`` stays the transport of everything that happens once per solve.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _hip
+
+
+class PeerExchange:
+    SPIN_LIMIT = 20_000_000  # polls of ~60 ns before an exchange gives up (about a second): a peer died or fell out of step
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+
+        self.lib = _hip.load_library()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if self.world > _hip.XDE_P2P_MAX_RANKS:
+            raise _hip.XdeError("PeerExchange serves one node: at most {} ranks".format(_hip.XDE_P2P_MAX_RANKS))
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._local = None
+        self._opened = []
+        with torch.cuda.device(self.device):
+            p = C.c_void_p()
+            self._check(self.lib.xde_p2p_alloc(C.byref(p)), "xde_p2p_alloc")
+            self._local = p.value
+            handle = (C.c_ubyte * _hip.XDE_P2P_HANDLE_BYTES)()
+            self._check(self.lib.xde_p2p_export(self._local, handle), "xde_p2p_export")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle), group=group)
+            ptrs = []
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    ptrs.append(self._local)
+                    continue
+                q = C.c_void_p()
+                buf = (C.c_ubyte * _hip.XDE_P2P_HANDLE_BYTES).from_buffer_copy(h)
+                self._check(self.lib.xde_p2p_import(buf, C.byref(q)), "xde_p2p_import")
+                self._opened.append(q.value)
+                ptrs.append(q.value)
+            self._peers = (C.c_void_p * self.world)(*ptrs)
+        dist.barrier(group=group)  # every mailbox is mapped everywhere before the first store into it
+
+    def _check(self, rc, who):
+        if rc != _hip.XDE_OK:
+            raise _hip.XdeError("{} failed (status {}): {}".format(who, rc, self.lib.xde_last_error().decode()))
+
+    def exchange(self, sums, norm_kind):
+        """In place: ``sums`` (2*XDE_MAX_SEG device doubles) becomes the rank-ordered sum (max for a linf norm's values) over
+        all ranks.  Enqueued on torch's current stream."""
+        if not sums.is_cuda or sums.dtype != torch.float64 or sums.numel() != 2 * _hip.XDE_MAX_SEG:
+            raise _hip.XdeError("PeerExchange.exchange takes the solver's 2*XDE_MAX_SEG float64 device sums")
+        rc = self.lib.xde_p2p_exchange(sums.data_ptr(), self._local, self._peers, self.world, self.rank, int(norm_kind),
+                                       self.SPIN_LIMIT, _hip.HipBackend._stream(sums))
+        self._check(rc, "xde_p2p_exchange")
+
+    def error(self):
+        """Exchange number of the first timed-out exchange on this rank, or 0 (one blocking 8-byte read)."""
+        e = C.c_int64(0)
+        self._check(self.lib.xde_p2p_error(self._local, C.byref(e), _hip.HipBackend._stream(torch.empty(0, device=self.device))), "xde_p2p_error")
+        return int(e.value)
+
+    def close(self):
+        import torch.distributed as dist
+
+        if self._local is None:
+            return
+        torch.cuda.synchronize(self.device)
+        try:
+            dist.barrier(group=self.group)  # nobody unmaps a mailbox a peer may still be storing into
+        except Exception:
+            pass
+        for q in self._opened:
+            self.lib.xde_p2p_close(q)
+        self._opened = []
+        self.lib.xde_p2p_free(self._local)
+        self._local = None

@@ -115,6 +115,11 @@ def test_every_entry_point_rejects_null_arguments():
         "xde_hermite_gather": lambda: lib.xde_hermite_gather(None, None, None, None, None, 1, 4, 2, 1, 0, None),
         "xde_scale_fanout": lambda: lib.xde_scale_fanout(None, None, None, 1, None, 8, 0, None),
         "xde_graph_replace_memsets": lambda: lib.xde_graph_replace_memsets(None, C.byref(n)),
+        "xde_p2p_alloc": lambda: lib.xde_p2p_alloc(None),
+        "xde_p2p_export": lambda: lib.xde_p2p_export(None, None),
+        "xde_p2p_import": lambda: lib.xde_p2p_import(None, None),
+        "xde_p2p_exchange": lambda: lib.xde_p2p_exchange(None, None, None, 2, 0, 0, 1000, None),
+        "xde_p2p_error": lambda: lib.xde_p2p_error(None, None, None),
         "xde_prof_collect": lambda: lib.xde_prof_collect(None, None, None),
     }
     for name, call in calls.items():
@@ -122,6 +127,7 @@ def test_every_entry_point_rejects_null_arguments():
         msg = lib.xde_last_error().decode()
         assert rc == _hip.XDE_EBADARG, (name, rc, msg)
         assert msg and (name in msg or "segments" in msg), (name, msg)
-    covered = set(calls) | {"xde_last_error", "xde_abi_version", "xde_sizeof_ctrl", "xde_sizeof_ctrl_params", "xde_workspace_bytes", "xde_host_free", "xde_prof_enable"}
+    covered = set(calls) | {"xde_last_error", "xde_abi_version", "xde_sizeof_ctrl", "xde_sizeof_ctrl_params", "xde_workspace_bytes", "xde_host_free", "xde_prof_enable",
+                                "xde_p2p_mailbox_bytes", "xde_p2p_free", "xde_p2p_close"}
     assert covered == set(_hip.SYMBOLS), set(_hip.SYMBOLS) ^ covered
     assert lib.xde_host_free(None) == _hip.XDE_OK  # freeing nothing is fine

@@ -34,17 +34,18 @@ def test_bench_json_contract():
     # warmup + steps attempted, nothing skipped (+ the untimed settle attempts after which pipeline="auto" has captured its graph)
     assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"] and j["solver"]["settle_steps"] == 0
 
-
-def test_bench_default_pipeline_settles_before_the_timed_region():
-    j = _run("--no-cpu-baseline")
-    assert j["config"]["pipeline"] == "auto -> graph" and j["solver"]["settle_steps"] >= 16
-    assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"]
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["achieved"] > 0
     assert "traffic" in rf
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "states/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+
+
+def test_bench_default_pipeline_settles_before_the_timed_region():
+    j = _run("--no-cpu-baseline")
+    assert j["config"]["pipeline"] == "auto -> graph" and j["solver"]["settle_steps"] >= 16
+    assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"]
 
 
 def test_bench_side_workloads_run():

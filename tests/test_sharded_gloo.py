@@ -30,7 +30,7 @@ def _problem(B, D):
     return A, y0
 
 
-def _solve(y0, A, pg, norm_name="rms", pipeline="sync"):
+def _solve(y0, A, pg, norm_name="rms", pipeline="sync", exchange=None):
     from paddlexde_amd import Dopri5
     from paddlexde_amd.utils import _linf_norm, _rms_norm
     from paddlexde_amd.xde import BaseODE
@@ -38,7 +38,7 @@ def _solve(y0, A, pg, norm_name="rms", pipeline="sync"):
     t = torch.linspace(0.0, 1.0, 4)
     xde = BaseODE(lambda t_, y: y @ A.T, y0=y0, t_span=t)
     s = Dopri5(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm if norm_name == "rms" else _linf_norm, process_group=pg,
-               record_trace=True, pipeline=pipeline)
+               record_trace=True, pipeline=pipeline, norm_exchange=exchange)
     return s.integrate(t), s
 
 
@@ -249,3 +249,57 @@ def test_rccl_backend_world_size_one(tmp_path, pipeline):
     tr = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
     assert np.array_equal(tr, r["trace"])
     assert np.array_equal(full.cpu().numpy(), r["sol"])
+
+
+# ----------------------------------------------------------------------------------------------
+# one-shot peer-to-peer norm exchange (utils.PeerExchange / xde_p2p_*): rehearsal with two processes on ONE GPU
+# ----------------------------------------------------------------------------------------------
+def _p2p_worker(rank, world, port, out_dir, norm_name, pipeline):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # set-up transport only (handles, element counts)
+    try:
+        from paddlexde_amd.utils import PeerExchange
+
+        B, D = 256, 32
+        A, y0 = _problem(B, D)
+        rows = slice(rank * B // world, (rank + 1) * B // world)
+        ex = PeerExchange()
+        try:
+            # the exchange alone: 100 rounds of known vectors, sum and max, checked exactly
+            sums = torch.zeros(32, dtype=torch.float64, device="cuda:0")
+            for i in range(100):
+                sums.copy_(torch.arange(32, dtype=torch.float64) * (rank + 1) + i)
+                ex.exchange(sums, 0)
+                want = sum(torch.arange(32, dtype=torch.float64) * (r + 1) + i for r in range(world))
+                assert torch.equal(sums.cpu(), want), (i, sums.cpu(), want)
+                sums.copy_(torch.arange(32, dtype=torch.float64) * (rank + 1) - i)
+                ex.exchange(sums, 1)
+                parts = [torch.arange(32, dtype=torch.float64) * (r + 1) - i for r in range(world)]
+                want = torch.cat([torch.stack(parts).max(0).values[:16], torch.stack(parts).sum(0)[16:]])
+                assert torch.equal(sums.cpu(), want), (i, sums.cpu(), want)
+            assert ex.error() == 0
+            sol, s = _solve(y0[rows].contiguous().to("cuda:0"), A.to("cuda:0"), True, norm_name, pipeline, exchange=ex)
+            sol2, s2 = _solve(y0[rows].contiguous().to("cuda:0"), A.to("cuda:0"), True, norm_name, pipeline)  # gloo all-reduce
+        finally:
+            ex.close()
+        tr = lambda so: np.asarray([[a, b, c, float(d)] for a, b, c, d in so.trace])  # noqa: E731
+        np.savez(os.path.join(out_dir, "p2p{}.npz".format(rank)), sol=sol.cpu().numpy(), trace=tr(s), sol_ar=sol2.cpu().numpy(),
+                 trace_ar=tr(s2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm_name,pipeline", [("rms", "sync"), ("rms", "lag"), ("linf", "lag")])
+def test_peer_exchange_two_ranks_on_one_gpu(tmp_path, norm_name, pipeline):
+    """The IPC-mapped mailboxes carry the per-attempt norm sums instead of an all-reduce: both ranks stay in lock-step and the
+    run is BIT-identical to the all-reduce run (two summands: the rank-ordered sum is the all-reduce's sum)."""
+    world = 2
+    mp.spawn(_p2p_worker, args=(world, _free_port(), str(tmp_path), norm_name, pipeline), nprocs=world, join=True)
+    rs = [np.load(tmp_path / "p2p{}.npz".format(r)) for r in range(world)]
+    assert np.array_equal(rs[0]["trace"], rs[1]["trace"])
+    for r in rs:
+        assert np.array_equal(r["trace"], r["trace_ar"]) and np.array_equal(r["sol"], r["sol_ar"])
+    assert len(rs[0]["trace"]) > 5
