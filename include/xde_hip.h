@@ -317,6 +317,16 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
                    int dtype, int64_t expect_step, void* stream);
 
 /*
+ * xde_dense_eval and xde_commit in ONE launch, for the hipGraph pipeline (one node less per replayed attempt; most replays
+ * have no output time inside the step and only hand the state over): rows covered by the last accepted step are written as
+ * xde_dense_eval writes them, then, if ctrl->accept, y0 <- y1 and f0 <- f1 IN PLACE (y0 and f0 = k[0] are both operands and
+ * destinations; every lane reads an element before it overwrites it).
+ */
+int xde_dense_commit(void* out_base, const void* const* k, const double* mid, int nk, void* y0, const void* y1, void* f0,
+                     const void* f1, const xde_ctrl_t* ctrl, const double* t_span_dev, int time_dtype, int64_t n, int dtype,
+                     void* stream);
+
+/*
  * Backward of xde_stage_combine for discretise-then-optimise training (the reference back-propagates through
  * its eager ops, example/ode_demo.py:51-53): every input gradient of a combine is a scalar multiple of the
  * output gradient, so one pass reads g once and writes outs[j] = g * factor_j * (dt_dev ? *dt_dev : 1).

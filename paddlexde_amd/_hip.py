@@ -49,6 +49,7 @@ SYMBOLS = (
     "xde_ctrl_wait",
     "xde_dense_eval",
     "xde_commit",
+    "xde_dense_commit",
     "xde_hermite_gather",
     "xde_scale_fanout",
     "xde_graph_replace_memsets",
@@ -214,6 +215,8 @@ def load_library():
         lib.xde_scale_fanout.argtypes = [vpp, vp, dp, i32, vp, i64, i32, vp]
         lib.xde_hermite_gather.restype = i32
         lib.xde_hermite_gather.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        lib.xde_dense_commit.restype = i32
+        lib.xde_dense_commit.argtypes = [vp, vpp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]
         lib.xde_commit.restype = i32
         lib.xde_commit.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
         lib.xde_graph_replace_memsets.restype = i32
@@ -538,6 +541,16 @@ class HipBackend:
         rc = self.lib.xde_hermite_gather(val.data_ptr(), der.data_ptr(), his.data_ptr(), his_t.data_ptr(), lags.data_ptr(), outer,
                                          T, D, lags.numel(), dtype_code(his.dtype), self._stream(his))
         self._check(rc, "xde_hermite_gather")
+
+    def dense_commit(self, out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype):
+        """dense_eval + commit in one launch (graph pipeline): rows of the last accepted step, then (y0, ks[0]) <- (y1, f1)."""
+        self._require_device(out_base, y0, y1, f1, ctrl, t_span_dev, *ks)
+        if y0.numel() == 0:
+            return
+        rc = self.lib.xde_dense_commit(out_base.data_ptr(), _ptr_array(ks), _dbl_array(mid), len(ks), y0.data_ptr(), y1.data_ptr(),
+                                       ks[0].data_ptr(), f1.data_ptr(), ctrl.data_ptr(), t_span_dev.data_ptr(), time_dtype,
+                                       y0.numel(), dtype_code(y0.dtype), self._stream(y0))
+        self._check(rc, "xde_dense_commit")
 
     def commit(self, ctrl, y0_dst, y1_src, f0_dst, f1_src):
         self._require_device(ctrl, y0_dst, y1_src, f0_dst, f1_src)

@@ -70,6 +70,21 @@ inline int grid_cap() {
   return cap > XDE_MAX_PARTIALS ? XDE_MAX_PARTIALS : cap;
 }
 
+// Grid of the norm launches (error norm, scaled norms).  Measured on config 2: the streaming rate of these kernels is the
+// same with 512, 1024 and 2048 workgroups (each lane keeps 4-8 independent 16-byte loads in flight), while every workgroup
+// costs the controller one 32-byte partial record to fetch — 512 is the default.  XDE_NORM_GRID overrides; an explicit
+// XDE_GRID_BLOCKS applies to these launches too.
+inline int norm_grid_cap() {
+  static int cap = [] {
+    const char* e = getenv("XDE_NORM_GRID");
+    if (e && *e && atoi(e) > 0) return atoi(e);
+    const char* g = getenv("XDE_GRID_BLOCKS");
+    if (g && *g && atoi(g) > 0) return atoi(g);
+    return 512;
+  }();
+  return cap > XDE_MAX_PARTIALS ? XDE_MAX_PARTIALS : cap;
+}
+
 // ------------------------------------------------------------------------------------------
 // vector types: 16 bytes per lane
 // ------------------------------------------------------------------------------------------
@@ -226,6 +241,10 @@ struct DenseArgs {
   int use_sel;
   int time_dtype;
   int64_t expect_step;
+  // optional predicated commit fused into the launch (hipGraph pipeline): if ctrl->accept, y0 <- y1 and f0 <- f1 after the
+  // rows were evaluated (the destinations ARE the y0 / k[0] operands: each lane reads an element before it overwrites it)
+  void* commit_y0;
+  void* commit_f0;
 };
 
 // fuse(dy, dt, y0): BaseODE `dy*dt + y0` (xde/base_ode.py:58) or, with damping, BaseDDE
@@ -285,7 +304,7 @@ struct ProfScope {
 
 inline int build_segmap(const xde_segments_t* segs, int width, bool vec, SegMap* m, int* nblocks_out, int cap_override = 0) {
   if (!segs || segs->n_seg < 1 || segs->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, "segments: n_seg out of range");
-  const int cap = cap_override > 0 ? cap_override : grid_cap();
+  const int cap = cap_override > 0 ? cap_override : norm_grid_cap();
   m->n_seg = segs->n_seg;
   int64_t total = 0;
   for (int s = 0; s < segs->n_seg; ++s) {

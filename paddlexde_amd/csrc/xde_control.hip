@@ -78,6 +78,53 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, 
   if (threadIdx.x == 0) __hip_atomic_store(&a.slot->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// K2+K3 for SMALL states (launch-latency-bound: configs 3 and 5): ONE workgroup walks every segment, reduces it in LDS and
+// runs the controller — no partial records, no tickets, one launch (and one hipGraph node) less per attempted step.
+template <typename T, int NORM, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_errnorm_control_single_kernel(ErrArgs a, CtrlTail tl, int flags) {
+  __shared__ double seg_val[XDE_MAX_SEG];
+  __shared__ double seg_nf[XDE_MAX_SEG];
+  __shared__ double w_val[kWaves];
+  __shared__ double w_nf[kWaves];
+  __shared__ xde_ctrl_t zs;
+  __shared__ TimePrefetch pfs;
+  control_prologue(tl.ctrl, tl.p, tl.t_span, tl.step_t, tl.mirror, flags, &zs, &pfs);
+  int sel = 0;
+  const T dt = T(a.ctrl->dt);
+  if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int seg = 0; seg < a.map.n_seg; ++seg) {
+    double acc = 0.0;
+    int nfi = 0;
+    errnorm_dispatch<T, NORM, VEC>(a, y0, k0, dt, seg, 0, 1, acc, nfi);
+    double nf = double(nfi);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      acc = merge_<NORM>(acc, __shfl_down(acc, off, 64));
+      nf += __shfl_down(nf, off, 64);
+    }
+    if (lane == 0) {
+      w_val[wave] = acc;
+      w_nf[wave] = nf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = w_val[0], f = w_nf[0];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) {
+        v = merge_<NORM>(v, w_val[w]);
+        f += w_nf[w];
+      }
+      seg_val[seg] = v;
+      seg_nf[seg] = f;
+    }
+    __syncthreads();
+  }
+  control_tail(tl.ctrl, tl.p, seg_val, seg_nf, tl.t_span, tl.step_t, tl.t_stage_out, tl.mirror, flags, &zs, &pfs);
+}
+
 __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
                                      int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
                                      int64_t seq0, const double* first_step_dev) {
@@ -233,6 +280,36 @@ int xde_error_norm_control(const void* const* k, const void* k0_alt, const doubl
   tl.mirror = host_mirror;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_ERRNORM, bytes);
+  {
+    // small state: one workgroup does everything (XDE_SINGLE_ELEMS elements or fewer; 0 switches the path off)
+    static const int64_t single_max = [] {
+      const char* e = getenv("XDE_SINGLE_ELEMS");
+      return (e && *e) ? atoll(e) : int64_t(1) << 16;
+    }();
+    int64_t total = 0;
+    for (int s2 = 0; s2 < segs->n_seg; ++s2) total += segs->seg_len[s2];
+    if (total <= single_max) {
+      dim3 g1(1), b1(kBlock);
+      const int fl = ctrl_flags();
+#define LAUNCH_ES(T, NORM)                                                                           \
+  do {                                                                                               \
+    if (vec)                                                                                         \
+      XDE_LAUNCH((xde_errnorm_control_single_kernel<T, NORM, true>), g1, b1, st, prof, a, tl, fl);   \
+    else                                                                                             \
+      XDE_LAUNCH((xde_errnorm_control_single_kernel<T, NORM, false>), g1, b1, st, prof, a, tl, fl);  \
+  } while (0)
+      if (dtype == XDE_F32) {
+        if (params->norm_kind == XDE_NORM_RMS) LAUNCH_ES(float, XDE_NORM_RMS);
+        else LAUNCH_ES(float, XDE_NORM_LINF);
+      } else {
+        if (params->norm_kind == XDE_NORM_RMS) LAUNCH_ES(double, XDE_NORM_RMS);
+        else LAUNCH_ES(double, XDE_NORM_LINF);
+      }
+#undef LAUNCH_ES
+      HIP_TRY(hipGetLastError());
+      return XDE_OK;
+    }
+  }
   dim3 g(nblocks), b(kBlock);
 #define LAUNCH_EC(T, NORM)                                                                 \
   do {                                                                                     \
@@ -263,7 +340,7 @@ int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void
   if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_rk_control: n_step_t > 0 without step_t_dev");
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_CONTROL, 0.0);
-  int cap = grid_cap() + XDE_MAX_SEG;  // the largest grid a norm launch uses (build_segmap: the cap + one block per segment)
+  int cap = (norm_grid_cap() > fused_grid_cap() ? norm_grid_cap() : fused_grid_cap()) + XDE_MAX_SEG;  // the largest grid a norm launch uses (build_segmap: the cap + one block per segment)
   if (cap > XDE_MAX_PARTIALS) cap = XDE_MAX_PARTIALS;
   XDE_LAUNCH(xde_control_kernel, dim3(1), dim3(kBlock), st, prof, ctrl, *params, ws ? slot_ptr(ws, 0) : nullptr, sums,
              t_span_dev, step_t_dev, t_stage_out, host_mirror, ctrl_flags(), cap);

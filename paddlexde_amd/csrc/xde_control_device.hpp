@@ -210,9 +210,69 @@ __device__ inline void publish_block(xde_ctrl_t* c, const xde_ctrl_t& zs, xde_ct
   }
 }
 
-// The controller workgroup: reduce the partials (or take finalised sums), run the controller on a register copy of
-// the control block, write it back to the device block and the pinned host mirror.  FUSED = called by the last
-// workgroup of the fused error-norm launch (partials were published write-through inside this launch).
+// The controller workgroup, in three parts so that the single-workgroup error-norm + controller launch can put its own
+// reduction in the middle:
+//   control_prologue  the first lanes fetch the control block into LDS, invalidate the mirror slot, prefetch the time tables;
+//   (reduction)       per-segment sums into seg_val / seg_nf (LDS), ending in a __syncthreads;
+//   control_tail      lane 0 runs the controller on the LDS block in place, one wave publishes it.
+__device__ __forceinline__ void control_prologue(const xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* t_span,
+                                                 const double* step_t, xde_ctrl_t* mirror, int flags, xde_ctrl_t* zs,
+                                                 TimePrefetch* pfs) {
+  constexpr int kWords = sizeof(xde_ctrl_t) / 8;
+  const bool prefetch = (flags & kCtrlPrefetchTimes) != 0;
+  if (prefetch && threadIdx.x == 64) {  // a lane of wave 1: two dependent loads, off lane 0's critical path
+    const int i = c->next_out;
+    pfs->out_idx = i;
+    pfs->out_t[0] = i < c->n_out ? t_span[i] : 0.0;
+    pfs->out_t[1] = i + 1 < c->n_out ? t_span[i + 1] : 0.0;
+  }
+  if (prefetch && threadIdx.x == 128) {
+    const int i = c->next_step_index;
+    pfs->step_idx = i;
+    const bool has = p.n_step_t > 0 && step_t;
+    pfs->step_v[0] = has && i < p.n_step_t ? step_t[i] : 0.0;
+    pfs->step_v[1] = has && i + 1 < p.n_step_t ? step_t[i + 1] : 0.0;
+  }
+  // the control block is fetched by the first lanes while the reduction runs (it is written only by controller launches,
+  // i.e. before this launch started)
+  if (threadIdx.x < kWords) {
+    const uint64_t word = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
+    reinterpret_cast<uint64_t*>(zs)[threadIdx.x] = word;
+    if (mirror && threadIdx.x == offsetof(xde_ctrl_t, seq) / 8) invalidate_slot(mirror, int64_t(word) + 1);
+  }
+}
+
+// Call after a __syncthreads that made zs / pfs / seg_val / seg_nf visible.
+__device__ __forceinline__ void control_tail(xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* seg_val, const double* seg_nf,
+                                             const double* t_span, const double* step_t, void* t_stage_out, xde_ctrl_t* mirror,
+                                             int flags, xde_ctrl_t* zs, const TimePrefetch* pfs) {
+  if (threadIdx.x == 0) {
+    // The controller works on the LDS copy in place.  (A private copy of the 288-byte block — it has arrays indexed at run
+    // time — lives in SCRATCH memory: every field access is a memory round trip and, worse, a dispatch that needs scratch
+    // costs microseconds more to launch.  These kernels use no scratch.)
+    xde_ctrl_t& z = *zs;
+    z.seq += 1;
+    if (z.done) {
+      // an attempt enqueued past the last output (speculative / graph replay) is a no-op: nothing to commit,
+      // no rows to emit
+      z.accept = 0;
+      z.out_begin = z.out_end = z.next_out;
+    } else {
+      double ratio = norm_from_sums(seg_val, p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, z.ratio_seg);
+      double nf = 0.0;
+      for (int s = 0; s < p.n_seg; ++s) nf += seg_nf[s];
+      const TimePrefetch* pf = (flags & kCtrlPrefetchTimes) ? pfs : nullptr;
+      if (p.time_dtype == XDE_F32)
+        control_step<float>(&z, p, ratio, nf, t_span, step_t, t_stage_out, pf);
+      else
+        control_step<double>(&z, p, ratio, nf, t_span, step_t, t_stage_out, pf);
+    }
+  }
+  __syncthreads();
+  publish_block(c, *zs, mirror, flags);
+}
+
+// FUSED = called by the last workgroup of the ticketed error-norm launch (partials were published write-through inside it).
 template <bool FUSED>
 __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const NormSlot* slot, const double* sums,
                               const double* t_span, const double* step_t, void* t_stage_out, xde_ctrl_t* mirror,
@@ -221,28 +281,7 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
   __shared__ double seg_nf[XDE_MAX_SEG];
   __shared__ xde_ctrl_t zs;
   __shared__ TimePrefetch pfs;
-  constexpr int kWords = sizeof(xde_ctrl_t) / 8;
-  const bool prefetch = (flags & kCtrlPrefetchTimes) != 0;
-  if (prefetch && threadIdx.x == 64) {  // a lane of wave 1: two dependent loads, off lane 0's critical path
-    const int i = c->next_out;
-    pfs.out_idx = i;
-    pfs.out_t[0] = i < c->n_out ? t_span[i] : 0.0;
-    pfs.out_t[1] = i + 1 < c->n_out ? t_span[i + 1] : 0.0;
-  }
-  if (prefetch && threadIdx.x == 128) {
-    const int i = c->next_step_index;
-    pfs.step_idx = i;
-    const bool has = p.n_step_t > 0 && step_t;
-    pfs.step_v[0] = has && i < p.n_step_t ? step_t[i] : 0.0;
-    pfs.step_v[1] = has && i + 1 < p.n_step_t ? step_t[i + 1] : 0.0;
-  }
-  // the control block is fetched by the first lanes while the partials are being reduced (it is written only by
-  // controller launches, i.e. before this launch started)
-  if (threadIdx.x < kWords) {
-    const uint64_t word = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
-    reinterpret_cast<uint64_t*>(&zs)[threadIdx.x] = word;
-    if (mirror && threadIdx.x == offsetof(xde_ctrl_t, seq) / 8) invalidate_slot(mirror, int64_t(word) + 1);
-  }
+  control_prologue(c, p, t_span, step_t, mirror, flags, &zs, &pfs);
   if (sums) {
     if (threadIdx.x < XDE_MAX_SEG) {
       seg_val[threadIdx.x] = sums[threadIdx.x];
@@ -262,30 +301,7 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
     else
       reduce_partials<false>(slot, seg_val, seg_nf);
   }
-  if (threadIdx.x == 0) {
-    // The controller works on the LDS copy in place.  (A private copy of the 288-byte block — it has arrays indexed at run
-    // time — lives in SCRATCH memory: every field access is a memory round trip and, worse, a dispatch that needs scratch
-    // costs microseconds more to launch.  This kernel uses no scratch.)
-    xde_ctrl_t& z = zs;
-    z.seq += 1;
-    if (z.done) {
-      // an attempt enqueued past the last output (speculative / graph replay) is a no-op: nothing to commit,
-      // no rows to emit
-      z.accept = 0;
-      z.out_begin = z.out_end = z.next_out;
-    } else {
-      double ratio = norm_from_sums(seg_val, p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, z.ratio_seg);
-      double nf = 0.0;
-      for (int s = 0; s < p.n_seg; ++s) nf += seg_nf[s];
-      const TimePrefetch* pf = prefetch ? &pfs : nullptr;  // (visible: every path above ends in a __syncthreads)
-      if (p.time_dtype == XDE_F32)
-        control_step<float>(&z, p, ratio, nf, t_span, step_t, t_stage_out, pf);
-      else
-        control_step<double>(&z, p, ratio, nf, t_span, step_t, t_stage_out, pf);
-    }
-  }
-  __syncthreads();
-  publish_block(c, zs, mirror, flags);
+  control_tail(c, p, seg_val, seg_nf, t_span, step_t, t_stage_out, mirror, flags, &zs, &pfs);
 }
 
 

@@ -21,21 +21,24 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // K4: dense output (quartic through y0, y_mid, y1, f0, f1), coefficients never materialised
 // ------------------------------------------------------------------------------------------
-template <typename T, typename TT, bool VEC>
+template <typename T, typename TT, bool VEC, bool COMMIT = false>
 __global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
   const xde_ctrl_t* c = a.ctrl;
-  if (!c->accept) return;
-  if (a.expect_step >= 0 && c->n_steps != a.expect_step) return;
-  const int ob = c->out_begin, oe = c->out_end;
-  if (oe <= ob) return;
+  if (!c->accept) return;  // nothing to emit, nothing to commit
+  const bool expected = !(a.expect_step >= 0 && c->n_steps != a.expect_step);
+  const int ob = c->out_begin, oe = expected ? c->out_end : c->out_begin;
+  if (!COMMIT && oe <= ob) return;
   const int sel = a.use_sel ? (c->sel_used ? 1 : 0) : 0;
-  const T* __restrict__ y0 = static_cast<const T*>(a.y0[sel]);
-  const T* __restrict__ k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  // (no __restrict__ on the operands the COMMIT variant also writes)
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
   const T* __restrict__ y1 = static_cast<const T*>(a.y1);
   const T* __restrict__ f1p = static_cast<const T*>(a.f1);
-  T* __restrict__ out = static_cast<T*>(a.out_base);
+  T* out = static_cast<T*>(a.out_base);
+  T* cy = static_cast<T*>(a.commit_y0);
+  T* cf = static_cast<T*>(a.commit_f0);
   const T dt = T(TT(c->dt_last));  // `dt.astype(y0.dtype)`
   const TT t0 = TT(c->t0), t1 = TT(c->t1);
   const int nk = a.nk;
@@ -60,10 +63,15 @@ __global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
   };
 
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
-    P y0v = P::load(y0, i);
     P y1v = P::load(y1, i);
-    P f0v = P::load(k0, i);
     P f1v = P::load(f1p, i);
+    if (COMMIT && oe <= ob) {  // the common replay: no output time inside this step, only the state hand-over
+      y1v.store(cy, i);
+      f1v.store(cf, i);
+      continue;
+    }
+    P y0v = P::load(y0, i);
+    P f0v = P::load(k0, i);
     P acc;
     for (int j = 0; j < nk; ++j) {
       const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
@@ -80,6 +88,10 @@ __global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
       for (int w = 0; w < W; ++w) o.v[w] = eval(y0v.v[w], y1v.v[w], f0v.v[w], f1v.v[w], y0v.v[w] + acc.v[w], x);
       o.store(out + int64_t(r) * a.n, i);
     }
+    if (COMMIT) {
+      y1v.store(cy, i);
+      f1v.store(cf, i);
+    }
   }
   if (VEC) {
     const int64_t i = nvec * W + threadIdx.x;
@@ -93,6 +105,10 @@ __global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
       for (int r = ob; r < oe; ++r) {
         TT xt = (TT(a.t_span[r]) - t0) / (t1 - t0);
         out[int64_t(r) * a.n + i] = eval(y0[i], y1[i], k0[i], f1p[i], y0[i] + acc, T(xt));
+      }
+      if (COMMIT) {
+        cy[i] = y1[i];
+        cf[i] = f1p[i];
       }
     }
   }
@@ -241,18 +257,26 @@ __global__ __launch_bounds__(kBlock) void xde_hermite_vec_kernel(T* __restrict__
 
 extern "C" {
 
-int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, const double* mid, int nk, const void* y0,
-                   const void* y0_alt, const void* y1, const void* f1, const xde_ctrl_t* ctrl, const double* t_span_dev,
-                   int time_dtype, int64_t n, int dtype, int64_t expect_step, void* stream) {
-  if (!out_base || !k || !mid || !y0 || !y1 || !f1 || !ctrl || !t_span_dev) return fail(XDE_EBADARG, "xde_dense_eval: null pointer");
-  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_dense_eval: nk out of range");
-  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_dense_eval: bad dtype");
-  if (time_dtype != XDE_F32 && time_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_dense_eval: bad time_dtype");
-  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_dense_eval: y0_alt/k0_alt must come together");
-  if (n < 0) return fail(XDE_EBADARG, "xde_dense_eval: negative n");
+}  // extern "C"
+
+static int dense_launch(const char* who_c, void* out_base, const void* const* k, const void* k0_alt, const double* mid, int nk,
+                        const void* y0, const void* y0_alt, const void* y1, const void* f1, const xde_ctrl_t* ctrl,
+                        const double* t_span_dev, int time_dtype, int64_t n, int dtype, int64_t expect_step, void* commit_y0,
+                        void* commit_f0, void* stream) {
+  const std::string who(who_c);
+  if (!out_base || !k || !mid || !y0 || !y1 || !f1 || !ctrl || !t_span_dev) return fail(XDE_EBADARG, who + ": null pointer");
+  if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, who + ": nk out of range");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, who + ": bad dtype");
+  if (time_dtype != XDE_F32 && time_dtype != XDE_F64) return fail(XDE_EBADARG, who + ": bad time_dtype");
+  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, who + ": y0_alt/k0_alt must come together");
+  if ((commit_y0 == nullptr) != (commit_f0 == nullptr)) return fail(XDE_EBADARG, who + ": commit destinations must come together");
+  if (commit_y0 && y0_alt) return fail(XDE_EBADARG, who + ": the fused commit serves the graph pipeline (no operand select)");
+  if (n < 0) return fail(XDE_EBADARG, who + ": negative n");
   if (n == 0) return XDE_OK;
   DenseArgs a;
   memset(&a, 0, sizeof(a));
+  a.commit_y0 = commit_y0;
+  a.commit_f0 = commit_f0;
   a.out_base = out_base;
   a.y0[0] = y0;
   a.y0[1] = y0_alt ? y0_alt : y0;
@@ -270,8 +294,9 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
   // every output row starts at out_base + r*n elements: rows stay 16-byte aligned only if n % width == 0
   bool vec = aligned16(out_base) && (n % width == 0) && aligned16(y0) && aligned16(a.y0[1]) && aligned16(y1) &&
              aligned16(f1) && aligned16(a.k0_alt);
+  if (commit_y0) vec = vec && aligned16(commit_y0) && aligned16(commit_f0);
   for (int j = 0; j < nk; ++j) {
-    if (!k[j]) return fail(XDE_EBADARG, "xde_dense_eval: null k[j]");
+    if (!k[j]) return fail(XDE_EBADARG, who + ": null k[j]");
     a.k[j] = k[j];
     a.mid[j] = mid[j];
     vec = vec && aligned16(k[j]);
@@ -286,12 +311,17 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_DENSE, double(nk + 4) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
-#define LAUNCH_DENSE(T, TT)                                                     \
-  do {                                                                          \
-    if (vec)                                                                    \
-      XDE_LAUNCH((xde_dense_kernel<T, TT, true>), g, b, st, prof, a);      \
-    else                                                                        \
-      XDE_LAUNCH((xde_dense_kernel<T, TT, false>), g, b, st, prof, a);     \
+#define LAUNCH_DENSE(T, TT)                                                              \
+  do {                                                                                   \
+    if (commit_y0) {                                                                     \
+      if (vec)                                                                           \
+        XDE_LAUNCH((xde_dense_kernel<T, TT, true, true>), g, b, st, prof, a);            \
+      else                                                                               \
+        XDE_LAUNCH((xde_dense_kernel<T, TT, false, true>), g, b, st, prof, a);           \
+    } else if (vec)                                                                      \
+      XDE_LAUNCH((xde_dense_kernel<T, TT, true>), g, b, st, prof, a);                    \
+    else                                                                                 \
+      XDE_LAUNCH((xde_dense_kernel<T, TT, false>), g, b, st, prof, a);                   \
   } while (0)
   if (dtype == XDE_F32) {
     if (time_dtype == XDE_F32) LAUNCH_DENSE(float, float);
@@ -303,6 +333,23 @@ int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, con
 #undef LAUNCH_DENSE
   HIP_TRY(hipGetLastError());
   return XDE_OK;
+}
+
+extern "C" {
+
+int xde_dense_eval(void* out_base, const void* const* k, const void* k0_alt, const double* mid, int nk, const void* y0,
+                   const void* y0_alt, const void* y1, const void* f1, const xde_ctrl_t* ctrl, const double* t_span_dev,
+                   int time_dtype, int64_t n, int dtype, int64_t expect_step, void* stream) {
+  return dense_launch("xde_dense_eval", out_base, k, k0_alt, mid, nk, y0, y0_alt, y1, f1, ctrl, t_span_dev, time_dtype, n, dtype,
+                      expect_step, nullptr, nullptr, stream);
+}
+
+int xde_dense_commit(void* out_base, const void* const* k, const double* mid, int nk, void* y0, const void* y1, void* f0,
+                     const void* f1, const xde_ctrl_t* ctrl, const double* t_span_dev, int time_dtype, int64_t n, int dtype,
+                     void* stream) {
+  if (!k || !f0 || k[0] != f0) return fail(XDE_EBADARG, "xde_dense_commit: k[0] must be f0 (the derivative at the step's start)");
+  return dense_launch("xde_dense_commit", out_base, k, nullptr, mid, nk, y0, nullptr, y1, f1, ctrl, t_span_dev, time_dtype, n, dtype,
+                      -1, y0, f0, stream);
 }
 
 int xde_hermite_gather(void* val_out, void* der_out, const void* his, const void* his_t, const void* lags, int64_t outer,

@@ -175,11 +175,15 @@ class AdaptiveRKSolver(AdaptiveSolver):
         if _step_hook is not None:
             if pipeline not in ("auto", "sync"):
                 raise NotImplementedError("_step_hook observes attempts of pipeline='sync'")
-            pipeline = "sync"
+            self.pipeline = pipeline = "sync"
         # XDE_FUSE_CONTROL=1: error norm + controller as ONE launch (xde_error_norm_control, last-workgroup-done).
         # Bit-identical, but measured no faster than two launches (the controller's latency chain just moves into
         # the tail of the norm kernel: 36.4 us vs 23.1 + 12 us on config 2), so it is off by default.
         self._fuse_control = os.environ.get("XDE_FUSE_CONTROL", "0") == "1"
+        # ... except for SMALL states (configs 3 and 5: launch-latency-bound): there xde_error_norm_control runs as ONE workgroup
+        # that walks the segments and goes straight on to the controller — no partial records, no tickets, one launch and
+        # one hipGraph node less per attempt.  XDE_SINGLE_ELEMS = largest state (elements) served that way; 0 = off.
+        self._single_max = int(os.environ.get("XDE_SINGLE_ELEMS", str(1 << 16)))
         # the initial-step heuristic's scalar arithmetic runs on the device (xde_initial_step; no host read before the first
         # attempt).  XDE_HOST_FIRST_STEP=1 takes the host version (select_initial_step), which a custom norm always does.
         self._device_first_step = os.environ.get("XDE_HOST_FIRST_STEP", "0") != "1"
@@ -209,7 +213,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
                 raise TypeError("options['norm'] must be callable")
             if pipeline not in ("auto", "sync"):
                 raise NotImplementedError("custom norm callables run with pipeline='sync' only")
-            pipeline = "sync"
+            self.pipeline = pipeline = "sync"
             if process_group is not None:
                 raise NotImplementedError("a user norm callable cannot be all-reduced over a process_group; use _rms_norm / "
                                           "_linf_norm (or, for odeint_adjoint, the default adjoint norm or \"seminorm\")")
@@ -234,6 +238,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # one partial + finalize + result launch per chunk, each over its own segments only, so nothing is read twice — and
         # the chunk results are max-combined on the device; the controller then takes that scalar the way it takes a custom
         # norm's (a 1-segment "linf" value).  Same value as the single launch: max over segments of the per-segment RMS.
+        self._small_state = (not self._custom_norm and len(self._norm_segs) <= _hip.XDE_MAX_SEG
+                             and 0 < sum(l for _, l in self._norm_segs) <= self._single_max)
         self._chunks = None
         self._ctrl_norm_kind = self._norm_kind
         if len(self._norm_segs) > _hip.XDE_MAX_SEG:
@@ -515,7 +521,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._reduce_chunks(partial, self._csums[0:1], nonfinite_out=self._csums[m : m + 1])
             be.rk_control(ctrl, self._params, None, self._csums, self._t_span_dev, self._step_t_dev, self._t_stage)
             return y1, ks
-        if self.process_group is None and self._fuse_control:
+        if self.process_group is None and (self._fuse_control or self._small_state):
             # single GPU: error norm + controller in ONE launch (the last workgroup to arrive runs the controller)
             if fuse:
                 be.error_norm_control([ks[-1]], [coef[-1]], y0, y1, self._xsegs, self._ws, ctrl, self._params, self._t_span_dev,
@@ -715,9 +721,12 @@ class AdaptiveRKSolver(AdaptiveSolver):
                 nfe0 = self.nfe  # evaluations are accounted per resolved replay below, not while recording
                 base = self._gbase
                 y1, ks = self._attempt(base)
-                if self._solution is not None:
-                    self._dense(self._solution, base, y1, ks)
-                be.commit(self._ctrl, base[0], y1, base[1], ks[-1])
+                if self._solution is not None:  # rows of this step + the state hand-over, one launch
+                    idx, coef = self._mid_plan
+                    be.dense_commit(self._solution, [ks[j] for j in idx], coef, base[0], y1, ks[-1], self._ctrl, self._t_span_dev,
+                                    _hip.dtype_code(self.dtype))
+                else:
+                    be.commit(self._ctrl, base[0], y1, base[1], ks[-1])
                 self.nfe = nfe0
 
             self._graph = be.capture(body, self._ctrl)

@@ -474,6 +474,10 @@ class NumpyDoubleBackend:
             v[:, l, :] = (((c0 * p0 + c1 * p1) + c2 * d0) + c3 * d1) * h1
             dv[:, l, :] = ((g0 * p0 + g1 * p1) + g2 * d0) + g3 * d1
 
+    def dense_commit(self, out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype):
+        self.dense_eval(out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype)
+        self.commit(ctrl, y0, y1, ks[0], f1)
+
     def commit(self, ctrl, y0_dst, y1_src, f0_dst, f1_src):
         self.launches.append("commit")
         if self._c(ctrl).accept:
