@@ -94,7 +94,7 @@ typedef struct xde_ctrl {
   int32_t reserved[4];
 } xde_ctrl_t;
 
-#define XDE_MIRROR_SLOTS 4 /* host mirror ring: slot[seq % XDE_MIRROR_SLOTS] */
+#define XDE_MIRROR_SLOTS 16 /* host mirror ring: slot[seq % XDE_MIRROR_SLOTS] (a replayed hipGraph may hold several controller launches) */
 #define XDE_ETIMEOUT 3
 
 /* Controller parameters (host struct, passed by pointer, copied at call time). */

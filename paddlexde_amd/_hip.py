@@ -13,7 +13,7 @@ import weakref
 import torch
 
 XDE_OK, XDE_EBADARG, XDE_EHIP, XDE_ETIMEOUT = 0, 1, 2, 3
-XDE_MIRROR_SLOTS = 4
+XDE_MIRROR_SLOTS = 16
 ABI_VERSION = 2
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
@@ -560,17 +560,22 @@ class HipBackend:
 
     # -- hipGraph capture of one attempted step ---------------------------------------------------
     class _Graph:
-        def __init__(self, backend, graph, ctrl):
-            self.backend, self.graph, self.ctrl = backend, graph, ctrl
+        def __init__(self, backend, graph, ctrl, launches=1):
+            self.backend, self.graph, self.ctrl, self.launches = backend, graph, ctrl, int(launches)
 
         def replay(self):
+            """Launch the graph; returns one read handle per controller launch it holds, in order."""
             self.graph.replay()
             m = self.backend._mirrors.get(self.ctrl.data_ptr())
-            if m is not None:
-                m.seq += 1  # one controller launch per replay
+            if m is None:
+                return []
+            first = m.seq + 1
+            m.seq += self.launches
+            return [(m, first + i) for i in range(self.launches)]
 
-    def capture(self, body, ctrl):
-        """Record ``body()`` (kernels of this library + the framework ops of the user's func) into a hipGraph."""
+    def capture(self, body, ctrl, launches=1):
+        """Record ``body()`` (kernels of this library + the framework ops of the user's func) into a hipGraph; ``launches`` =
+        controller launches ``body`` makes (attempted steps per replay)."""
         from .utils.graphed import CapturedGraph
 
         g = CapturedGraph()  # (replays of a graph that holds memset nodes are synchronised: see its docstring)
@@ -581,7 +586,7 @@ class HipBackend:
         finally:
             self._tls.capturing = False
         g.finish()
-        return HipBackend._Graph(self, g, ctrl)
+        return HipBackend._Graph(self, g, ctrl, launches)
 
     # -- profiling ---------------------------------------------------------------------------
     def prof_enable(self, period=1):

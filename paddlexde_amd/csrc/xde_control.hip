@@ -80,12 +80,17 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, 
 
 // K2+K3 for SMALL states (launch-latency-bound: configs 3 and 5): ONE workgroup walks every segment, reduces it in LDS and
 // runs the controller — no partial records, no tickets, one launch (and one hipGraph node) less per attempted step.
+// The workgroup has kSingleBlock = 1024 lanes (a 32 KiB state is two 16-byte loads per lane and stream: the pass is one or two
+// memory round trips, not eight); errnorm_body's indexing takes it as kSingleBlock / kBlock "virtual" workgroups side by side.
+constexpr int kSingleBlock = 1024;
+constexpr int kSingleWaves = kSingleBlock / 64;
+
 template <typename T, int NORM, bool VEC>
-__global__ __launch_bounds__(kBlock) void xde_errnorm_control_single_kernel(ErrArgs a, CtrlTail tl, int flags) {
+__global__ __launch_bounds__(kSingleBlock) void xde_errnorm_control_single_kernel(ErrArgs a, CtrlTail tl, int flags) {
   __shared__ double seg_val[XDE_MAX_SEG];
   __shared__ double seg_nf[XDE_MAX_SEG];
-  __shared__ double w_val[kWaves];
-  __shared__ double w_nf[kWaves];
+  __shared__ double w_val[kSingleWaves];
+  __shared__ double w_nf[kSingleWaves];
   __shared__ xde_ctrl_t zs;
   __shared__ TimePrefetch pfs;
   control_prologue(tl.ctrl, tl.p, tl.t_span, tl.step_t, tl.mirror, flags, &zs, &pfs);
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_control_single_kernel(ErrA
   for (int seg = 0; seg < a.map.n_seg; ++seg) {
     double acc = 0.0;
     int nfi = 0;
-    errnorm_dispatch<T, NORM, VEC>(a, y0, k0, dt, seg, 0, 1, acc, nfi);
+    errnorm_dispatch<T, NORM, VEC>(a, y0, k0, dt, seg, 0, kSingleBlock / kBlock, acc, nfi);
     double nf = double(nfi);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_control_single_kernel(ErrA
     if (threadIdx.x == 0) {
       double v = w_val[0], f = w_nf[0];
 #pragma unroll
-      for (int w = 1; w < kWaves; ++w) {
+      for (int w = 1; w < kSingleWaves; ++w) {
         v = merge_<NORM>(v, w_val[w]);
         f += w_nf[w];
       }
@@ -289,7 +294,7 @@ int xde_error_norm_control(const void* const* k, const void* k0_alt, const doubl
     int64_t total = 0;
     for (int s2 = 0; s2 < segs->n_seg; ++s2) total += segs->seg_len[s2];
     if (total <= single_max) {
-      dim3 g1(1), b1(kBlock);
+      dim3 g1(1), b1(kSingleBlock);
       const int fl = ctrl_flags();
 #define LAUNCH_ES(T, NORM)                                                                           \
   do {                                                                                               \

@@ -584,7 +584,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._graph = None
         self.advance(None)
         self._solution = None
-        self._graph = None  # releases the captured graph and its private memory pool
+        self._graph = None  # releases the captured graphs and their private memory pools
+        self._graphs = {}
 
     AUTO_GRAPH_MAX_BYTES = 8 << 20  # per state operand; above it the step is bandwidth-bound and "lag" wins
     AUTO_GRAPH_AFTER = 16  # attempts made eagerly before a capture is worth its ~2 ms
@@ -698,8 +699,33 @@ class AdaptiveRKSolver(AdaptiveSolver):
         return c
 
     GRAPH_WARMUP_ATTEMPTS = 2
-    GRAPH_LOOKAHEAD = 2  # replays in flight before the host waits (ring has XDE_MIRROR_SLOTS = 4 slots)
-    assert GRAPH_LOOKAHEAD < _hip.XDE_MIRROR_SLOTS  # an unread block must never be overwritten (the slot is a seqlock too)
+    # Attempted steps captured per graph.  A graph launch costs the GPU ~8 us of idle time between the last node of one
+    # replay and the first node of the next (rocprofv3 trace of config 5: profiles/r02_c5_graph_gaps.txt), so a solve that
+    # runs to its end replays graphs of several attempts; attempts past the last output are device-side no-ops.
+    GRAPH_ATTEMPTS = 4
+    assert 2 * GRAPH_ATTEMPTS < _hip.XDE_MIRROR_SLOTS  # an unread block must never be overwritten (the slot is a seqlock too)
+
+    def _graph_of(self, k):
+        """The captured graph of ``k`` consecutive attempted steps on the static operands ``self._gbase``."""
+        be = self.backend
+        g = self._graphs.get(k)
+        if g is None:
+            def body():
+                nfe0 = self.nfe  # evaluations are accounted per resolved replay, not while recording
+                base = self._gbase
+                for _ in range(k):
+                    y1, ks = self._attempt(base)
+                    if self._solution is not None:  # rows of this step + the state hand-over, one launch
+                        idx, coef = self._mid_plan
+                        be.dense_commit(self._solution, [ks[j] for j in idx], coef, base[0], y1, ks[-1], self._ctrl,
+                                        self._t_span_dev, _hip.dtype_code(self.dtype))
+                    else:
+                        be.commit(self._ctrl, base[0], y1, base[1], ks[-1])
+                self.nfe = nfe0
+
+            g = self._graphs[k] = be.capture(body, self._ctrl, launches=k)
+            self._graph = g
+        return g
 
     def _advance_graph(self, max_attempts):
         be = self.backend
@@ -716,30 +742,20 @@ class AdaptiveRKSolver(AdaptiveSolver):
                     return c
             y0, f0 = self._base
             self._gbase = (y0.clone(), f0.clone())  # static operands of the captured step
-
-            def body():
-                nfe0 = self.nfe  # evaluations are accounted per resolved replay below, not while recording
-                base = self._gbase
-                y1, ks = self._attempt(base)
-                if self._solution is not None:  # rows of this step + the state hand-over, one launch
-                    idx, coef = self._mid_plan
-                    be.dense_commit(self._solution, [ks[j] for j in idx], coef, base[0], y1, ks[-1], self._ctrl, self._t_span_dev,
-                                    _hip.dtype_code(self.dtype))
-                else:
-                    be.commit(self._ctrl, base[0], y1, base[1], ks[-1])
-                self.nfe = nfe0
-
-            self._graph = be.capture(body, self._ctrl)
+            self._graphs = {}
+            self._graph_of(self.GRAPH_ATTEMPTS if to_end else min(self.GRAPH_ATTEMPTS, max(max_attempts - done, 1)))
             self._base = self._gbase
+        K = self.GRAPH_ATTEMPTS
         pending = collections.deque()
         issued = 0
         finished = False
         while True:
-            budget = to_end or (done + issued) < max_attempts
-            if not finished and budget and len(pending) < self.GRAPH_LOOKAHEAD:
-                self._graph.replay()
-                pending.append(be.ctrl_read_async(self._ctrl))
-                issued += 1
+            left = None if to_end else max_attempts - done - issued
+            if not finished and (to_end or left > 0) and len(pending) <= K:
+                # a budgeted advance (bench.py times EXACTLY its step count) ends on single-attempt replays
+                k = K if (to_end or left >= K) else (left if left in self._graphs else 1)
+                pending.extend(self._graph_of(k).replay())
+                issued += k
                 continue
             if not pending:
                 break

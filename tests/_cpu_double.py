@@ -301,6 +301,11 @@ class NumpyDoubleBackend:
             c.status = _hip.STATUS_OK
 
     def rk_control(self, ctrl, params, ws, sums, t_span_dev, step_t_dev, t_stage):
+        self._rk_control(ctrl, params, ws, sums, t_span_dev, step_t_dev, t_stage)
+        if getattr(self, "_snaps", None) is not None:
+            self._snaps.append(self.ctrl_read(ctrl))
+
+    def _rk_control(self, ctrl, params, ws, sums, t_span_dev, step_t_dev, t_stage):
         self.launches.append("control")
         c, p = self._c(ctrl), params
         c.seq += 1
@@ -485,15 +490,22 @@ class NumpyDoubleBackend:
             f0_dst.copy_(f1_src)
 
     class _Replayable:
-        def __init__(self, body):
-            self.body = body
+        def __init__(self, backend, body, ctrl, launches):
+            self.backend, self.body, self.ctrl, self.launches = backend, body, ctrl, launches
 
         def replay(self):
-            self.body()
+            # one read handle (= a snapshot of the control block) per controller launch of the body, in order
+            self.backend._snaps = snaps = []
+            try:
+                self.body()
+            finally:
+                self.backend._snaps = None
+            assert len(snaps) == self.launches
+            return snaps
 
-    def capture(self, body, ctrl):
+    def capture(self, body, ctrl, launches=1):
         # the double executes ops immediately: "capture" records the callable, each replay runs it
-        return NumpyDoubleBackend._Replayable(body)
+        return NumpyDoubleBackend._Replayable(self, body, ctrl, launches)
 
     def prof_enable(self, on=True):
         pass
