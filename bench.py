@@ -453,6 +453,9 @@ def main():
     while args.pipeline == "auto" and solver._auto_state in (None, "sync-then-graph") and settle < 64:
         solver.advance(4)
         settle += 4
+    if solver._auto_state == "graph" or args.pipeline == "graph":
+        solver.advance(solver.GRAPH_ATTEMPTS + 1)  # both graphs a budgeted advance replays (4 attempts, 1 attempt) now exist
+        settle += solver.GRAPH_ATTEMPTS + 1
     solver.advance(args.warmup)
     barrier()
     if not args.no_kernel_events:

@@ -257,6 +257,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct ProfRec {
   int kid;
   hipEvent_t start, stop;
+  double bytes;
 };
 extern std::mutex g_prof_mu;
 extern bool g_prof_on;
@@ -275,19 +276,19 @@ struct ProfScope {
   bool on;
   int kid;
   hipEvent_t start = nullptr, stop = nullptr;
-  ProfScope(int kid_, double bytes) : on(g_prof_on), kid(kid_) {
+  double bytes;
+  ProfScope(int kid_, double bytes_) : on(g_prof_on), kid(kid_), bytes(bytes_) {
     if (on) on = (g_prof_launches[kid]++ % g_prof_period) == 0;  // sample every period-th launch of this kernel
     if (on) {
       std::lock_guard<std::mutex> lk(g_prof_mu);
       start = get_event();
       stop = get_event();
-      g_prof_bytes[kid] += bytes;
     }
   }
   ~ProfScope() {
     if (on) {
       std::lock_guard<std::mutex> lk(g_prof_mu);
-      g_prof_recs.push_back(ProfRec{kid, start, stop});
+      g_prof_recs.push_back(ProfRec{kid, start, stop, bytes});
     }
   }
 };

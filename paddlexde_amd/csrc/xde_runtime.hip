@@ -153,11 +153,16 @@ int xde_prof_collect(int64_t* counts_out, double* ms_out, double* bytes_out) {
   if (!counts_out || !ms_out || !bytes_out) return fail(XDE_EBADARG, "xde_prof_collect: null pointer");
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof_recs) {
-    HIP_TRY(hipEventSynchronize(r.stop));
+    // a sampled launch that was RECORDED into a hipGraph instead of executed (stream capture) never stamped its events:
+    // it is dropped from the statistics, not an error
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
-    g_prof_counts[r.kid] += 1;
-    g_prof_ms[r.kid] += double(ms);
+    if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      g_prof_counts[r.kid] += 1;
+      g_prof_ms[r.kid] += double(ms);
+      g_prof_bytes[r.kid] += r.bytes;
+    } else {
+      (void)hipGetLastError();
+    }
     g_event_pool.push_back(r.start);
     g_event_pool.push_back(r.stop);
   }
