@@ -363,6 +363,9 @@ def main():
                     help="auto = the library default (resolves to 'lag' at the headline size)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="state dtype (the headline metric is quoted on f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p"],
+                    help="N>1: how the per-attempt norm sums travel — torch.distributed all-reduce (RCCL, default) or the one-shot "
+                         "peer-to-peer mailbox exchange (utils.PeerExchange; rehearsed on one GPU only so far)")
     ap.add_argument("--graph-func", action="store_true", help="c3: replay the augmented dynamics from a captured HIP graph")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "rk4"],
                     help="c1: configs[0], the demo's 1000-point spiral with RK4 (plumbing); c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
@@ -435,8 +438,13 @@ def main():
 
     t_span = torch.tensor([0.0, 1.0e9])
     xde = BaseODE(func, y0=y0, t_span=t_span)
+    exchange = None
+    if args.exchange == "p2p" and (world > 1 or force_dist):
+        from paddlexde_amd.utils import PeerExchange
+
+        exchange = PeerExchange()
     solver = Dopri5(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=args.pipeline,
-                    process_group=(True if (world > 1 or force_dist) else None))
+                    process_group=(True if (world > 1 or force_dist) else None), norm_exchange=exchange)
     solver.y0 = y0
     solver._before_integrate(np.asarray([0.0, 1.0e9], dtype=np.float32))
     be = _hip.get_backend()
@@ -500,7 +508,8 @@ def main():
             "rows_per_gpu": B,
             "dim": D,
             "pipeline": args.pipeline if args.pipeline != "auto" else "auto -> " + str(solver._auto_state),
-            "parallelism": "batch-sharded x{} (error-norm all-reduce only)".format(world) if world > 1 else "single GPU",
+            "parallelism": "batch-sharded x{} (error-norm {} only)".format(world, "peer-to-peer exchange" if exchange is not None else "all-reduce")
+                           if world > 1 else "single GPU",
         },
         "solver": {"n_steps": int(c.n_steps), "n_accept": int(c.n_accept), "n_reject": int(c.n_reject), "t": float(c.t1),
                    "dt": float(c.dt), "settle_steps": settle},
@@ -552,6 +561,8 @@ def main():
         if eager is not None:
             out["cpu_baseline_eager"] = eager
 
+    if exchange is not None:
+        exchange.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,6 +23,8 @@ python3 bench.py --workload c3 > $OUT/c3_eager.json 2>/dev/null
 python3 bench.py --workload c1 > $OUT/c1.json 2>/dev/null
 python3 bench.py --dtype f64 --no-cpu-baseline > $OUT/bench_f64.json 2>/dev/null
 XDE_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline > $OUT/force_dist.json 2> $OUT/force_dist.err
+XDE_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --exchange p2p > $OUT/force_dist_p2p.json 2> $OUT/force_dist_p2p.err
+for x in allreduce p2p; do XDE_BENCH_REHEARSAL=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --exchange $x --steps 20 --warmup 5 > $OUT/rehearsal_n2_$x.json 2> $OUT/rehearsal_n2_$x.err; done
 for b in 2048 8192 32768 65536 262144; do for p in auto sync lag graph; do python3 bench.py --batch $b --pipeline $p --no-cpu-baseline --steps 60 --warmup 20 > $OUT/sweep_${b}_$p.json 2>/dev/null; done; done
 python3 profiles/tools/ctrl_bench.py > $OUT/ctrl_decomposition.txt 2>&1
 python3 profiles/tools/graph_bench.py > $OUT/graph_replay.txt 2>&1
