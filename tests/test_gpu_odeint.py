@@ -3,6 +3,7 @@ import pytest
 
 from ._dde_cases import *  # noqa: F401,F403
 from ._e2e_cases import *  # noqa: F401,F403
+from ._kernel_oracle_cases import *  # noqa: F401,F403
 from ._replay_cases import *  # noqa: F401,F403
 
 pytestmark = pytest.mark.gpu
