@@ -35,6 +35,15 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """Print the result line on the process's real stdout (see main)."""
+    sys.stdout.flush()
+    if _REAL_STDOUT is not None:
+        os.dup2(_REAL_STDOUT, 1)
+    print(json.dumps(obj), flush=True)
 
 
 def make_problem(B, D, rank, device):
@@ -203,8 +212,8 @@ def side_workload(args):
         ref = O.odeint(lambda t_, y: (y * y * y) @ An, y0.numpy(), t.numpy(), "rk4")
         res["cpu_baseline"] = {"seconds": time.perf_counter() - t0, "kind": "port", "cores": 1, "sample": "the whole trajectory, numpy oracle"}
         res["bit_exact_vs_oracle"] = bool(np.array_equal(last.cpu().numpy(), ref))
-        print(json.dumps({"metric": "seconds for the 1000-point spiral trajectory (launch-latency-bound plumbing)", "workload": "c1: "
-                          "example/ode_demo.py spiral, RK4 (reference variant), batch 1 x dim 2, 999 steps", "results": res}))
+        emit({"metric": "seconds for the 1000-point spiral trajectory (launch-latency-bound plumbing)", "workload": "c1: "
+                          "example/ode_demo.py spiral, RK4 (reference variant), batch 1 x dim 2, 999 steps", "results": res})
         return
     if args.workload == "c5":
         mu = 1000.0
@@ -233,8 +242,8 @@ def side_workload(args):
                 res[controller + "/" + str(dtype).split(".")[-1]] = {
                     "n_accept": st["n_accept"], "n_reject": st["n_reject"], "nfe": st["nfe"], "seconds": el,
                     "us_per_attempted_step": 1e6 * el / max(st["n_steps"], 1), "finite": bool(torch.isfinite(sol).all())}
-        print(json.dumps({"metric": "us per attempted dopri5 step (latency-bound)", "workload": "c5: Van der Pol mu=1000, batch 4096 x 2, "
-                          "t in [0,1], rtol 1e-5 atol 1e-7", "pipeline": args.pipeline, "tunable_op": bool(args.tunable_op), "results": res}))
+        emit({"metric": "us per attempted dopri5 step (latency-bound)", "workload": "c5: Van der Pol mu=1000, batch 4096 x 2, "
+                          "t in [0,1], rtol 1e-5 atol 1e-7", "pipeline": args.pipeline, "tunable_op": bool(args.tunable_op), "results": res})
         return
 
     class ODEFunc(nn.Module):  # example/ode_demo.py:17-33
@@ -286,9 +295,9 @@ def side_workload(args):
             t2 = time.perf_counter()
         gn = float(sum(p.grad.double().pow(2).sum() for p in func.parameters()).sqrt())
         res[name] = {"forward_s": t1 - t0, "backward_s": t2 - t1, "grad_norm": gn, "n_params": sum(p.numel() for p in func.parameters())}
-    print(json.dumps({"metric": "seconds per forward / adjoint backward (latency-bound)", "workload": "c3: spiral neural-ODE (2-50-2 MLP on y^3), "
+    emit({"metric": "seconds per forward / adjoint backward (latency-bound)", "workload": "c3: spiral neural-ODE (2-50-2 MLP on y^3), "
                       "batch 8192, 32 output times, odeint_adjoint", "pipeline": args.pipeline, "graph_func": bool(args.graph_func),
-                      "tunable_op": bool(args.tunable_op), "results": res}))
+                      "tunable_op": bool(args.tunable_op), "results": res})
 
 
 def rk4_workload(args):
@@ -349,7 +358,7 @@ def rk4_workload(args):
             if kern:
                 per_step = 3 * kern.get("combine_fuse", {}).get("avg_us", 0.0) + kern.get("combine_wfuse", {}).get("avg_us", 0.0)
                 out["solver_kernel_ms_per_step"] = per_step * 1e-3
-    print(json.dumps(out))
+    emit(out)
 
 
 def main():
@@ -379,6 +388,12 @@ def main():
                     help="time every p-th launch of each kernel inside the timed region (5 is coprime with the 6 "
                          "combines per step, so all stages are sampled evenly)")
     args = ap.parse_args()
+    # stdout carries ONE JSON line: whatever libraries print there meanwhile (RCCL's version banner, tuner notes) goes to
+    # stderr; the original stdout is restored just before the line is printed
+    sys.stdout.flush()
+    global _REAL_STDOUT
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     args.tunable_op = enable_tunable_op(not args.no_tunable_op)
 
     if args.workload == "rk4":
@@ -567,7 +582,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":
