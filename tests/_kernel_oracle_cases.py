@@ -96,7 +96,8 @@ def test_one_attempt_taken_apart_vs_oracle(dev, name, dtype):
     # the controller's next step from the ORACLE's ratio is what optimal_step_size gives               ode_utils.py:85-97
     tt = so.tt
     want_dt = tt(np.clip(O.optimal_step_size(tt(dt), tt(c.ratio), so.safety, so.ifactor, so.dfactor, so.order), so.min_step, so.max_step))
-    assert c.dt == float(want_dt), (name, c.dt, float(want_dt))
+    # (`ratio ** (1/order)` is the one transcendental on the path: the device's pow and numpy's agree to an ulp, not always to the bit)
+    assert c.dt == pytest.approx(float(want_dt), rel=2.4e-7 if dtype == np.float32 else 4.5e-16), (name, c.dt, float(want_dt))
 
     # ---- dense output at a time inside the step                                     :286-292; ode_utils.py:28-77
     if c.accept:
