@@ -303,3 +303,42 @@ def test_peer_exchange_two_ranks_on_one_gpu(tmp_path, norm_name, pipeline):
     for r in rs:
         assert np.array_equal(r["trace"], r["trace_ar"]) and np.array_equal(r["sol"], r["sol_ar"])
     assert len(rs[0]["trace"]) > 5
+
+
+def _p2p_timeout_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from paddlexde_amd import _hip
+        from paddlexde_amd.utils import PeerExchange
+
+        ex = PeerExchange()
+        ex.SPIN_LIMIT = 20_000  # ~ a millisecond of polling instead of a second
+        outcome = "skipped"
+        try:
+            if rank == 0:  # rank 1 never joins the solve: rank 0's first exchange must give up, not hang the GPU
+                B, D = 256, 32
+                A, y0 = _problem(B, D)
+                try:
+                    _solve(y0[: B // 2].contiguous().to("cuda:0"), A.to("cuda:0"), True, "rms", "sync", exchange=ex)
+                    outcome = "no error"
+                except _hip.XdeError as e:
+                    outcome = str(e)
+        finally:
+            ex.close()
+        with open(os.path.join(out_dir, "timeout{}.txt".format(rank)), "w") as fh:
+            fh.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_peer_exchange_gives_up_when_a_rank_never_arrives(tmp_path):
+    """The wait inside xde_p2p_exchange is bounded: a peer that never posts makes the exchange poison its sums (the controller
+    stops the solve at once) and raise the mailbox's error flag; the host reports the exchange, not a bogus non-finite state."""
+    mp.spawn(_p2p_timeout_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msg = open(tmp_path / "timeout0.txt").read()
+    assert "peer-to-peer norm exchange" in msg and "timed out" in msg, msg
+    assert open(tmp_path / "timeout1.txt").read() == "skipped"
