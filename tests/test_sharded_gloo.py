@@ -318,11 +318,24 @@ def _p2p_timeout_worker(rank, world, port, out_dir):
         ex.SPIN_LIMIT = 20_000  # ~ a millisecond of polling instead of a second
         outcome = "skipped"
         try:
-            if rank == 0:  # rank 1 never joins the solve: rank 0's first exchange must give up, not hang the GPU
-                B, D = 256, 32
-                A, y0 = _problem(B, D)
+            if rank == 0:  # rank 1 never posts: rank 0's exchange must give up, not hang the GPU
+                from paddlexde_amd import Dopri5
+                from paddlexde_amd.utils import _rms_norm
+                from paddlexde_amd.xde import BaseODE
+
+                sums = torch.arange(32, dtype=torch.float64, device="cuda:0")
+                ex.exchange(sums, 0)
+                torch.cuda.synchronize()
+                assert ex.error() == 1  # the first exchange
+                assert sums[:16].abs().sum().item() == 0.0 and (sums[16:] == 1.0).all()  # poisoned: "non-finite" count > 0
+                # ... which stops the solve; the host then reports the exchange instead of a bogus non-finite state
+                y0 = torch.ones(4, 2, device="cuda:0")
+                s_ = Dopri5(xde=BaseODE(lambda t_, y: -y, y0=y0, t_span=torch.tensor([0.0, 1.0])), y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm,
+                            process_group=True, norm_exchange=ex)
+                c = _hip.XdeCtrl()
+                c.status = _hip.STATUS_NONFINITE
                 try:
-                    _solve(y0[: B // 2].contiguous().to("cuda:0"), A.to("cuda:0"), True, "rms", "sync", exchange=ex)
+                    s_._raise_status(c)
                     outcome = "no error"
                 except _hip.XdeError as e:
                     outcome = str(e)
