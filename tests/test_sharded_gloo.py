@@ -124,13 +124,13 @@ class _Net(torch.nn.Module):
         return torch.tanh(y @ self.W1) @ self.W2 - 0.1 * y
 
 
-def _adjoint_run(y0, pg, norm="seminorm", t_grad=False, trace=None):
+def _adjoint_run(y0, pg, norm="seminorm", t_grad=False, trace=None, device="cpu"):
     from paddlexde_amd import Dopri5, odeint_adjoint
     from paddlexde_amd.utils import _rms_norm
 
-    m = _Net()
-    y0 = y0.clone().requires_grad_(True)
-    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64).requires_grad_(t_grad)
+    m = _Net().to(device)
+    y0 = y0.clone().to(device).requires_grad_(True)
+    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64).to(device).requires_grad_(t_grad)
     opts = {"norm": _rms_norm, "dtype": torch.float64}
     if pg:
         opts["process_group"] = True
@@ -143,7 +143,7 @@ def _adjoint_run(y0, pg, norm="seminorm", t_grad=False, trace=None):
     if trace is not None:
         adj["_step_hook"] = lambda i, y0_, y1_, ks, c: trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
     sol = odeint_adjoint(m, y0, t, solver=Dopri5, rtol=1e-7, atol=1e-9, options=opts, adjoint_options=adj)
-    w = torch.linspace(-1.0, 1.0, sol.numel(), dtype=torch.float64).reshape(sol.shape)
+    w = torch.linspace(-1.0, 1.0, sol.numel(), dtype=torch.float64).reshape(sol.shape).to(device)
     return m, y0, sol, w, t
 
 
@@ -355,3 +355,34 @@ def test_peer_exchange_gives_up_when_a_rank_never_arrives(tmp_path):
     msg = open(tmp_path / "timeout0.txt").read()
     assert "peer-to-peer norm exchange" in msg and "timed out" in msg, msg
     assert open(tmp_path / "timeout1.txt").read() == "skipped"
+
+
+def _nccl_adjoint_worker(rank, world, port, out_dir, norm):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        _, y_all = _adjoint_problem()
+        m, y0, sol, w, t = _adjoint_run(y_all, True, norm, True, device="cuda:0")
+        (sol * w).sum().backward()
+        np.savez(os.path.join(out_dir, "nccl_adj.npz"), sol=sol.detach().cpu().numpy(), gy=y0.grad.cpu().numpy(), gW1=m.W1.grad.cpu().numpy(),
+                 gW2=m.W2.grad.cpu().numpy(), gt=t.grad.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm", ["default", "seminorm"])
+def test_rccl_backend_world_size_one_adjoint(tmp_path, norm):
+    """The sharded odeint_adjoint over the nccl backend (RCCL) with one rank, HIP kernels: the per-evaluation sums of the
+    parameter / time adjoints (default norm), the final all-reduce ("seminorm") and the norm exchange all run on the device;
+    with one rank every sum is the identity, so solution and all gradients equal the unsharded run's."""
+    mp.spawn(_nccl_adjoint_worker, args=(1, _free_port(), str(tmp_path), norm), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl_adj.npz")
+    _, y_all = _adjoint_problem()
+    m, y0, sol, w, t = _adjoint_run(y_all, False, norm, True, device="cuda:0")
+    (sol * w).sum().backward()
+    assert P.rel_err(r["sol"], sol.detach().cpu().numpy()) <= 1e-9
+    for key, ref in (("gy", y0.grad), ("gW1", m.W1.grad), ("gW2", m.W2.grad), ("gt", t.grad)):
+        assert P.rel_err(r[key], ref.cpu().numpy()) <= 1e-8, key
