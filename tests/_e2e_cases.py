@@ -1476,3 +1476,38 @@ def test_adjoint_default_norm_with_many_parameter_tensors(dev, n_layers, pipelin
     assert P.rel_err(y0g.grad.cpu().numpy(), gy0) <= 1e-7, P.rel_err(y0g.grad.cpu().numpy(), gy0)
     for p_, g_ in zip(m.parameters(), gps):
         assert P.rel_err(p_.grad.cpu().numpy(), g_) <= 1e-7, P.rel_err(p_.grad.cpu().numpy(), g_)
+
+
+def test_auto_pipeline_survives_a_func_that_cannot_be_captured(dev):
+    """pipeline="auto" (the default) tries a hipGraph capture of the attempted step once a small-state solve has run 16
+    attempts.  A func that synchronises with the host (here: it reads a tensor value) makes that capture fail; the solve must
+    carry on eagerly and return what pipeline="sync" returns, bit for bit, with the same counts."""
+    from paddlexde_amd.xde import BaseODE
+
+    A, y0 = _linear(32, 16, torch.float32)
+    Ad = A.to(dev)
+    t = torch.linspace(0.0, 12.0, 5)
+    calls = []
+
+    def func(t_, y):
+        calls.append(float(y.abs().max()))  # device -> host read: illegal inside a stream capture
+        return y @ Ad.T
+
+    def run(pipeline):
+        y0d = y0.to(dev)
+        s = Dopri5(xde=BaseODE(func, y0=y0d, t_span=t), y0=y0d, rtol=1e-6, atol=1e-8, norm=_rms_norm, pipeline=pipeline)
+        return s.integrate(t), s
+
+    want, s1 = run("sync")
+    got, s2 = run("auto")
+    assert s1.stats["n_steps"] > 40  # long enough for auto to attempt its capture
+    assert torch.equal(got, want)
+    assert (s2.stats["n_accept"], s2.stats["n_reject"], s2.stats["nfe"]) == (s1.stats["n_accept"], s1.stats["n_reject"], s1.stats["nfe"])
+    if str(dev).startswith("cuda"):
+        assert s2._auto_state == "sync"  # the capture was attempted and abandoned
+    # and the device is still usable for a capture that can succeed
+    plain, s3 = (lambda: (lambda s: (s.integrate(t), s))(Dopri5(xde=BaseODE(lambda t_, y: y @ Ad.T, y0=y0.to(dev), t_span=t), y0=y0.to(dev),
+                                                            rtol=1e-6, atol=1e-8, norm=_rms_norm)))()
+    assert torch.equal(plain, want)
+    if str(dev).startswith("cuda"):
+        assert s3._auto_state == "graph"
