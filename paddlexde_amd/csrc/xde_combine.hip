@@ -57,10 +57,14 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
     // NT: with operands of >= 64 MiB nothing survives in the 256 MiB Infinity Cache between uses anyway; streaming
     // loads then run 12-17 % faster (5.1 -> 5.8 TB/s at 128 MiB x 7 streams).  At the 32 MiB headline size the
     // default policy wins by 18 % (the working set half-fits the cache), so the flag is size-dependent (host).
-    P y = load_sel<P>(y0, i, (ntm >> 31) & 1u);
+    // Program order of the loads: the operands whose ADDRESS does not depend on the device-side select come first.  In the
+    // speculative pipeline y0 / k0 are picked by ctrl->accept, a scalar load that is still in flight when the wave starts;
+    // k_1.. can be requested meanwhile, so the select's memory round trip hides behind them (it cost ~0.9 us per launch).
     P kk[NK];
 #pragma unroll
-    for (int j = 0; j < NK; ++j) kk[j] = load_sel<P>(kp[j], i, (ntm >> j) & 1u);
+    for (int j = NK - 1; j >= 1; --j) kk[j] = load_sel<P>(kp[j], i, (ntm >> j) & 1u);
+    P y = load_sel<P>(y0, i, (ntm >> 31) & 1u);
+    kk[0] = load_sel<P>(kp[0], i, ntm & 1u);
     P o;
     P o2;
 #pragma unroll
@@ -181,8 +185,7 @@ __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
   int sel = 0;
   T dt;
   if (a.ctrl) {
-    dt = T(a.ctrl->dt);
-    if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
   } else {
     dt = T(a.dt_host);
   }

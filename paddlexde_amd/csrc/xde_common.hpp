@@ -135,6 +135,17 @@ template <typename T> struct Pack<T, false> {
   __device__ void store(T* p, int64_t i) const { p[i] = v[0]; }
 };
 
+// dt and the operand select of this launch, read from the device control block.  Both fields are requested BEFORE either is
+// waited for (they sit in different cache lines of the block, and every launch finds them cold): one memory round trip
+// instead of two dependent ones in front of the first vector load.
+template <typename T>
+__device__ __forceinline__ void read_dt_sel(const xde_ctrl_t* c, int use_sel, T& dt, int& sel) {
+  const double dtd = __builtin_nontemporal_load(&c->dt);
+  const int32_t acc = __builtin_nontemporal_load(&c->accept);
+  dt = T(dtd);
+  sel = (use_sel && acc) ? 1 : 0;
+}
+
 // load with a run-time (wave-uniform) choice of cache policy
 template <typename P, typename T>
 __device__ __forceinline__ P load_sel(const T* p, int64_t i, bool nt) {

@@ -53,8 +53,8 @@ struct CtrlTail {
 template <typename T, int NORM, bool VEC>
 __global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, CtrlTail tl) {
   int sel = 0;
-  const T dt = T(a.ctrl->dt);
-  if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+  T dt;
+  read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
   const T* y0 = static_cast<const T*>(a.y0[sel]);
   const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
   const int seg = find_segment(a.map, blockIdx.x);
@@ -95,8 +95,8 @@ __global__ __launch_bounds__(kSingleBlock) void xde_errnorm_control_single_kerne
   __shared__ TimePrefetch pfs;
   control_prologue(tl.ctrl, tl.p, tl.t_span, tl.step_t, tl.mirror, flags, &zs, &pfs);
   int sel = 0;
-  const T dt = T(a.ctrl->dt);
-  if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+  T dt;
+  read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
   const T* y0 = static_cast<const T*>(a.y0[sel]);
   const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

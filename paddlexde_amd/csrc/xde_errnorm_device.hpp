@@ -49,13 +49,15 @@ __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restri
     // NT: y0 and k_0..k_{NK-2} are read here for the last time when the step is accepted (the common case) and
     // are streamed; y1 and the last operand (f1) become the next step's (y0, f0), which all its stage combines
     // re-read, so they keep the default policy and stay in the Infinity Cache
-    P y0v = NT ? P::load_nt(y0, vbase + i) : P::load(y0, vbase + i);
+    // (program order: operands whose address does not depend on the device-side select first, y0 / k0 last — see combine_body)
     P y1v = P::load(y1, vbase + i);
-    P kk[NK];
-#pragma unroll
-    for (int j = 0; j < NK; ++j) kk[j] = (NT && j < NK - 1) ? P::load_nt(kp[j], vbase + i) : P::load(kp[j], vbase + i);
     P ep;
     if (PRE) ep = NT ? P::load_nt(epre, vbase + i) : P::load(epre, vbase + i);
+    P kk[NK];
+#pragma unroll
+    for (int j = NK - 1; j >= 1; --j) kk[j] = (NT && j < NK - 1) ? P::load_nt(kp[j], vbase + i) : P::load(kp[j], vbase + i);
+    kk[0] = (NT && 0 < NK - 1) ? P::load_nt(kp[0], vbase + i) : P::load(kp[0], vbase + i);
+    P y0v = NT ? P::load_nt(y0, vbase + i) : P::load(y0, vbase + i);
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       T e = PRE ? ep.v[w] + kk[0].v[w] * c[0] : kk[0].v[w] * c[0];

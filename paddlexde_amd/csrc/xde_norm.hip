@@ -25,8 +25,7 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
   int sel = 0;
   T dt;
   if (a.ctrl) {
-    dt = T(a.ctrl->dt);
-    if (a.use_sel) sel = a.ctrl->accept ? 1 : 0;
+    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
   } else {
     dt = T(a.dt_host);
   }
