@@ -133,6 +133,33 @@ def _make_functional_dynamics(func, adjoint_params, t_requires_grad):
 
 _GRAPH_CACHE = weakref.WeakKeyDictionary()  # func module -> {signature: GraphedFunc}; captures are reused across calls
 
+AUTO_GRAPH_FUNC_MAX_BYTES = 8 << 20  # "auto": states above this are bandwidth-bound, the launches are not the cost
+AUTO_GRAPH_FUNC_MIN_INTERVALS = 4  # "auto": output intervals needed to amortise a first capture
+
+
+class _NoGraph:
+    """Cache marker: capturing the dynamics of this module / signature failed once; it runs eagerly."""
+
+    refused = True
+
+
+def _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options):
+    """Whether adjoint_options["graph_func"] = "auto" captures the augmented dynamics for this call."""
+    import threading
+
+    if not (isinstance(func, nn.Module) and torch.is_tensor(y0) and y0.is_cuda):
+        return False
+    if threading.current_thread() is not threading.main_thread() or torch.cuda.is_current_stream_capturing():
+        return False
+    if adjoint_options.get("process_group") is not None:
+        return False
+    if y0.numel() * y0.element_size() > AUTO_GRAPH_FUNC_MAX_BYTES or len(adjoint_params) == 0:
+        return False
+    own = {id(p) for p in func.parameters()}
+    if any(id(p) not in own for p in adjoint_params):
+        return False
+    return len(t_span) - 1 >= AUTO_GRAPH_FUNC_MIN_INTERVALS or func in _GRAPH_CACHE
+
 
 def _graph_time_examples(adjoint_method, adjoint_options, t_span, y0):
     """The time arguments (shape, dtype) the adjoint solver will hand to func, for pre-capturing its HIP graph."""
@@ -342,18 +369,26 @@ def odeint_adjoint(
     if not torch.is_tensor(t_span):
         t_span = torch.as_tensor(t_span)
 
-    # opt-in adjoint_options["graph_func"] (True, or a dict that caches captures across calls): the augmented dynamics
-    # (func forward + autograd vjp, ~30 eager launches) is captured into one HIP graph per time-argument signature.
-    # It has to happen HERE — on the calling thread and outside the autograd Function: capturing from the engine's
-    # worker thread (where backward runs), or inside Function.forward while the parameters are its inputs, crashes
-    # the runtime.
-    if adjoint_options.get("graph_func", False):
+    # adjoint_options["graph_func"]: the augmented dynamics (func forward + autograd vjp, ~30 eager launches) captured into one
+    # HIP graph per time-argument signature and replayed (config 3's backward: 105 -> 34 ms).  True (or a dict that caches
+    # captures across calls) forces it; False switches it off; absent / "auto" (the default) uses it when it pays and is safe:
+    # a small state (launch-bound), an nn.Module func whose parameters are the adjoint parameters, several output intervals to
+    # amortise the capture over (or a capture already cached for this module), the main thread, no capture in progress, no
+    # per-evaluation all-reduce — and falls back to the eager dynamics if the capture fails.
+    # The capture has to happen HERE — on the calling thread and outside the autograd Function: capturing from the engine's
+    # worker thread (where backward runs), or inside Function.forward while the parameters are its inputs, crashes the runtime.
+    mode = adjoint_options.get("graph_func", "auto")
+    forced = mode is True or isinstance(mode, dict)
+    if mode == "auto":
+        adjoint_options.pop("graph_func", None)
+        mode = _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options)
+    if mode:
         from ..utils.graphed import GraphedFunc
 
         if not isinstance(func, nn.Module):
             raise NotImplementedError("adjoint_options['graph_func'] needs func to be an nn.Module")
-        if isinstance(adjoint_options["graph_func"], dict):
-            cache = adjoint_options["graph_func"]
+        if isinstance(mode, dict):
+            cache = mode
         else:
             cache = _GRAPH_CACHE.setdefault(func, {})
         t_rg = bool(t_span.requires_grad)
@@ -363,6 +398,9 @@ def odeint_adjoint(
         key = ("aug-flat", tuple(y0.shape), y0.dtype, str(y0.device), t_rg, fixed,
                tuple((id(p), p.data_ptr()) for p in adjoint_params))
         graphed = cache.get(key)
+        if isinstance(graphed, _NoGraph):
+            mode = False
+    if mode and not isinstance(cache.get(key), _NoGraph):
         # the augmented state (adj_t, y, adj_y, *adj_params) in the flat, 16-byte-segment layout odeint() will use
         aug_example = [torch.zeros([], dtype=y0.dtype, device=y0.device), y0.detach(), torch.zeros_like(y0)]
         aug_example += [torch.zeros_like(p) for p in adjoint_params]
@@ -384,9 +422,19 @@ def odeint_adjoint(
             cache[key] = graphed
         flat_ex = _pack(aug_example, segs, total, adt, y0.device)
         flat_ex = flat_ex[None, :] if fixed else flat_ex
-        for t_ex in _graph_time_examples(adjoint_solver, adjoint_options, t_span, y0):
-            graphed.prepare(t_ex, flat_ex)
-        adjoint_options["_graphed"] = graphed
+        try:
+            for t_ex in _graph_time_examples(adjoint_solver, adjoint_options, t_span, y0):
+                graphed.prepare(t_ex, flat_ex)
+            if not graphed.refused:
+                adjoint_options["_graphed"] = graphed
+        except Exception:
+            if forced:
+                raise
+            # "auto": this func cannot be captured (host synchronisation, unsupported op, ...): eager dynamics, and no
+            # second attempt for this module and signature
+            cache[key] = _NoGraph()
+        if isinstance(cache.get(key), _NoGraph):
+            adjoint_options.pop("_graphed", None)
 
     solution = OdeintAdjointMethod.apply(
         func,

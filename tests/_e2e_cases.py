@@ -1511,3 +1511,45 @@ def test_auto_pipeline_survives_a_func_that_cannot_be_captured(dev):
     assert torch.equal(plain, want)
     if str(dev).startswith("cuda"):
         assert s3._auto_state == "graph"
+
+
+def test_adjoint_graph_func_auto(dev):
+    """adjoint_options["graph_func"] defaults to "auto": with an nn.Module func, a small state and several output intervals the
+    augmented dynamics is replayed from a captured HIP graph without the caller asking — same gradients, bit for bit, as with
+    graph_func=False; a module whose forward synchronises with the host cannot be captured and silently stays eager."""
+    from paddlexde_amd.functional import odeint_adjoint as OA
+
+    dtype = torch.float32
+    t = torch.linspace(0.0, 1.0, 6).to(dev)
+    y0 = (torch.rand(128, 2, generator=torch.Generator().manual_seed(0)) * 4 - 2).to(dev)
+
+    def grads(m, **adj):
+        for p_ in m.parameters():
+            p_.grad = None
+        y = y0.clone().requires_grad_(True)
+        sol = odeint_adjoint(m, y, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm}, adjoint_options=adj or None)
+        sol.abs().mean().backward()
+        return [y.grad.clone()] + [p_.grad.clone() for p_ in m.parameters()]
+
+    m = ODEFunc(dtype).to(dev)
+    eager = grads(m, graph_func=False)
+    auto = grads(m)
+    for a, b in zip(auto, eager):
+        assert torch.equal(a, b)
+    if str(dev).startswith("cuda"):
+        cached = [g for g in OA._GRAPH_CACHE.get(m, {}).values() if not isinstance(g, OA._NoGraph)]
+        assert cached and cached[0].replays > 0  # the backward really ran on the captured dynamics
+
+    class Syncing(ODEFunc):
+        def forward(self, t_, y):
+            if float(y.abs().max()) < 0:  # a host read inside forward: not capturable
+                return y
+            return super().forward(t_, y)
+
+    ms = Syncing(dtype).to(dev)
+    a = grads(ms)
+    b = grads(ms, graph_func=False)
+    for ga, gb in zip(a, b):
+        assert torch.equal(ga, gb)
+    if str(dev).startswith("cuda"):
+        assert all(isinstance(g, OA._NoGraph) for g in OA._GRAPH_CACHE.get(ms, {}).values())
