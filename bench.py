@@ -283,8 +283,8 @@ def side_workload(args):
                 opts["pipeline"] = "graph"  # forward: one captured RK4 step replayed over the 31 intervals
             if "pipeline" in aopts:
                 aopts["pipeline"] = "sync"  # adjoint intervals are 1-3 steps long: speculation would waste an attempt each
-            if args.graph_func:
-                aopts["graph_func"] = True
+            if args.graph_func != "auto":
+                aopts["graph_func"] = args.graph_func == "on"
             pred = odeint_adjoint(func, y0, t, solver=solver, rtol=1e-5, atol=1e-7, options=opts, adjoint_options=aopts)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -296,7 +296,7 @@ def side_workload(args):
         gn = float(sum(p.grad.double().pow(2).sum() for p in func.parameters()).sqrt())
         res[name] = {"forward_s": t1 - t0, "backward_s": t2 - t1, "grad_norm": gn, "n_params": sum(p.numel() for p in func.parameters())}
     emit({"metric": "seconds per forward / adjoint backward (latency-bound)", "workload": "c3: spiral neural-ODE (2-50-2 MLP on y^3), "
-                      "batch 8192, 32 output times, odeint_adjoint", "pipeline": args.pipeline, "graph_func": bool(args.graph_func),
+                      "batch 8192, 32 output times, odeint_adjoint", "pipeline": args.pipeline, "graph_func": args.graph_func,
                       "tunable_op": bool(args.tunable_op), "results": res})
 
 
@@ -375,7 +375,8 @@ def main():
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p"],
                     help="N>1: how the per-attempt norm sums travel — torch.distributed all-reduce (RCCL, default) or the one-shot "
                          "peer-to-peer mailbox exchange (utils.PeerExchange; rehearsed on one GPU only so far)")
-    ap.add_argument("--graph-func", action="store_true", help="c3: replay the augmented dynamics from a captured HIP graph")
+    ap.add_argument("--graph-func", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="c3: replay the augmented dynamics from a captured HIP graph (auto = the library default, which captures here)")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "rk4"],
                     help="c1: configs[0], the demo's 1000-point spiral with RK4 (plumbing); c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
                          "batch 8192 (latency-bound, reports ms per fwd+bwd and per attempted step); c5: stiff Van der Pol "

@@ -31,7 +31,7 @@ def main():
     for src, dst in [("bench_default.json", "r02_bench_default.json"), ("rk4.json", "r02_rk4.json"), ("bench_f64.json", "r02_bench_f64.json"),
                      ("force_dist.json", "r02_force_dist.json"), ("force_dist_p2p.json", "r02_force_dist_p2p.json"),
                      ("rehearsal_n2_allreduce.json", "r02_rehearsal_n2_allreduce.json"), ("rehearsal_n2_p2p.json", "r02_rehearsal_n2_p2p.json"),
-                     ("c3_graph.json", "r02_c3_graph.json"), ("c3_eager.json", "r02_c3_eager.json"), ("c1.json", "r02_c1.json"),
+                     ("c3_graph.json", "r02_c3_graph.json"), ("c3_eager.json", "r02_c3_eager.json"), ("c3_auto.json", "r02_c3_auto.json"), ("c1.json", "r02_c1.json"),
                      ("pmc_traffic.json", "r02_pmc_traffic.json"), ("pmc_traffic_rk4.json", "r02_pmc_traffic_rk4.json")]:
         save(src, dst)
     for p in ("graph", "auto", "sync", "lag"):

@@ -19,7 +19,8 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/c5 -- python3 bench.py --wo
 python3 profiles/tools/trace_gaps.py $OUT/c5 > $OUT/c5_graph_gaps.txt 2>&1
 for p in graph auto sync lag; do python3 bench.py --workload c5 --pipeline $p > $OUT/c5_$p.json 2>/dev/null; done
 python3 bench.py --workload c3 --graph-func > $OUT/c3_graph.json 2>/dev/null
-python3 bench.py --workload c3 > $OUT/c3_eager.json 2>/dev/null
+python3 bench.py --workload c3 --graph-func off > $OUT/c3_eager.json 2>/dev/null
+python3 bench.py --workload c3 > $OUT/c3_auto.json 2>/dev/null
 python3 bench.py --workload c1 > $OUT/c1.json 2>/dev/null
 python3 bench.py --dtype f64 --no-cpu-baseline > $OUT/bench_f64.json 2>/dev/null
 XDE_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline > $OUT/force_dist.json 2> $OUT/force_dist.err
