@@ -1517,7 +1517,9 @@ def test_adjoint_graph_func_auto(dev):
     """adjoint_options["graph_func"] defaults to "auto": with an nn.Module func, a small state and several output intervals the
     augmented dynamics is replayed from a captured HIP graph without the caller asking — same gradients, bit for bit, as with
     graph_func=False; a module whose forward synchronises with the host cannot be captured and silently stays eager."""
-    from paddlexde_amd.functional import odeint_adjoint as OA
+    import importlib
+
+    OA = importlib.import_module("paddlexde_amd.functional.odeint_adjoint")  # (the package exports the function under this name)
 
     dtype = torch.float32
     t = torch.linspace(0.0, 1.0, 6).to(dev)
