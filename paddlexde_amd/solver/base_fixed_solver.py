@@ -32,16 +32,18 @@ class FixedSolver(metaclass=abc.ABCMeta):
 
     graphable = True  # the step's control flow does not depend on data (False: AdamsBashforthMoulton)
     GRAPH_MIN_STEPS = 4
+    AUTO_GRAPH_MIN_STEPS = 24  # pipeline="auto": steps needed to amortise a capture (~2 ms against ~100 us saved per step)
+    AUTO_GRAPH_MAX_BYTES = 8 << 20  # ... and only for launch-bound (small) states
 
-    def __init__(self, xde, y0, step_size=None, grid_constructor=None, interp="linear", perturb=False, pipeline="sync", **kwargs):
+    def __init__(self, xde, y0, step_size=None, grid_constructor=None, interp="linear", perturb=False, pipeline="auto", **kwargs):
         self.xde = xde
         self.y0 = y0
         self.dtype = y0.dtype
         self.step_size = step_size
         self.interp = interp
         self.perturb = perturb
-        if pipeline not in ("sync", "lag", "graph"):
-            raise ValueError("pipeline must be 'sync' or 'graph' ('lag' means 'sync' for a fixed grid)")
+        if pipeline not in ("auto", "sync", "lag", "graph"):
+            raise ValueError("pipeline must be 'auto', 'sync' or 'graph' ('lag' means 'sync' for a fixed grid)")
         self.pipeline = pipeline
         self._g_ctrls = None  # graph pipeline: device dt sources of the step's combines, in call order
         self._g_slot = 0
@@ -173,10 +175,22 @@ class FixedSolver(metaclass=abc.ABCMeta):
         direct = (int(np.prod(lead)) == 1) if len(lead) else True  # output rows are contiguous slices
         out.narrow(-2, 0, L).copy_(y0)
 
-        if (self.pipeline == "graph" and self.graphable and not tracking and not torch.is_grad_enabled() and table is not None
-                and y0.is_cuda and self.interp != "cubic" and pred_len - 1 >= self.GRAPH_MIN_STEPS
-                and threading.current_thread() is threading.main_thread() and not torch.cuda.is_current_stream_capturing()):
+        # pipeline="graph": one captured step replayed over the grid (no autograd, data-independent step).  "auto" (default)
+        # takes it for inference-style calls (grad mode off) on small states with enough steps to pay for the capture, behind
+        # the capture guard, and falls back to the eager loop below if the capture is refused or fails.
+        can_graph = (self.graphable and not tracking and not torch.is_grad_enabled() and table is not None and y0.is_cuda
+                     and self.interp != "cubic" and pred_len - 1 >= self.GRAPH_MIN_STEPS
+                     and threading.current_thread() is threading.main_thread() and not torch.cuda.is_current_stream_capturing())
+        if self.pipeline == "graph" and can_graph:
             return self._integrate_graph(t_host, t_dev, table, y0, out, L)
+        if (self.pipeline == "auto" and can_graph and pred_len - 1 >= self.AUTO_GRAPH_MIN_STEPS
+                and y0.numel() * y0.element_size() <= self.AUTO_GRAPH_MAX_BYTES):
+            nfe0 = self.nfe
+            try:
+                return self._integrate_graph(t_host, t_dev, table, y0, out, L, guard=True)
+            except Exception:  # refused by the guard, or func cannot be captured: eager loop, from the start
+                self.nfe = nfe0
+                self._g_ctrls = None
 
         try:
             for i in range(1, pred_len):
@@ -220,7 +234,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
         finally:
             self._rec, self._dt, self._row = None, None, None
 
-    def _integrate_graph(self, t_host, t_dev, table, y0, out, L):
+    def _integrate_graph(self, t_host, t_dev, table, y0, out, L, guard=False):
         """``options={"pipeline": "graph"}`` (no autograd, data-independent step): the first step runs eagerly, then ONE step
         — the combines, the framework ops of ``func``, the state hand-over — is captured into a hipGraph and replayed; per
         step the host rewrites the step's times and step sizes in device memory (two small copies) and stores the row.
@@ -256,7 +270,15 @@ class FixedSolver(metaclass=abc.ABCMeta):
 
         nfe0 = self.nfe
         load(0)
-        body()  # step 1, eagerly (warm-up of func and of the allocator)
+        if guard:  # "auto": a func that differentiates w.r.t. parameter leaves must never be captured (utils/graphed.py)
+            from ..utils.graphed import _AutogradTargetProbe
+
+            with _AutogradTargetProbe() as probe:
+                body()
+            if probe.hit is not None:
+                raise RuntimeError("capture refused: func calls " + probe.hit)
+        else:
+            body()  # step 1, eagerly (warm-up of func and of the allocator)
         out.narrow(-2, L, L).copy_(y_cur)
         per_step = self.nfe - nfe0
         from ..utils.graphed import CapturedGraph

@@ -1555,3 +1555,36 @@ def test_adjoint_graph_func_auto(dev):
         assert torch.equal(ga, gb)
     if str(dev).startswith("cuda"):
         assert all(isinstance(g, OA._NoGraph) for g in OA._GRAPH_CACHE.get(ms, {}).values())
+
+
+@pytest.mark.parametrize("name", ["euler", "midpoint", "rk4"])
+def test_fixed_auto_pipeline(dev, name):
+    """Fixed solvers default to pipeline="auto": an inference-style call (grad mode off) on a small state with >= 24 steps
+    replays ONE captured step over the grid — same trajectory bit for bit, same NFE — and a func that cannot be captured
+    (it reads a tensor value on the host) makes the call fall back to the eager loop."""
+    from paddlexde_amd.xde import BaseODE
+
+    y0 = torch.tensor([[2.0, 0.0], [1.0, -1.0]]).to(dev)
+    t = torch.linspace(0.0, 0.5, 60).to(dev)  # (short enough for first-order Euler to stay bounded on the cubic spiral)
+
+    def run(func, pipeline):
+        s = FIXED[name](xde=BaseODE(func, y0=y0, t_span=t), y0=y0, rtol=1e-3, atol=1e-4, norm=_rms_norm, pipeline=pipeline)
+        with torch.no_grad():
+            return s.integrate(t), s
+
+    want, s1 = run(P.spiral_torch, "sync")
+    got, s2 = run(P.spiral_torch, "auto")
+    assert torch.isfinite(want).all() and torch.equal(got, want) and s2.nfe == s1.nfe
+    seen = []
+
+    def syncing(t_, y):
+        seen.append(float(y.abs().max()))
+        return P.spiral_torch(t_, y)
+
+    got2, s3 = run(syncing, "auto")
+    assert torch.equal(got2, want) and s3.nfe == s1.nfe
+    # training-style call (grad mode on): the eager loop with its autograd graph, as before
+    y0g = y0.clone().requires_grad_(True)
+    sol = odeint(P.spiral_torch, y0g, t[:8], solver=FIXED[name])
+    sol.sum().backward()
+    assert y0g.grad is not None and torch.isfinite(y0g.grad).all()
