@@ -59,9 +59,14 @@ inline bool big_operand(int64_t n, int dtype) {
   return (nt_policy() & 2) && n * (dtype == XDE_F32 ? 4 : 8) >= thr;
 }
 
-// grid of the fused error-norm + controller launch: fewer, longer-running workgroups = fewer ticket arrivals
+// grid of the (opt-in) ticketed error-norm + controller launch: the norm launches' own grid unless XDE_FUSED_GRID says
+// otherwise — with the same grid both paths reduce in the same order and give bit-identical results
+inline int norm_grid_cap();
 inline int fused_grid_cap() {
-  static int cap = env_int("XDE_FUSED_GRID", 1024);
+  static int cap = [] {
+    const char* e = getenv("XDE_FUSED_GRID");
+    return (e && *e && atoi(e) > 0) ? atoi(e) : norm_grid_cap();
+  }();
   return cap > XDE_MAX_PARTIALS ? XDE_MAX_PARTIALS : cap;
 }
 
