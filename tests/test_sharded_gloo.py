@@ -281,7 +281,8 @@ def _p2p_worker(rank, world, port, out_dir, norm_name, pipeline):
                 assert torch.equal(sums.cpu(), want), (i, sums.cpu(), want)
             assert ex.error() == 0
             sol, s = _solve(y0[rows].contiguous().to("cuda:0"), A.to("cuda:0"), True, norm_name, pipeline, exchange=ex)
-            sol2, s2 = _solve(y0[rows].contiguous().to("cuda:0"), A.to("cuda:0"), True, norm_name, pipeline)  # gloo all-reduce
+            # the all-reduce twin (gloo): a captured step cannot hold it, so the graph case is compared with the lag pipeline
+            sol2, s2 = _solve(y0[rows].contiguous().to("cuda:0"), A.to("cuda:0"), True, norm_name, "lag" if pipeline == "graph" else pipeline)
         finally:
             ex.close()
         tr = lambda so: np.asarray([[a, b, c, float(d)] for a, b, c, d in so.trace])  # noqa: E731
@@ -292,10 +293,11 @@ def _p2p_worker(rank, world, port, out_dir, norm_name, pipeline):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("norm_name,pipeline", [("rms", "sync"), ("rms", "lag"), ("linf", "lag")])
+@pytest.mark.parametrize("norm_name,pipeline", [("rms", "sync"), ("rms", "lag"), ("linf", "lag"), ("rms", "graph")])
 def test_peer_exchange_two_ranks_on_one_gpu(tmp_path, norm_name, pipeline):
     """The IPC-mapped mailboxes carry the per-attempt norm sums instead of an all-reduce: both ranks stay in lock-step and the
-    run is BIT-identical to the all-reduce run (two summands: the rank-ordered sum is the all-reduce's sum)."""
+    run is BIT-identical to the all-reduce run (two summands: the rank-ordered sum is the all-reduce's sum).  The exchange
+    counter lives in device memory, so the sharded step can also be captured and replayed (pipeline="graph")."""
     world = 2
     mp.spawn(_p2p_worker, args=(world, _free_port(), str(tmp_path), norm_name, pipeline), nprocs=world, join=True)
     rs = [np.load(tmp_path / "p2p{}.npz".format(r)) for r in range(world)]
