@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XDE_ABI_VERSION 2
+#define XDE_ABI_VERSION 3
 
 #define XDE_OK 0
 #define XDE_EBADARG 1
@@ -198,10 +198,13 @@ int xde_error_norm_control(const void* const* k, const void* k0_alt, const doubl
  * compute_error_ratio (utils/ode_utils.py:80-82) materialised once: out[i] = (sum_j k_j[i]*(dt*c_err_j)) /
  * (atol + rtol*max(|y0[i]|,|y1[i]|)).  The caller applies its own norm to `out` with framework ops and hands the
  * scalar to xde_rk_control through `sums` (norm_kind = XDE_NORM_LINF, n_seg = 1, sums[0] = value).
+ *   y0_alt/k0_alt: the speculative pipeline's operand select, as in xde_stage_combine.
+ *   nonfinite_out (optional): device double, zeroed by the caller; the number of non-finite y0 elements is ADDED to it
+ *   (the `isfinite(y0).all()` pass, base_adaptive_solver_rk.py:201) — pass sums + XDE_MAX_SEG.
  */
-int xde_error_ratio(void* out, const void* const* k, const double* c_err, int nk, const void* y0, const void* y1,
-                    double rtol, double atol, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype,
-                    void* stream);
+int xde_error_ratio(void* out, const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
+                    const void* y0_alt, const void* y1, double rtol, double atol, double dt_host, const xde_ctrl_t* ctrl,
+                    int64_t n, int dtype, double* nonfinite_out, void* stream);
 
 /*
  * Scaled norms for the initial-step heuristic — replaces `scale = atol + abs(y0) * rtol`,

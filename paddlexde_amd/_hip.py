@@ -14,7 +14,7 @@ import torch
 
 XDE_OK, XDE_EBADARG, XDE_EHIP, XDE_ETIMEOUT = 0, 1, 2, 3
 XDE_MIRROR_SLOTS = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
 XDE_P2P_MAX_RANKS, XDE_P2P_HANDLE_BYTES = 16, 64
@@ -186,7 +186,7 @@ def load_library():
         lib.xde_error_norm_control.argtypes = [vpp, vp, dp, i32, vp, vp, vp, C.POINTER(XdeSegments), i32, vp, vp, vp,
                                                C.POINTER(XdeCtrlParams), vp, vp, vp, vp, vp]
         lib.xde_error_ratio.restype = i32
-        lib.xde_error_ratio.argtypes = [vp, vpp, dp, i32, vp, vp, dbl, dbl, dbl, vp, i64, i32, vp]
+        lib.xde_error_ratio.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, i64, i32, vp, vp]
         lib.xde_scaled_norm_partial.restype = i32
         lib.xde_scaled_norm_partial.argtypes = [vp, vp, vp, dbl, dbl, C.POINTER(XdeSegments), i32, i32, vp, i32, vp]
         lib.xde_norm_finalize.restype = i32
@@ -424,13 +424,13 @@ class HipBackend:
         if m is not None and not self._is_capturing():
             m.seq += 1
 
-    def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None):
-        self._require_device(out, y0, y1, *ks)
+    def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None, nonfinite_out=None):
+        self._require_device(out, y0, y1, y0_alt, k0_alt, nonfinite_out, *ks)
         if out.numel() == 0:
             return
-        rc = self.lib.xde_error_ratio(out.data_ptr(), _ptr_array(ks), _dbl_array(c_err), len(ks), y0.data_ptr(), y1.data_ptr(),
-                                      float(rtol), float(atol), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype),
-                                      self._stream(out))
+        rc = self.lib.xde_error_ratio(out.data_ptr(), _ptr_array(ks), _ptr(k0_alt), _dbl_array(c_err), len(ks), y0.data_ptr(),
+                                      _ptr(y0_alt), y1.data_ptr(), float(rtol), float(atol), float(dt_host), _ptr(ctrl), out.numel(),
+                                      dtype_code(out.dtype), _ptr(nonfinite_out), self._stream(out))
         self._check(rc, "xde_error_ratio")
 
     def scaled_norm_partial(self, a, b, y0, rtol, atol, segs, norm_kind, ws, slot):

@@ -135,12 +135,20 @@ __global__ void xde_norm_result_kernel(const double* sums, SegCounts counts, int
 // element-wise error ratio (materialised only for user-supplied norm callables)
 // ------------------------------------------------------------------------------------------
 template <typename T, bool VEC>
-__global__ __launch_bounds__(kBlock) void xde_ratio_kernel(ErrArgs a, T* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(kBlock) void xde_ratio_kernel(ErrArgs a, T* __restrict__ out, int64_t n, double* nonfinite_out) {
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
-  const T dt = a.ctrl ? T(a.ctrl->dt) : T(a.dt_host);
-  const T* __restrict__ y0 = static_cast<const T*>(a.y0[0]);
+  int sel = 0;
+  T dt;
+  if (a.ctrl) {
+    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
+  } else {
+    dt = T(a.dt_host);
+  }
+  const T* __restrict__ y0 = static_cast<const T*>(a.y0[sel]);
+  const T* __restrict__ k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
   const T* __restrict__ y1 = static_cast<const T*>(a.y1);
+  int nf = 0;
   const T rtol = T(a.rtol), atol = T(a.atol);
   const int nk = a.nk;
   const int64_t nvec = n / W;
@@ -150,14 +158,17 @@ __global__ __launch_bounds__(kBlock) void xde_ratio_kernel(ErrArgs a, T* __restr
     P y1v = P::load(y1, i);
     P e;
     for (int j = 0; j < nk; ++j) {
-      P kk = P::load(static_cast<const T*>(a.k[j]), i);
+      P kk = P::load(j == 0 ? k0 : static_cast<const T*>(a.k[j]), i);
       T cj = dt * T(a.coef[j]);
 #pragma unroll
       for (int w = 0; w < W; ++w) e.v[w] = (j == 0) ? kk.v[w] * cj : e.v[w] + kk.v[w] * cj;
     }
     P o;
 #pragma unroll
-    for (int w = 0; w < W; ++w) o.v[w] = e.v[w] / (atol + rtol * fmax_(abs_(y0v.v[w]), abs_(y1v.v[w])));
+    for (int w = 0; w < W; ++w) {
+      o.v[w] = e.v[w] / (atol + rtol * fmax_(abs_(y0v.v[w]), abs_(y1v.v[w])));
+      nf += finite_(y0v.v[w]) ? 0 : 1;
+    }
     o.store(out, i);
   }
   if (VEC) {
@@ -165,11 +176,20 @@ __global__ __launch_bounds__(kBlock) void xde_ratio_kernel(ErrArgs a, T* __restr
     if (blockIdx.x == 0 && i < n) {
       T e = T(0);
       for (int j = 0; j < nk; ++j) {
-        T term = static_cast<const T*>(a.k[j])[i] * (dt * T(a.coef[j]));
+        T term = (j == 0 ? k0 : static_cast<const T*>(a.k[j]))[i] * (dt * T(a.coef[j]));
         e = (j == 0) ? term : e + term;
       }
       out[i] = e / (atol + rtol * fmax_(abs_(y0[i]), abs_(y1[i])));
+      nf += finite_(y0[i]) ? 0 : 1;
     }
+  }
+  // the `isfinite(y0).all()` pass (base_adaptive_solver_rk.py:201) rides along: a count, added atomically (integers: exact in
+  // any order) to a device double the caller zeroed; non-finite states are the exception, so is the atomic
+  if (nonfinite_out && __any(nf != 0)) {
+    double c = double(nf);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c != 0.0) atomicAdd(nonfinite_out, c);
   }
 }
 
@@ -211,25 +231,30 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   return XDE_OK;
 }
 
-int xde_error_ratio(void* out, const void* const* k, const double* c_err, int nk, const void* y0, const void* y1,
-                    double rtol, double atol, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, void* stream) {
+int xde_error_ratio(void* out, const void* const* k, const void* k0_alt, const double* c_err, int nk, const void* y0,
+                    const void* y0_alt, const void* y1, double rtol, double atol, double dt_host, const xde_ctrl_t* ctrl,
+                    int64_t n, int dtype, double* nonfinite_out, void* stream) {
   if (!out || !k || !c_err || !y0 || !y1) return fail(XDE_EBADARG, "xde_error_ratio: null pointer");
+  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_error_ratio: y0_alt/k0_alt must come together");
+  if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_error_ratio: operand select needs ctrl");
   if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_error_ratio: nk out of range");
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_error_ratio: bad dtype");
   if (n < 0) return fail(XDE_EBADARG, "xde_error_ratio: negative n");
   if (n == 0) return XDE_OK;
   ErrArgs a;
   memset(&a, 0, sizeof(a));
-  a.y0[0] = a.y0[1] = y0;
+  a.y0[0] = y0;
+  a.y0[1] = y0_alt ? y0_alt : y0;
+  a.use_sel = y0_alt ? 1 : 0;
   a.y1 = y1;
-  bool vec = aligned16(out) && aligned16(y0) && aligned16(y1);
+  bool vec = aligned16(out) && aligned16(y0) && aligned16(y1) && aligned16(a.y0[1]) && (!k0_alt || aligned16(k0_alt));
   for (int j = 0; j < nk; ++j) {
     if (!k[j]) return fail(XDE_EBADARG, "xde_error_ratio: null k[j]");
     a.k[j] = k[j];
     a.coef[j] = c_err[j];
     vec = vec && aligned16(k[j]);
   }
-  a.k0_alt = k[0];
+  a.k0_alt = k0_alt ? k0_alt : k[0];
   a.rtol = rtol;
   a.atol = atol;
   a.dt_host = dt_host;
@@ -243,11 +268,11 @@ int xde_error_ratio(void* out, const void* const* k, const double* c_err, int nk
   ProfScope prof(XDE_KID_ERRNORM, double(nk + 3) * double(n) * (dtype == XDE_F32 ? 4.0 : 8.0));
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
   if (dtype == XDE_F32) {
-    if (vec) XDE_LAUNCH((xde_ratio_kernel<float, true>), g, b, st, prof, a, static_cast<float*>(out), n);
-    else XDE_LAUNCH((xde_ratio_kernel<float, false>), g, b, st, prof, a, static_cast<float*>(out), n);
+    if (vec) XDE_LAUNCH((xde_ratio_kernel<float, true>), g, b, st, prof, a, static_cast<float*>(out), n, nonfinite_out);
+    else XDE_LAUNCH((xde_ratio_kernel<float, false>), g, b, st, prof, a, static_cast<float*>(out), n, nonfinite_out);
   } else {
-    if (vec) XDE_LAUNCH((xde_ratio_kernel<double, true>), g, b, st, prof, a, static_cast<double*>(out), n);
-    else XDE_LAUNCH((xde_ratio_kernel<double, false>), g, b, st, prof, a, static_cast<double*>(out), n);
+    if (vec) XDE_LAUNCH((xde_ratio_kernel<double, true>), g, b, st, prof, a, static_cast<double*>(out), n, nonfinite_out);
+    else XDE_LAUNCH((xde_ratio_kernel<double, false>), g, b, st, prof, a, static_cast<double*>(out), n, nonfinite_out);
   }
   HIP_TRY(hipGetLastError());
   return XDE_OK;

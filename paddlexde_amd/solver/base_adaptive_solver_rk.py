@@ -20,7 +20,7 @@ Pipelines (``options["pipeline"]``):
           kernels pick (y0, f0) between the two candidates from ctrl->accept on the device.  The GPU never
           waits for the host.  One extra (discarded) attempt runs after the last output.
   "graph" one whole attempted step captured into a hipGraph and replayed (launch-bound small states).
-  "auto"  (default) picks among them per solve: "sync" for a user norm callable; "lag" when an operand is larger than
+  "auto"  (default) picks among them per solve: "lag" when an operand is larger than
           AUTO_GRAPH_MAX_BYTES (the step is bandwidth-bound; also with a process_group); otherwise it starts in "sync" and,
           if the solve is still running after AUTO_GRAPH_AFTER attempts, captures the step and continues as "graph" —
           provided the capture is safe (main thread, no capture in progress, func does not differentiate with respect to
@@ -213,9 +213,6 @@ class AdaptiveRKSolver(AdaptiveSolver):
             # as framework ops on it and its scalar feeds the device controller (as a 1-segment "linf" value)
             if not callable(self.norm):
                 raise TypeError("options['norm'] must be callable")
-            if pipeline not in ("auto", "sync"):
-                raise NotImplementedError("custom norm callables run with pipeline='sync' only")
-            self.pipeline = pipeline = "sync"
             if process_group is not None:
                 raise NotImplementedError("a user norm callable cannot be all-reduced over a process_group; use _rms_norm / "
                                           "_linf_norm (or, for odeint_adjoint, the default adjoint norm or \"seminorm\")")
@@ -503,11 +500,15 @@ class AdaptiveRKSolver(AdaptiveSolver):
             be.stage_combine(y1, y0, [ks[j] for j in idx], coef, _hip.COMBINE_RK, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
         idx, coef = self._err_plan
         if self._custom_norm:
+            # err/tol materialised once (with the speculative pipeline's operand select and the non-finite count of y0 riding
+            # along), the user's callable on it as framework ops, its scalar into the controller: nothing here needs the host,
+            # so a norm callable that stays on the device runs under "lag" and "graph" too
             r = torch.empty_like(y0)
-            be.error_ratio(r, [ks[j] for j in idx], coef, y0, y1, float(self.rtol), float(self.atol), ctrl=ctrl)
             self._sums.zero_()
-            self._sums[0] = self._user_norm(r)
-            self._sums[_hip.XDE_MAX_SEG] = (~torch.isfinite(y0)).sum()
+            m = _hip.XDE_MAX_SEG
+            be.error_ratio(r, [ks[j] for j in idx], coef, y0, y1, float(self.rtol), float(self.atol), ctrl=ctrl, y0_alt=y0_alt,
+                           k0_alt=k0_alt, nonfinite_out=self._sums[m : m + 1])
+            self._sums[0:1].copy_(self._user_norm(r).reshape(1))
             be.rk_control(ctrl, self._params, None, self._sums, self._t_span_dev, self._step_t_dev, self._t_stage)
             return y1, ks
         if self._chunks is not None:

@@ -149,18 +149,27 @@ class NumpyDoubleBackend:
                                 k0_alt=k0_alt, e_pre=e_pre)
         self.rk_control(ctrl, params, ws, None, t_span_dev, step_t_dev, t_stage)
 
-    def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None):
+    def error_ratio(self, out, ks, c_err, y0, y1, rtol, atol, *, dt_host=0.0, ctrl=None, y0_alt=None, k0_alt=None, nonfinite_out=None):
         self.launches.append("ratio")
         T = _NP[y0.dtype]
-        dt = T(self._c(ctrl).dt) if ctrl is not None else T(dt_host)
-        y0v, y1v = _np(y0).reshape(-1), _np(y1).reshape(-1)
-        kk = [_np(k).reshape(-1) for k in ks]
+        sel = 0
+        if ctrl is not None:
+            c = self._c(ctrl)
+            dt = T(c.dt)
+            if y0_alt is not None and c.accept:
+                sel = 1
+        else:
+            dt = T(dt_host)
+        y0v, y1v = _np(y0_alt if sel else y0).reshape(-1), _np(y1).reshape(-1)
+        kk = [_np(k0_alt if sel else ks[0]).reshape(-1)] + [_np(k).reshape(-1) for k in ks[1:]]
         with np.errstate(all="ignore"):
             cs = [dt * T(c_) for c_ in c_err]
             e = kk[0] * cs[0]
             for j in range(1, len(kk)):
                 e = e + kk[j] * cs[j]
             _np(out).reshape(-1)[...] = e / (T(atol) + T(rtol) * np.fmax(np.abs(y0v), np.abs(y1v)))
+        if nonfinite_out is not None:
+            nonfinite_out += float(np.count_nonzero(~np.isfinite(y0v)))
 
     def scaled_norm_partial(self, a, b, y0, rtol, atol, segs, norm_kind, ws, slot):
         self.launches.append("scalednorm")

@@ -197,10 +197,13 @@ def test_linf_norm_and_options(dev):
     assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
 
 
-def test_custom_norm_callable(dev):
-    """A user-supplied norm: err/tol is materialised by xde_error_ratio and the callable runs on it."""
+@pytest.mark.parametrize("pipeline", ["sync", "lag", "graph", "auto"])
+def test_custom_norm_callable(dev, pipeline):
+    """A user-supplied norm: err/tol is materialised by xde_error_ratio and the callable runs on it as framework
+    ops; its scalar feeds the device controller without visiting the host, so every pipeline serves it (speculative enqueue:
+    the kernel takes the operand select; graph: the callable's ops are captured with the step)."""
     A, y0 = _linear(64, 32, torch.float64)
-    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64)
+    t = torch.linspace(0.0, 4.0, 4, dtype=torch.float64)
     An = A.numpy()
     ref, so = O.odeint(lambda t_, y: y @ An.T, y0.numpy(), t.numpy(), "dopri5", rtol=1e-6, atol=1e-8,
                        options={"norm": lambda x: 0.5 * np.abs(x).max() + 0.5 * np.sqrt(np.mean(x * x)), "dtype": np.float64},
@@ -212,12 +215,24 @@ def test_custom_norm_callable(dev):
         calls.append(tuple(x.shape))
         return 0.5 * x.abs().max() + 0.5 * x.pow(2).mean().sqrt()
 
-    got = odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, rtol=1e-6, atol=1e-8, options={"norm": my_norm, "dtype": torch.float64})
+    from paddlexde_amd.xde import BaseODE
+
+    y0d = y0.to(dev)
+    s = Dopri5(xde=BaseODE(lambda t_, y: y @ Ad.T, y0=y0d, t_span=t), y0=y0d, rtol=1e-6, atol=1e-8, norm=my_norm, dtype=torch.float64,
+               pipeline=pipeline)
+    got = s.integrate(t)
     assert P.parity_ok(got.cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
+    assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == (so.n_accept, so.n_reject, so.nfe)
     assert calls and all(c == (64, 32) for c in calls)
-    assert len(calls) == 3 + so.n_accept + so.n_reject  # 3 in select_initial_step + one per attempted step
-    with pytest.raises(NotImplementedError):
-        odeint(lambda t_, y: y @ Ad.T, y0.to(dev), t, solver=Dopri5, options={"norm": my_norm, "pipeline": "lag"})
+    if pipeline == "sync":
+        assert len(calls) == 3 + so.n_accept + so.n_reject  # 3 in select_initial_step + one per attempted step
+    # non-finite state: the count rides along in the same kernel and raises the reference's assertion
+    bad = y0d.clone()
+    bad[3, 5] = float("nan")
+    s2 = Dopri5(xde=BaseODE(lambda t_, y: y @ Ad.T, y0=bad, t_span=t), y0=bad, rtol=1e-6, atol=1e-8, norm=my_norm, dtype=torch.float64,
+                pipeline=pipeline, first_step=0.01)
+    with pytest.raises(AssertionError, match="non-finite"):
+        s2.integrate(t)
 
 
 @pytest.mark.parametrize("pipeline", ["sync", "lag"])

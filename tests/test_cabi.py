@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _hip.load_library()
     for sym in _declared():
         assert hasattr(lib, sym), sym
-    assert lib.xde_abi_version() == _hip.ABI_VERSION == 2
+    assert lib.xde_abi_version() == _hip.ABI_VERSION == 3
 
 
 def test_struct_layouts_match():
@@ -99,7 +99,7 @@ def test_every_entry_point_rejects_null_arguments():
                                                                     None, None, None),
         "xde_error_norm_control": lambda: lib.xde_error_norm_control(None, None, None, 1, None, None, None, C.byref(S), 0, None, None, None,
                                                                     C.byref(P), None, None, None, None, None),
-        "xde_error_ratio": lambda: lib.xde_error_ratio(None, None, None, 1, None, None, 1e-3, 1e-6, 0.0, None, 8, 0, None),
+        "xde_error_ratio": lambda: lib.xde_error_ratio(None, None, None, None, 1, None, None, None, 1e-3, 1e-6, 0.0, None, 8, 0, None, None),
         "xde_scaled_norm_partial": lambda: lib.xde_scaled_norm_partial(None, None, None, 1e-3, 1e-6, C.byref(S), 0, 0, None, 0, None),
         "xde_norm_finalize": lambda: lib.xde_norm_finalize(None, 0, None, None),
         "xde_norm_result": lambda: lib.xde_norm_result(None, None, 1, 0, 0, None, None),
