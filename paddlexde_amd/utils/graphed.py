@@ -121,6 +121,8 @@ class _AutogradTargetProbe:
     catch.  Differentiating w.r.t. fresh detached aliases (``p.detach().requires_grad_()`` + ``torch.func.functional_call``,
     what ``odeint_adjoint(graph_func=True)`` does) is safe: they have no accumulator."""
 
+    _LOCK = threading.RLock()  # one probe at a time: it swaps module attributes of torch.autograd for its duration
+
     def __init__(self):
         self.hit = None
 
@@ -135,6 +137,7 @@ class _AutogradTargetProbe:
                 return
 
     def __enter__(self):
+        self._LOCK.acquire()
         ag = torch.autograd
         self._grad, self._backward = ag.grad, ag.backward
         probe = self
@@ -152,6 +155,7 @@ class _AutogradTargetProbe:
 
     def __exit__(self, *exc):
         torch.autograd.grad, torch.autograd.backward = self._grad, self._backward
+        self._LOCK.release()
         return False
 
 

@@ -50,6 +50,16 @@ class PeerExchange:
             self._peers = (C.c_void_p * self.world)(*ptrs)
         dist.barrier(group=group)  # every mailbox is mapped everywhere before the first store into it
 
+    def __del__(self):  # best effort for a forgotten close(): release what is ours, touch nothing a peer may still use
+        try:
+            if getattr(self, "_local", None) is not None:
+                for q in self._opened:
+                    self.lib.xde_p2p_close(q)
+                self.lib.xde_p2p_free(self._local)
+                self._local = None
+        except Exception:
+            pass
+
     def _check(self, rc, who):
         if rc != _hip.XDE_OK:
             raise _hip.XdeError("{} failed (status {}): {}".format(who, rc, self.lib.xde_last_error().decode()))
