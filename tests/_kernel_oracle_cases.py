@@ -100,6 +100,7 @@ def test_one_attempt_taken_apart_vs_oracle(dev, name, dtype):
     assert c.dt == pytest.approx(float(want_dt), rel=2.4e-7 if dtype == np.float32 else 4.5e-16), (name, c.dt, float(want_dt))
 
     # ---- dense output at a time inside the step                                     :286-292; ode_utils.py:28-77
+    assert c.accept  # (every case is built to accept, so that the dense-output part below always runs)
     if c.accept:
         assert (c.out_begin, c.out_end) == (1, 2)
         sol = torch.zeros((3,) + tuple(y0d.shape), dtype=tdt, device=device)
