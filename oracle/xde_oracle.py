@@ -805,11 +805,13 @@ def odeint_adjoint(func, vjp, params, y0, t_span, solver, *, rtol=1e-7, atol=1e-
             vjp_params = [np.zeros_like(p) if v is None else v for p, v in zip(params, vjp_params)]
             return (vjp_t, func_eval, vjp_y, *vjp_params)
 
+        backward.traces = []  # oracle-only instrumentation: the step records of every interval's solve, in the order run
         for i in range(len(t_span) - 1, 0, -1):  # :134-159
             ts = t_span[i - 1 : i + 1][::-1]
             if adjoint_solver in ADAPTIVE:
-                aug = odeint(augmented_dynamics, tuple(aug_state), ts, adjoint_solver,
-                             rtol=adjoint_rtol, atol=adjoint_atol, options=adjoint_options)
+                aug, s_ = odeint(augmented_dynamics, tuple(aug_state), ts, adjoint_solver,
+                                 rtol=adjoint_rtol, atol=adjoint_atol, options=adjoint_options, return_solver=True)
+                backward.traces.append(list(s_.trace))
             else:
                 fopts = dict(adjoint_options)
                 fopts["norm"] = None

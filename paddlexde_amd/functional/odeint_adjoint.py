@@ -253,7 +253,9 @@ class OdeintAdjointMethod(torch.autograd.Function):
                     "adjoint_options['graph_func'] with a process_group needs the \"seminorm\" adjoint norm and no time "
                     "gradients (the captured dynamics cannot hold the per-evaluation all-reduce)")
             augmented_dynamics = _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg, reduce_params)
-            solver_options = {k: v for k, v in adjoint_options.items() if k not in ("graph_func", "_graphed")}
+            solver_options = {k: v for k, v in adjoint_options.items() if k not in ("graph_func", "_graphed", "_replay_intervals")}
+            # parity harness: one prescribed (dt, accept) table per interval's solve, in the order the intervals are run
+            replay_intervals = adjoint_options.get("_replay_intervals")
             if adjoint_options.get("_graphed") is not None:
                 # the captured FLAT dynamics (same segment layout) replaces the unpack -> dynamics -> pack wrapper:
                 # 2 input copies + 1 replay + 1 clone per evaluation
@@ -276,6 +278,9 @@ class OdeintAdjointMethod(torch.autograd.Function):
                         (dLd_cur_t,) = _group_sum([dLd_cur_t], pg)
                     flat[s_t] -= dLd_cur_t.to(adt)  # aug_state[0] = aug_state[0] - dLd_cur_t
                     grad_t_span[i] = dLd_cur_t
+
+                if replay_intervals is not None:
+                    solver_options["_replay"] = replay_intervals[T - 1 - i]
 
                 # Run the augmented system backwards in time.
                 sol = _odeint_packed(

@@ -141,10 +141,10 @@ def rel_err(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300))
 
 
-def ulp_atol(ref, k):
+def ulp_atol(ref, k, floor=1e-7):
     """k fp32 ulps at the scale of `ref` (its largest magnitude).  north_star's absolute tolerance, 1e-7, is BELOW one fp32 ulp
     of any quantity larger than 1 (ulp(1) = 1.19e-7, ulp(4) = 4.8e-7): where two fp32 implementations differ by one rounding of
     an O(1) intermediate (a GEMM summed in another order), elements of the state that pass through zero cannot agree to 1e-7.
     Tests whose func is not bit-identical on both sides state the bar's absolute part in ulps of the state's scale instead;
     the relative part stays 1e-5."""
-    return max(1e-7, k * float(np.spacing(np.float32(np.abs(np.asarray(ref)).max()))))
+    return max(floor, k * float(np.spacing(np.float32(np.abs(np.asarray(ref)).max()))))
