@@ -133,6 +133,7 @@ def _make_functional_dynamics(func, adjoint_params, t_requires_grad):
 
 _GRAPH_CACHE = weakref.WeakKeyDictionary()  # func module -> {signature: GraphedFunc}; captures are reused across calls
 
+MAX_GRAPHS_PER_MODULE = 8  # captured dynamics kept per module (each holds static buffers of the state's size)
 AUTO_GRAPH_FUNC_MAX_BYTES = 8 << 20  # "auto": states above this are bandwidth-bound, the launches are not the cost
 AUTO_GRAPH_FUNC_MIN_INTERVALS = 4  # "auto": output intervals needed to amortise a first capture
 
@@ -424,6 +425,8 @@ def odeint_adjoint(
                 return k[None, :] if fixed else k
 
             graphed = GraphedFunc(flat_dynamics, clone_outputs=True)
+            while len(cache) >= MAX_GRAPHS_PER_MODULE:  # a loop over many batch shapes must not pile up captures (oldest first)
+                cache.pop(next(iter(cache)))
             cache[key] = graphed
         flat_ex = _pack(aug_example, segs, total, adt, y0.device)
         flat_ex = flat_ex[None, :] if fixed else flat_ex
