@@ -256,7 +256,10 @@ class AdaptiveRKSolver(AdaptiveSolver):
         """``xde.move`` -> func(t, y); returns a kernel-ready tensor that aliases nothing we still need (``live``: the
         storage pointers of the tensors still in use)."""
         self.nfe += 1
-        with torch.no_grad():  # the adaptive path is forward-only; gradients come from odeint_adjoint
+        if torch.is_grad_enabled():
+            with torch.no_grad():  # the adaptive path is forward-only; gradients come from odeint_adjoint
+                f = self.move(t, None, y)
+        else:
             f = self.move(t, None, y)
         f = as_operand(f, like=y)
         sp = storage_ptr(f)
@@ -664,14 +667,15 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._n_attempts = 0
             self._last = None
             self._graph = None
-        if self.pipeline == "auto":
-            c = self._advance_auto(max_attempts)
-        elif self.pipeline == "lag":
-            c = self._advance_lag(max_attempts)
-        elif self.pipeline == "graph":
-            c = self._advance_graph(max_attempts)
-        else:
-            c = self._advance_sync(max_attempts)
+        with torch.no_grad():  # once per advance, not once per func evaluation
+            if self.pipeline == "auto":
+                c = self._advance_auto(max_attempts)
+            elif self.pipeline == "lag":
+                c = self._advance_lag(max_attempts)
+            elif self.pipeline == "graph":
+                c = self._advance_graph(max_attempts)
+            else:
+                c = self._advance_sync(max_attempts)
         self._finish(c, self._base)
         return c
 
