@@ -3,6 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts the N ranks itself (a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`), relays rank 0's
+line and exits non-zero if a rank fails, if the box has fewer than N GPUs (unless XDE_BENCH_REHEARSAL=1: all ranks on cuda:0 over
+gloo) or if the line does not say n_gpus == N.  Under a launcher (the driver's torch.distributed.run) it is one rank of the job.
+
 A "step" is ONE attempted Dopri5 step over the whole batch: 6 stage combines (xde_stage_combine), 6 calls
 of the user's func (a framework call: torch matmul ``y @ A^T``), one fused error-norm launch and the device
 controller — exactly what ``paddlexde_amd.odeint(..., solver=Dopri5)`` runs per attempt.
@@ -12,7 +17,9 @@ Workload (N=1): BASELINE.json configs[1] — linear ODE dy/dt = A y, A = U - U^T
 N>1: BASELINE.json configs[3] — the same ODE at GLOBAL batch 524288 x dim 64, rows split evenly over the N ranks
 (rank r owns rows [r*B/N, (r+1)*B/N): 65536 x 64 per GPU at N=8); the total work is the same for every N > 1
 ("scaling": "strong"); the only collective is the all-reduce of the error norm's partial sums (32 doubles) per
-attempted step over RCCL.  `--batch` (rows PER GPU) / `--dim` override either default (then "weak").
+attempted step over RCCL (`rccl_ranks` = size of that nccl group).  Because the driver's `--gpus 1` line is config 2 — a different
+amount of work — the N > 1 line carries `n1_same_workload`: rank 0's own single-GPU run of the SAME global 524288 x 64 problem,
+taken after the timed region, so a strong-scaling efficiency can be computed from one line.  `--batch` (rows PER GPU) / `--dim` override either default (then "weak").
 `--workload rk4`: the bandwidth-bound fixed-step line (reference RK4 variant, 65536 x 128, 18 N 4 B per step).
 
 value = states/sec = (global batch * dim) / (wall time per attempted step), whole job.
@@ -361,6 +368,82 @@ def rk4_workload(args):
     emit(out)
 
 
+def time_unsharded(B, D, dtype, pipeline, device, steps, warmup):
+    """One rank, no process group: attempted Dopri5 steps of the linear ODE at batch B x dim D.  Used by the N > 1 line for
+    `n1_same_workload` (config 4's GLOBAL problem on one GPU — the N=1 point of the strong-scaling curve)."""
+    from paddlexde_amd import Dopri5
+    from paddlexde_amd.utils import _rms_norm
+    from paddlexde_amd.xde import BaseODE
+
+    A, y0 = make_problem(B, D, 0, device)
+    if dtype == "f64":
+        A, y0 = A.double(), y0.double()
+    AT = A.T.contiguous()
+    func = lambda t, y: y @ AT  # noqa: E731
+    xde = BaseODE(func, y0=y0, t_span=torch.tensor([0.0, 1.0e9]))
+    s = Dopri5(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=pipeline)
+    s.y0 = y0
+    s._before_integrate(np.asarray([0.0, 1.0e9], dtype=np.float32))
+    s.advance(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.advance(steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": B * D * steps / el, "unit": "states/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
+            "global_batch": B, "dim": D, "n_gpus": 1}
+
+
+def _free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) invoked WITHOUT a launcher (the reference's own recipe is one command too,
+    example/D3STN/README.md:53-59): start one rank per GPU with `python -m torch.distributed.run` as a CHILD process, relay rank 0's
+    JSON line, return non-zero if any rank fails or the line does not say `n_gpus == N`.  The parent never initialises the GPU
+    and never re-execs itself.  On a box with fewer than N GPUs this refuses, unless XDE_BENCH_REHEARSAL=1 (all ranks share
+    cuda:0, gloo carries the collectives: a functional rehearsal, not a scaling number)."""
+    import subprocess
+
+    n = args.gpus
+    rehearsal = os.environ.get("XDE_BENCH_REHEARSAL", "0") == "1"
+    have = torch.cuda.device_count()  # (does not initialise the GPU)
+    if have < n and not rehearsal:
+        print("bench.py: --gpus {} but this box has {} GPU(s); refusing to print a mislabelled line "
+              "(XDE_BENCH_REHEARSAL=1 rehearses the N-rank invocation on one GPU over gloo)".format(n, have), file=sys.stderr)
+        return 2
+    if rehearsal and n > 6:
+        print("bench.py: a rehearsal keeps to 6 ranks on one card", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0:
+        print("bench.py: the {}-rank job exited with {}".format(n, r.returncode), file=sys.stderr)
+        return r.returncode or 1
+    if len(lines) != 1:
+        print("bench.py: expected ONE JSON line from rank 0, got {}".format(len(lines)), file=sys.stderr)
+        return 3
+    try:
+        got = json.loads(lines[0]).get("n_gpus")
+    except Exception:
+        got = None
+    if got != n:
+        print("bench.py: the line says n_gpus={} but --gpus {} was asked".format(got, n), file=sys.stderr)
+        return 4
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -381,6 +464,7 @@ def main():
                     help="c1: configs[0], the demo's 1000-point spiral with RK4 (plumbing); c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
                          "batch 8192 (latency-bound, reports ms per fwd+bwd and per attempted step); c5: stiff Van der Pol "
                          "mu=1000 batch 4096 (step-rejection stress, reports accepted/rejected and us per step)")
+    ap.add_argument("--no-n1", action="store_true", help="N>1: skip rank 0's extra single-GPU run of the same global problem (n1_same_workload)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-tunable-op", action="store_true",
                     help="leave PyTorch's TunableOp off (by default the framework tunes the GEMMs inside the user's func during "
@@ -389,6 +473,12 @@ def main():
                     help="time every p-th launch of each kernel inside the timed region (5 is coprime with the 6 "
                          "combines per step, so all stages are sampled evenly)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: this process becomes the launcher.  Nothing here has touched the
+        # GPU (importing torch and counting devices do not initialise HIP), so starting children is safe.
+        raise SystemExit(self_launch(args))
     # stdout carries ONE JSON line: whatever libraries print there meanwhile (RCCL's version banner, tuner notes) goes to
     # stderr; the original stdout is restored just before the line is printed
     sys.stdout.flush()
@@ -405,16 +495,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus {} but WORLD_SIZE={}: launch one rank per GPU (or run `python bench.py --gpus N` with no "
+                         "launcher, which starts the ranks itself)".format(args.gpus, world))
     # rehearsal on a one-GPU box (XDE_BENCH_REHEARSAL=1): all ranks share cuda:0 and gloo carries the collectives
     # (RCCL refuses several ranks on one device); the driver's real runs use one GPU per rank over nccl (= RCCL)
     rehearsal = os.environ.get("XDE_BENCH_REHEARSAL", "0") == "1"
     if rehearsal:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("--gpus {} but this box has {} GPU(s) (XDE_BENCH_REHEARSAL=1 rehearses on one GPU over gloo)".format(
+            world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    rccl_ranks = 0
     # XDE_BENCH_FORCE_DIST=1: take the sharded code path (finalize -> RCCL all-reduce -> controller) even with one
     # rank, to measure its per-step overhead on a one-GPU box
     force_dist = os.environ.get("XDE_BENCH_FORCE_DIST", "0") == "1"
@@ -430,6 +525,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+        rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
 
     from paddlexde_amd import Dopri5, _hip
     from paddlexde_amd.utils import _rms_norm
@@ -527,6 +623,7 @@ def main():
             "parallelism": "batch-sharded x{} (error-norm {} only)".format(world, "peer-to-peer exchange" if exchange is not None else "all-reduce")
                            if world > 1 else "single GPU",
         },
+        "rccl_ranks": rccl_ranks,  # ranks of the nccl (= RCCL) group the norm sums were all-reduced over; 0 = no RCCL group (one GPU, or a gloo rehearsal)
         "solver": {"n_steps": int(c.n_steps), "n_accept": int(c.n_accept), "n_reject": int(c.n_reject), "t": float(c.t1),
                    "dt": float(c.dt), "settle_steps": settle},
     }
@@ -576,6 +673,18 @@ def main():
         out["cpu_baseline"], eager = cpu_baseline(B, D)
         if eager is not None:
             out["cpu_baseline_eager"] = eager
+
+    if world > 1 and scaling == "strong" and not args.no_n1 and rank == 0:
+        # the same GLOBAL problem on this rank alone, so that a strong-scaling efficiency can be computed from this one line
+        # (the driver's own `--gpus 1` line is config 2, a different amount of work); the other ranks wait at the barrier below
+        del solver
+        torch.cuda.empty_cache()
+        try:
+            out["n1_same_workload"] = time_unsharded(GLOBAL_C4, DIM_C4, args.dtype, args.pipeline, device, min(args.steps, 60), min(args.warmup, 10))
+            if rehearsal:
+                out["n1_same_workload"]["note"] = "rehearsal: measured while the other ranks idle on the SAME GPU"
+        except Exception as e:  # never lose the N-rank line to the extra measurement
+            out["n1_same_workload"] = {"error": "{}: {}".format(type(e).__name__, e)}
 
     if exchange is not None:
         exchange.close()

@@ -56,3 +56,43 @@ def test_bench_side_workloads_run():
     for controller in ("I", "PI"):
         r64 = j["results"][controller + "/float64"]
         assert r64["n_reject"] > 0 and r64["finite"]
+
+
+def _launch(env_extra, *args):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher starts two ranks itself (rehearsed on this one-GPU box: both
+    ranks on cuda:0, gloo) and prints ONE line that says n_gpus == 2 = config 4 split over two ranks, with the N=1 datum of the
+    same global workload riding along."""
+    r = _launch({"XDE_BENCH_REHEARSAL": "1"}, "--gpus", "2", "--steps", "5", "--warmup", "2")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["scaling"] == "strong"
+    assert j["config"]["global_batch"] == 524288 and j["config"]["rows_per_gpu"] == 262144 and j["config"]["dim"] == 64
+    assert j["rccl_ranks"] == 0  # gloo rehearsal: no RCCL group was formed, and the line says so
+    n1 = j["n1_same_workload"]
+    assert n1["n_gpus"] == 1 and n1["global_batch"] == 524288 and n1["dim"] == 64 and n1["value"] > 0
+
+
+def test_bench_gpus_2_refuses_on_a_one_gpu_box():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    r = _launch({"XDE_BENCH_REHEARSAL": "0"}, "--gpus", "2", "--steps", "5", "--warmup", "2")
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_rccl_group_of_one_reports_its_ranks():
+    r = _launch({"XDE_BENCH_FORCE_DIST": "1"}, "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "4096", "--pipeline", "lag", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["rccl_ranks"] == 1 and j["n_gpus"] == 1

@@ -12,3 +12,24 @@ from ._replay_cases import *  # noqa: F401,F403
 @pytest.fixture
 def dev(cpu_double):
     return "cpu"
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_touching_a_gpu():
+    """`python bench.py --gpus N` with no launcher starts its own ranks; on a box with fewer GPUs it must refuse (exit code != 0,
+    no JSON line) rather than print an N=1 number — and a launcher's WORLD_SIZE that contradicts --gpus is refused too."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "XDE_BENCH_REHEARSAL")}
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3"], capture_output=True, text=True,
+                           timeout=120, env=env)
+        assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout
+    env["WORLD_SIZE"], env["RANK"] = "2", "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "{" not in r.stdout
