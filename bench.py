@@ -460,7 +460,7 @@ def main():
                          "peer-to-peer mailbox exchange (utils.PeerExchange; rehearsed on one GPU only so far)")
     ap.add_argument("--graph-func", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="c3: replay the augmented dynamics from a captured HIP graph (auto = the library default, which captures here)")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "rk4"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "rk4", "c4-shard", "c4-n1", "dense", "dde"],
                     help="c1: configs[0], the demo's 1000-point spiral with RK4 (plumbing); c2: BASELINE.json configs[1] (headline, default); c3: spiral neural-ODE odeint_adjoint backward, "
                          "batch 8192 (latency-bound, reports ms per fwd+bwd and per attempted step); c5: stiff Van der Pol "
                          "mu=1000 batch 4096 (step-rejection stress, reports accepted/rejected and us per step)")
@@ -487,8 +487,20 @@ def main():
     os.dup2(2, 1)
     args.tunable_op = enable_tunable_op(not args.no_tunable_op)
 
+    c4_label = None
+    if args.workload in ("c4-shard", "c4-n1"):
+        # config 4's sizes on ONE GPU: "c4-shard" = 65536 x 64, one rank's rows at N=8 (16 MiB operands, the whole
+        # working set Infinity-Cache resident); "c4-n1" = the GLOBAL 524288 x 64 on one rank, the N=1 point of the strong-scaling curve
+        args.batch, args.dim = (65536 if args.workload == "c4-shard" else 524288), 64
+        c4_label = ("BASELINE.json configs[3], one rank's shard at N=8 on one GPU" if args.workload == "c4-shard"
+                    else "BASELINE.json configs[3], the whole problem on one GPU (N=1 point of the strong-scaling curve)")
+        args.workload = "c2"
     if args.workload == "rk4":
         return rk4_workload(args)
+    if args.workload == "dense":
+        return dense_workload(args)
+    if args.workload == "dde":
+        return dde_workload(args)
     if args.workload != "c2":
         return side_workload(args)
 
@@ -541,7 +553,7 @@ def main():
     else:
         B = 65536 if args.batch is None else args.batch
         D = (128 if world == 1 else DIM_C4) if args.dim is None else args.dim
-        scaling, cfg_name = "weak", ("BASELINE.json configs[1]" if (B, D) == (65536, 128) else "custom size")
+        scaling, cfg_name = "weak", ("BASELINE.json configs[1]" if (B, D) == (65536, 128) else (c4_label or "custom size"))
     A, y0 = make_problem(B, D, rank, device)
     if args.dtype == "f64":
         A, y0 = A.double(), y0.double()
