@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XDE_ABI_VERSION 3
+#define XDE_ABI_VERSION 4
 
 #define XDE_OK 0
 #define XDE_EBADARG 1
@@ -97,8 +97,14 @@ typedef struct xde_ctrl {
 #define XDE_MIRROR_SLOTS 16 /* host mirror ring: slot[seq % XDE_MIRROR_SLOTS] (a replayed hipGraph may hold several controller launches) */
 #define XDE_ETIMEOUT 3
 
-/* Controller parameters (host struct, passed by pointer, copied at call time). */
+/* Controller parameters (host struct, passed by pointer, copied at call time).
+ * The first two words are the binding's statement of the layout it was written against: every entry point that takes
+ * this struct returns XDE_EBADARG — before reading anything else, without launching — unless struct_size ==
+ * sizeof(xde_ctrl_params_t) and abi_version == XDE_ABI_VERSION.  (A hand-written mirror that predates a field would
+ * otherwise make the library read past its end: exactly how a stale `replay` pointer once aborted the process.) */
 typedef struct xde_ctrl_params {
+  uint32_t struct_size;      /* = sizeof(xde_ctrl_params_t) as the CALLER sees it */
+  uint32_t abi_version;      /* = XDE_ABI_VERSION the caller was written against */
   double rtol, atol;         /* already rounded to the time dtype by the caller */
   double min_step, max_step; /* base_adaptive_solver_rk.py:36-37 */
   double safety, ifactor, dfactor; /* :41-43 */
@@ -126,6 +132,7 @@ typedef struct xde_ctrl_params {
 
 /* Description of one state operand list + segment layout, shared by the norm kernels. */
 typedef struct xde_segments {
+  uint32_t struct_size; /* = sizeof(xde_segments_t) as the caller sees it; anything else is XDE_EBADARG */
   int32_t n_seg;
   int64_t seg_start[XDE_MAX_SEG]; /* element offset of each segment in the flat state */
   int64_t seg_len[XDE_MAX_SEG];   /* LOCAL element count of each segment */
@@ -136,6 +143,7 @@ int xde_abi_version(void);
 int64_t xde_sizeof_ctrl(void);
 /* sizeof(xde_ctrl_params_t): a binding that mirrors the struct by hand (ctypes, cgo) checks its layout against this */
 int64_t xde_sizeof_ctrl_params(void);
+int64_t xde_sizeof_segments(void);
 /* bytes of scratch a norm launch needs (block partials + finalised per-segment sums) */
 int64_t xde_workspace_bytes(void);
 

@@ -14,7 +14,7 @@ import torch
 
 XDE_OK, XDE_EBADARG, XDE_EHIP, XDE_ETIMEOUT = 0, 1, 2, 3
 XDE_MIRROR_SLOTS = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
 XDE_P2P_MAX_RANKS, XDE_P2P_HANDLE_BYTES = 16, 64
@@ -31,6 +31,7 @@ SYMBOLS = (
     "xde_abi_version",
     "xde_sizeof_ctrl",
     "xde_sizeof_ctrl_params",
+    "xde_sizeof_segments",
     "xde_workspace_bytes",
     "xde_stage_combine",
     "xde_error_norm_partial",
@@ -102,6 +103,8 @@ class XdeCtrlParams(C.Structure):
     """xde_ctrl_params_t"""
 
     _fields_ = [
+        ("struct_size", C.c_uint32),  # the binding's statement of the layout: checked by the library before anything else is read
+        ("abi_version", C.c_uint32),
         ("rtol", C.c_double),
         ("atol", C.c_double),
         ("min_step", C.c_double),
@@ -126,15 +129,25 @@ class XdeCtrlParams(C.Structure):
         ("n_replay", C.c_int64),
     ]
 
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(type(self))
+        self.abi_version = ABI_VERSION
+
 
 class XdeSegments(C.Structure):
     """xde_segments_t"""
 
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("n_seg", C.c_int32),
         ("seg_start", C.c_int64 * XDE_MAX_SEG),
         ("seg_len", C.c_int64 * XDE_MAX_SEG),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(type(self))
 
 
 class XdeError(RuntimeError):
@@ -177,6 +190,7 @@ def load_library():
         lib.xde_abi_version.restype = i32
         lib.xde_sizeof_ctrl.restype = i64
         lib.xde_sizeof_ctrl_params.restype = i64
+        lib.xde_sizeof_segments.restype = i64
         lib.xde_workspace_bytes.restype = i64
         lib.xde_stage_combine.restype = i32
         lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, C.c_uint32, vp]
@@ -246,6 +260,8 @@ def load_library():
             raise XdeError("xde_ctrl_t layout mismatch between header and ctypes mirror")
         if lib.xde_sizeof_ctrl_params() != C.sizeof(XdeCtrlParams):
             raise XdeError("xde_ctrl_params_t layout mismatch between header and ctypes mirror")
+        if lib.xde_sizeof_segments() != C.sizeof(XdeSegments):
+            raise XdeError("xde_segments_t layout mismatch between header and ctypes mirror")
         _lib = lib
     return _lib
 

@@ -319,8 +319,20 @@ struct ProfScope {
   } while (0)
 
 
+// The caller's statement of xde_segments_t's layout is checked before any other field is read (a stale hand-written mirror
+// must get XDE_EBADARG, not a read past its end).
+inline int check_segments(const xde_segments_t* segs) {
+  if (!segs) return fail(XDE_EBADARG, "segments: null");
+  if (segs->struct_size != sizeof(xde_segments_t))
+    return fail(XDE_EBADARG, "segments: xde_segments_t layout mismatch: the caller says struct_size=" + std::to_string(segs->struct_size) +
+                                 ", this library has sizeof=" + std::to_string(sizeof(xde_segments_t)) +
+                                 " (rebuild the binding against include/xde_hip.h)");
+  if (segs->n_seg < 1 || segs->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, "segments: n_seg out of range");
+  return XDE_OK;
+}
+
 inline int build_segmap(const xde_segments_t* segs, int width, bool vec, SegMap* m, int* nblocks_out, int cap_override = 0) {
-  if (!segs || segs->n_seg < 1 || segs->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, "segments: n_seg out of range");
+  if (int rc0 = check_segments(segs)) return rc0;
   const int cap = cap_override > 0 ? cap_override : norm_grid_cap();
   m->n_seg = segs->n_seg;
   int64_t total = 0;

@@ -268,7 +268,8 @@ int xde_error_norm_control(const void* const* k, const void* k0_alt, const doubl
   int rc = check_params(params, "xde_error_norm_control");
   if (rc != XDE_OK) return rc;
   if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_error_norm_control: n_step_t > 0 without step_t_dev");
-  if (!segs || segs->n_seg != params->n_seg) return fail(XDE_EBADARG, "xde_error_norm_control: segments do not match params->n_seg");
+  if (int rc0 = check_segments(segs)) return rc0;
+  if (segs->n_seg != params->n_seg) return fail(XDE_EBADARG, "xde_error_norm_control: segments do not match params->n_seg");
   ErrArgs a;
   bool vec = false;
   int nblocks = 0;

@@ -307,6 +307,12 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
 
 inline int check_params(const xde_ctrl_params_t* p, const char* who) {
   if (!p) return fail(XDE_EBADARG, std::string(who) + ": null params");
+  // the caller's statement of the layout comes first: nothing past these two words is read from a struct that does not match
+  if (p->struct_size != sizeof(xde_ctrl_params_t) || p->abi_version != XDE_ABI_VERSION)
+    return fail(XDE_EBADARG, std::string(who) + ": xde_ctrl_params_t layout mismatch: the caller says struct_size=" + std::to_string(p->struct_size) +
+                                 ", abi_version=" + std::to_string(p->abi_version) + "; this library has sizeof=" +
+                                 std::to_string(sizeof(xde_ctrl_params_t)) + ", XDE_ABI_VERSION=" + std::to_string(XDE_ABI_VERSION) +
+                                 " (rebuild the binding against include/xde_hip.h)");
   if (p->n_stage < 1 || p->n_stage > XDE_MAX_STAGE) return fail(XDE_EBADARG, std::string(who) + ": n_stage out of range");
   if (p->n_seg < 1 || p->n_seg > XDE_MAX_SEG) return fail(XDE_EBADARG, std::string(who) + ": n_seg out of range");
   if (p->direction != 1 && p->direction != -1) return fail(XDE_EBADARG, std::string(who) + ": direction must be +-1");

@@ -171,6 +171,7 @@ inline int setup_err_args(const char* who, const void* const* k, const void* k0_
                           bool* vec_out, int* nblocks_out, double* bytes_out, int cap_override = 0) {
   const std::string w(who);
   if (!k || !c_err || !y0 || !y1 || !ws || !segs) return fail(XDE_EBADARG, w + ": null pointer");
+  if (int rc0 = check_segments(segs)) return rc0;
   if (e_pre && nk != 1) return fail(XDE_EBADARG, w + ": e_pre takes exactly one remaining operand");
   if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, w + ": nk out of range");
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, w + ": bad dtype");

@@ -281,6 +281,7 @@ int xde_error_ratio(void* out, const void* const* k, const void* k0_alt, const d
 int xde_scaled_norm_partial(const void* av, const void* bv, const void* y0, double rtol, double atol,
                             const xde_segments_t* segs, int norm_kind, int dtype, void* ws, int slot, void* stream) {
   if (!av || !y0 || !ws || !segs) return fail(XDE_EBADARG, "xde_scaled_norm_partial: null pointer");
+  if (int rc0 = check_segments(segs)) return rc0;
   if (slot < 0 || slot >= kSlots) return fail(XDE_EBADARG, "xde_scaled_norm_partial: bad slot");
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_scaled_norm_partial: bad dtype");
   if (norm_kind != XDE_NORM_RMS && norm_kind != XDE_NORM_LINF) return fail(XDE_EBADARG, "xde_scaled_norm_partial: bad norm");

@@ -127,6 +127,7 @@ const char* xde_last_error(void) { return g_last_error.c_str(); }
 int xde_abi_version(void) { return XDE_ABI_VERSION; }
 int64_t xde_sizeof_ctrl(void) { return int64_t(sizeof(xde_ctrl_t)); }
 int64_t xde_sizeof_ctrl_params(void) { return int64_t(sizeof(xde_ctrl_params_t)); }
+int64_t xde_sizeof_segments(void) { return int64_t(sizeof(xde_segments_t)); }
 int64_t xde_workspace_bytes(void) { return int64_t(sizeof(NormSlot)) * kSlots; }
 
 int xde_prof_enable(int on) {

@@ -26,13 +26,15 @@ def test_library_loads_and_exports_every_symbol():
     lib = _hip.load_library()
     for sym in _declared():
         assert hasattr(lib, sym), sym
-    assert lib.xde_abi_version() == _hip.ABI_VERSION == 3
+    assert lib.xde_abi_version() == _hip.ABI_VERSION == 4
 
 
 def test_struct_layouts_match():
     lib = _hip.load_library()
     assert lib.xde_sizeof_ctrl() == C.sizeof(_hip.XdeCtrl) == 288
     assert lib.xde_sizeof_ctrl_params() == C.sizeof(_hip.XdeCtrlParams)
+    assert lib.xde_sizeof_segments() == C.sizeof(_hip.XdeSegments)
+    assert _hip.XdeCtrlParams.struct_size.offset == 0 and _hip.XdeCtrlParams.abi_version.offset == 4 and _hip.XdeSegments.struct_size.offset == 0
     assert _hip.XdeCtrl.seq.offset % 8 == 0
     assert lib.xde_workspace_bytes() > 0
     # constants mirrored from the header
@@ -128,7 +130,80 @@ def test_every_entry_point_rejects_null_arguments():
         msg = lib.xde_last_error().decode()
         assert rc == _hip.XDE_EBADARG, (name, rc, msg)
         assert msg and (name in msg or "segments" in msg), (name, msg)
-    covered = set(calls) | {"xde_last_error", "xde_abi_version", "xde_sizeof_ctrl", "xde_sizeof_ctrl_params", "xde_workspace_bytes", "xde_host_free", "xde_prof_enable",
+    covered = set(calls) | {"xde_last_error", "xde_abi_version", "xde_sizeof_ctrl", "xde_sizeof_ctrl_params", "xde_sizeof_segments", "xde_workspace_bytes", "xde_host_free", "xde_prof_enable",
                                 "xde_p2p_mailbox_bytes", "xde_p2p_free", "xde_p2p_close"}
     assert covered == set(_hip.SYMBOLS), set(_hip.SYMBOLS) ^ covered
     assert lib.xde_host_free(None) == _hip.XDE_OK  # freeing nothing is fine
+
+
+def _old_params_mirror(short_by):
+    """A binding's hand-written mirror of xde_ctrl_params_t from BEFORE a field was added: `short_by` bytes shorter than the
+    library's struct (round 2's abort: a mirror without replay/n_replay, 16 bytes short, gpurun_out/r02_gpu1.log)."""
+    real = C.sizeof(_hip.XdeCtrlParams)
+    assert short_by % 8 == 0 and 0 < short_by < real
+
+    class Old(C.Structure):
+        _fields_ = [("words", C.c_double * ((real - short_by) // 8))]
+
+    return Old
+
+
+@pytest.mark.parametrize("stale", ["r02 layout (no size word, 16 bytes short)", "size word says 16 bytes short", "right size, old abi_version", "zeroed"])
+def test_a_stale_params_mirror_gets_ebadarg_not_a_read_past_its_end(stale):
+    """the library, not only the caller, guards the struct the round-2 abort came through.  Every entry point that
+    takes xde_ctrl_params_t checks struct_size / abi_version — the first 8 bytes — before it reads anything else: a stale mirror
+    yields XDE_EBADARG with a message that names the mismatch; nothing is launched (this runs on a box without a GPU)."""
+    lib = _hip.load_library()
+    real = C.sizeof(_hip.XdeCtrlParams)
+    if stale.startswith("r02"):
+        Old = _old_params_mirror(16 + 8)  # round 2's struct had neither the size word nor replay/n_replay
+        P = Old()
+        P.words[0], P.words[1] = 1e-5, 1e-7  # rtol, atol sat where struct_size/abi_version are now
+    elif stale.startswith("size word"):
+        P = _hip.XdeCtrlParams()
+        P.struct_size = real - 16
+    elif stale.startswith("right size"):
+        P = _hip.XdeCtrlParams()
+        P.abi_version = _hip.ABI_VERSION - 1
+    else:
+        P = _hip.XdeCtrlParams()
+        C.memset(C.byref(P), 0, real)
+    if isinstance(P, _hip.XdeCtrlParams):  # otherwise plausible, so that only the layout words can be what is refused
+        P.n_stage, P.n_seg, P.direction, P.order = 6, 1, 1, 5.0
+    dummy = C.c_void_p(0x1000)  # non-null "device pointers": validation must stop before anything dereferences or launches
+    S = _hip.XdeSegments()
+    S.n_seg = 1
+    ref = C.cast(C.byref(P), C.POINTER(_hip.XdeCtrlParams))
+    kk = (C.c_void_p * 1)(0x1000)
+    ce = (C.c_double * 1)(1.0)
+    calls = {
+        "xde_ctrl_init": lambda: lib.xde_ctrl_init(dummy, ref, 0.0, 0.1, 2, dummy, None, dummy, 0, None, None),
+        "xde_rk_control": lambda: lib.xde_rk_control(dummy, ref, dummy, None, dummy, None, dummy, None, None),
+        "xde_ctrl_retarget": lambda: lib.xde_ctrl_retarget(dummy, ref, dummy, 1, None, None),
+        "xde_initial_step": lambda: lib.xde_initial_step(1, dummy, dummy, ref, 0.0, None, 0, dummy, None),
+        "xde_error_norm_control": lambda: lib.xde_error_norm_control(kk, None, ce, 1, dummy, None, dummy, C.byref(S), 0, dummy, None, dummy,
+                                                                    ref, dummy, None, dummy, None, None),
+    }
+    for name, call in calls.items():
+        assert call() == _hip.XDE_EBADARG, name
+        msg = lib.xde_last_error().decode()
+        assert name in msg and "layout mismatch" in msg and "sizeof={}".format(real) in msg, msg
+
+
+def test_a_stale_segments_mirror_gets_ebadarg():
+    lib = _hip.load_library()
+
+    class OldSegments(C.Structure):  # round 2's xde_segments_t: n_seg first, no size word
+        _fields_ = [("n_seg", C.c_int32), ("seg_start", C.c_int64 * _hip.XDE_MAX_SEG), ("seg_len", C.c_int64 * _hip.XDE_MAX_SEG)]
+
+    S = OldSegments()
+    S.n_seg = 1
+    S.seg_len[0] = 1024
+    dummy = C.c_void_p(0x1000)
+    kk = (C.c_void_p * 1)(0x1000)
+    ce = (C.c_double * 1)(1.0)
+    sref = C.cast(C.byref(S), C.POINTER(_hip.XdeSegments))
+    assert lib.xde_scaled_norm_partial(dummy, None, dummy, 1e-3, 1e-6, sref, 0, 0, dummy, 0, None) == _hip.XDE_EBADARG
+    assert "xde_segments_t layout mismatch" in lib.xde_last_error().decode()
+    assert lib.xde_error_norm_partial(kk, None, ce, 1, dummy, None, dummy, 1e-3, 1e-6, 0.1, None, sref, 0, 0, dummy, None, None) == _hip.XDE_EBADARG
+    assert "xde_segments_t layout mismatch" in lib.xde_last_error().decode()

@@ -24,7 +24,8 @@ class Ctrl(C.Structure):  # xde_ctrl_t
 
 
 class Params(C.Structure):  # xde_ctrl_params_t
-    _fields_ = [(n, C.c_double) for n in ("rtol", "atol", "min_step", "max_step", "safety", "ifactor", "dfactor", "order")] + [
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32)] + [
+        (n, C.c_double) for n in ("rtol", "atol", "min_step", "max_step", "safety", "ifactor", "dfactor", "order")] + [
         ("max_num_steps", C.c_int64)] + [(n, C.c_int32) for n in ("time_dtype", "state_dtype", "direction", "norm_kind", "n_stage",
                                                                  "n_seg", "n_step_t", "pi_controller")] + [
         ("pi_beta", C.c_double), ("alpha", C.c_double * MAX_STAGE), ("seg_count", C.c_double * MAX_SEG),
@@ -32,7 +33,7 @@ class Params(C.Structure):  # xde_ctrl_params_t
 
 
 class Segs(C.Structure):  # xde_segments_t
-    _fields_ = [("n_seg", C.c_int32), ("seg_start", C.c_int64 * MAX_SEG), ("seg_len", C.c_int64 * MAX_SEG)]
+    _fields_ = [("struct_size", C.c_uint32), ("n_seg", C.c_int32), ("seg_start", C.c_int64 * MAX_SEG), ("seg_len", C.c_int64 * MAX_SEG)]
 
 
 def test_dopri5_through_raw_c_abi():
@@ -49,7 +50,7 @@ def test_dopri5_through_raw_c_abi():
     lib.xde_ctrl_read.argtypes = [vp, C.POINTER(Ctrl), vp]
     lib.xde_dense_eval.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i64, vp]
     lib.xde_sizeof_ctrl_params.restype = i64
-    assert lib.xde_abi_version() == 3
+    assert lib.xde_abi_version() == 4
     assert lib.xde_sizeof_ctrl() == C.sizeof(Ctrl)
     assert lib.xde_sizeof_ctrl_params() == C.sizeof(Params)  # a hand-written mirror must be checked before it is passed
 
@@ -77,6 +78,11 @@ def test_dopri5_through_raw_c_abi():
            187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
 
     p = Params()
+    # the binding states the layout it was written against; a stale mirror gets XDE_EBADARG from every entry point (first, prove it)
+    p.struct_size, p.abi_version = C.sizeof(Params) - 16, 4
+    assert lib.xde_ctrl_init(0x1000, C.byref(p), 0.0, 0.01, 3, 0x1000, None, 0x1000, 0, None, stream) == 1
+    assert "layout mismatch" in lib.xde_last_error().decode()
+    p.struct_size, p.abi_version = C.sizeof(Params), 4
     p.rtol, p.atol, p.min_step, p.max_step = float(np.float32(1e-5)), float(np.float32(1e-7)), 0.0, float("inf")
     p.safety, p.ifactor, p.dfactor, p.order = float(np.float32(0.9)), 10.0, float(np.float32(0.2)), 5.0
     p.max_num_steps = 2**31 - 1
@@ -86,6 +92,7 @@ def test_dopri5_through_raw_c_abi():
         p.alpha[i] = a
     p.seg_count[0] = float(n)
     segs = Segs()
+    segs.struct_size = C.sizeof(Segs)
     segs.n_seg, segs.seg_start[0], segs.seg_len[0] = 1, 0, n
 
     ctrl = torch.zeros(C.sizeof(Ctrl), dtype=torch.uint8, device=dev)
