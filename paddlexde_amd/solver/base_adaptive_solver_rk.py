@@ -468,6 +468,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         f1 = self._eval(t_probe, y1)
         norm_into(f1, f0, res[0:1])
         be.initial_step(1, res, hs, self._params, float(t0h), None, self._ctrl)
+        self._first_step_dbg = (res, hs)  # (third norm, [d0, d1, h0, first step]): read by the kernel-level parity tests only
         return hs[3:4]
 
     # ------------------------------------------------------------------------------------------

@@ -109,3 +109,180 @@ def test_one_attempt_taken_apart_vs_oracle(dev, name, dtype):
         coeffs = so._interp_fit(y0, y1_ref, k, dt)
         want = O.interp_evaluate(coeffs, tt(t0), tt(t0) + tt(dt), tt(t_out))
         assert np.array_equal(sol[1].cpu().numpy(), want), (name, "dense")
+
+
+# ----------------------------------------------------------------------------------------------
+# the norm kernels and the initial-step scalars against the ORACLE's functions (round 3; they used to reach the oracle only
+# through end-to-end runs): xde_scaled_norm_partial + xde_initial_step vs AdaptiveRKSolver.select_initial_step
+# (solver/base_adaptive_solver.py:33-72); xde_error_norm_partial + xde_rk_control with LINF and with a 5-segment mixed norm vs
+# compute_error_ratio over _linf_norm / _mixed_norm (utils/ode_utils.py:4-19,80-82); forward and reverse time.
+# ----------------------------------------------------------------------------------------------
+def _cubic_np(dtype):
+    c = dtype(0.25)
+    return lambda t, y: (y - (y * y) * y * c).astype(dtype)  # element-wise, +, -, * only: f(0) = 0 keeps pads at zero
+
+
+def _params(so, cls, S, dtype, n_seg, seg_counts, norm_kind, direction):
+    p = _hip.XdeCtrlParams()
+    p.rtol, p.atol, p.min_step, p.max_step = float(so.rtol), float(so.atol), 0.0, float("inf")
+    p.safety, p.ifactor, p.dfactor, p.order = float(so.safety), float(so.ifactor), float(so.dfactor), float(so.order)
+    p.max_num_steps = 2**31 - 1
+    p.time_dtype = p.state_dtype = _hip.XDE_F32 if dtype == np.float32 else _hip.XDE_F64
+    p.direction, p.norm_kind, p.n_stage, p.n_seg = direction, norm_kind, S, n_seg
+    for i, a in enumerate(cls.tableau.alpha):
+        p.alpha[i] = float(a)
+    for i, cnt in enumerate(seg_counts):
+        p.seg_count[i] = float(cnt)
+    return p
+
+
+@pytest.mark.parametrize("direction", [1, -1])
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("kind", ["linf", "mixed5", "rms"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_error_norm_kinds_vs_oracle(dev, dtype, kind, fused, direction):
+    """One attempted Dopri5 step on a ~1 M-element state: the error ratio the norm kernel + controller produce equals
+    compute_error_ratio(y1_error, rtol, atol, y0, y1, norm) with the oracle's norm functions — LINF to the bit, RMS / the
+    5-segment mixed norm (max of per-segment RMS = the adjoint's default norm shape) to reduction-order accuracy, every
+    segment's own value too.  Reverse time: the kernels get (k_j = f, dt < 0), the oracle its flipped problem (f -> -f, dt > 0)."""
+    be = _hip.get_backend()
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    width = 4 if dtype == np.float32 else 2
+    rng = np.random.RandomState(5)
+    lens = [1, 300001, 7, 500000, 252] if kind == "mixed5" else [(1 << 20) + 3]
+    starts, pos = [], 0
+    for ln in lens:  # tuple state: every segment starts on a 16-byte boundary, pads are zero
+        starts.append(pos)
+        pos += -(-ln // width) * width
+    total = pos
+    flat = np.zeros(total, dtype=dtype)
+    for s0, ln in zip(starts, lens):
+        flat[s0 : s0 + ln] = rng.uniform(-2, 2, size=ln).astype(dtype)
+    compact = np.concatenate([flat[s0 : s0 + ln] for s0, ln in zip(starts, lens)])
+    f = _cubic_np(dtype)
+    rtol, atol = 1e-4, 1e-6
+    norm = {"linf": O._linf_norm, "rms": O._rms_norm,
+            "mixed5": lambda x: O._mixed_norm(O._unflatten(x, [(ln,) for ln in lens]))}[kind]
+    f_or = f if direction > 0 else (lambda t, y: -f(-t, y))  # D5: the oracle integrates the flipped problem
+    so = O.AdaptiveRKSolver(f_or, compact, rtol, atol, method="dopri5", norm=norm, dtype=dtype)
+    t0, dt = dtype(0.5), dtype(0.11)
+    f0 = so.move(t0, 0, compact)
+    y1_ref, f1_ref, err_ref, k = so._runge_kutta_step(compact, f0, t0, dt, t0 + dt, so.tableau)
+    ratio_ref = O.compute_error_ratio(err_ref, so.rtol, so.atol, compact, y1_ref, norm)
+    seg_ref = [float(np.abs((O._linf_norm if kind == "linf" else O._rms_norm)(
+        (err_ref / (so.atol + so.rtol * np.fmax(np.abs(compact), np.abs(y1_ref))))[a : a + ln]))) for a, ln in
+        zip(np.cumsum([0] + lens[:-1]), lens)]
+
+    S = k.shape[-1] - 1
+    n_stage, stage_plan, fsal, sol_plan, err_plan, mid_plan, fuse_err, err2_coef, _ = _build_plans(Dopri5.tableau, Dopri5.mid)
+
+    def pad(compact_arr):  # the oracle's compact vector laid out with the device's pads
+        out = np.zeros(total, dtype=dtype)
+        a = 0
+        for s0, ln in zip(starts, lens):
+            out[s0 : s0 + ln] = compact_arr[a : a + ln]
+            a += ln
+        return torch.from_numpy(out).to(dev)
+
+    sign = dtype(direction)
+    ks = [pad(sign * k[..., j]) for j in range(S + 1)]  # the product's k_j = f(t, y) in real time
+    y0d, y1d = pad(compact), pad(y1_ref)
+    dts = float(sign * dt)
+    kind_code = _hip.NORM_LINF if kind == "linf" else _hip.NORM_RMS
+    p = _params(so, Dopri5, S, dtype, len(lens), lens, kind_code, direction)
+    ctrl, ws = be.new_ctrl(y0d.device), be.new_workspace(y0d.device)
+    ts = torch.zeros(_hip.XDE_MAX_STAGE, dtype=tdt, device=y0d.device)
+    t_span = torch.tensor([direction * 0.5, direction * 100.0], dtype=torch.float64, device=y0d.device)
+    be.ctrl_init(ctrl, p, direction * 0.5, dts, 2, t_span, None, ts)
+    segs = _hip.make_segments(list(zip(starts, lens)))
+    idx, coef = err_plan
+    if fused:
+        # the last stage's combine emits the partial error sum from the operands it holds (xde_stage_combine out2) ...
+        sidx, scoef = stage_plan[S - 1]
+        y_last, ebuf = torch.empty_like(y0d), torch.empty_like(y0d)
+        be.stage_combine(y_last, y0d, [ks[j] for j in sidx], scoef, _hip.COMBINE_RK, ctrl=ctrl, out2=ebuf, coef2=err2_coef)
+        assert np.array_equal(y_last.cpu().numpy(), y1d.cpu().numpy())  # = the oracle's y1, bit for bit, also with dt < 0
+        # ... and the norm pass reads 4 arrays instead of 8
+        be.error_norm_partial([ks[S]], [coef[-1]], y0d, y1d, p.rtol, p.atol, segs, kind_code, ws, ctrl=ctrl, e_pre=ebuf)
+    else:
+        be.error_norm_partial([ks[j] for j in idx], coef, y0d, y1d, p.rtol, p.atol, segs, kind_code, ws, ctrl=ctrl)
+    be.rk_control(ctrl, p, ws, None, t_span, None, ts)
+    c = be.ctrl_read(ctrl)
+    if kind == "linf":
+        assert c.ratio == float(ratio_ref), (c.ratio, float(ratio_ref))  # a maximum does not depend on the order it is taken in
+    else:
+        rel = 3e-6 if dtype == np.float32 else 1e-12  # numpy's pairwise fp32 mean vs fp32 lanes -> fp64 accumulation
+        assert c.ratio == pytest.approx(float(ratio_ref), rel=rel), (c.ratio, float(ratio_ref))
+        for s_, want in enumerate(seg_ref):
+            assert c.ratio_seg[s_] == pytest.approx(want, rel=rel), (s_, c.ratio_seg[s_], want)
+        assert int(np.argmax(seg_ref)) == int(np.argmax([c.ratio_seg[s_] for s_ in range(len(lens))]))
+    assert bool(c.accept) == bool(ratio_ref <= 1) and c.nonfinite == 0
+    tt = so.tt
+    want_dt = tt(np.clip(O.optimal_step_size(tt(dt), tt(c.ratio), so.safety, so.ifactor, so.dfactor, so.order), so.min_step, so.max_step))
+    assert c.dt == pytest.approx(direction * float(want_dt), rel=2.4e-7 if dtype == np.float32 else 4.5e-16)
+
+
+@pytest.mark.parametrize("direction", [1, -1])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_initial_step_vs_oracle_select_initial_step(dev, dtype, direction):
+    """select_initial_step (solver/base_adaptive_solver.py:33-72) on a 1 M-element state.  The oracle's own run is instrumented
+    (its norm and fuse calls are recorded), then (1) the three scaled norms of xde_scaled_norm_partial are held to the oracle's
+    norm values; (2) the scalar arithmetic of xde_initial_step, FED the oracle's norm values bit for bit, gives the oracle's h0
+    exactly and its first step to one ulp of the transcendental (pow); (3) the solver's own device path (_before_integrate, no
+    host read) lands on the oracle's first step, signed by the direction of integration."""
+    from paddlexde_amd import Dopri5 as Solver
+    from paddlexde_amd.utils import _rms_norm
+    from paddlexde_amd.xde import BaseODE
+
+    be = _hip.get_backend()
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.RandomState(8)
+    y0 = rng.uniform(-2, 2, size=((1 << 19) + 3, 2)).astype(dtype)
+    mu = 3.0
+    f_np, f_t = P.vdp_np(dtype(mu)), P.vdp_torch(mu)
+    rtol, atol = 1e-5, 1e-7
+    norms, h0s = [], []
+
+    def rec_norm(x):
+        v = O._rms_norm(x)
+        norms.append(v)
+        return v
+
+    f_or = f_np if direction > 0 else (lambda t, y: -f_np(-t, y))
+    so = O.AdaptiveRKSolver(f_or, y0, rtol, atol, method="dopri5", norm=rec_norm, dtype=dtype)
+    fuse0 = so.fuse
+    so.fuse = lambda dy, dt, y: (h0s.append(dt), fuse0(dy, dt, y))[1]
+    t0 = so.tt(direction * 0.25)
+    # real start time direction * 0.25; in reverse the oracle sees the flipped problem, whose start time is +0.25 again
+    first_ref = so.select_initial_step(so.tt(0.25), y0, so.order - 1, so.rtol, so.atol)
+    d0_ref, d1_ref, n3_ref = [float(np.abs(v)) for v in norms]
+    h0_ref = float(h0s[0])
+
+    y0d = torch.from_numpy(y0).to(dev)
+    t_span = np.asarray([direction * 0.25, direction * 5.0])
+    s = Solver(xde=BaseODE(f_t, y0=y0d, t_span=torch.from_numpy(t_span)), y0=y0d, rtol=rtol, atol=atol, norm=_rms_norm, dtype=tdt)
+    s.y0 = y0d
+    s._before_integrate(t_span.astype(np.float32 if dtype == np.float32 else np.float64))
+    res, hs = s._first_step_dbg
+    res, hs = res.cpu().numpy(), hs.cpu().numpy()
+    rel = 3e-6 if dtype == np.float32 else 1e-12
+    # (1) the norms
+    assert hs[0] == pytest.approx(d0_ref, rel=rel) and hs[1] == pytest.approx(d1_ref, rel=rel)
+    assert abs(res[0]) == pytest.approx(n3_ref, rel=30 * rel)  # f1 - f0 at h0 ~ 1e-5: a cancellation, and h0 differs in its last bits
+    # (3) the whole device path
+    assert hs[2] == pytest.approx(h0_ref, rel=2 * rel)
+    assert hs[3] == pytest.approx(float(first_ref), rel=30 * rel)
+
+    # (2) the scalar arithmetic alone, on the oracle's norm values
+    p = s._params
+    ctrl2 = be.new_ctrl(y0d.device)
+    r2 = torch.tensor([norms[0], norms[1]], dtype=torch.float64, device=y0d.device)
+    h2 = torch.zeros(4, dtype=torch.float64, device=y0d.device)
+    t_probe = torch.empty((), dtype=tdt, device=y0d.device)
+    be.initial_step(0, r2, h2, p, float(t0), t_probe, ctrl2)
+    assert h2.cpu().numpy()[2] == h0_ref  # h0 = 0.01 d0 / d1 in the state dtype, reference op order: exact
+    assert float(t_probe.cpu()) == float(so.tt(t0) + dtype(direction * h0_ref) if dtype == np.float32 else t0 + direction * h0_ref)
+    r2 = torch.tensor([norms[2], 0.0], dtype=torch.float64, device=y0d.device)
+    be.initial_step(1, r2, h2, p, float(t0), None, ctrl2)
+    ulp = 1.2e-7 if dtype == np.float32 else 2.3e-16
+    assert h2.cpu().numpy()[3] == pytest.approx(float(first_ref), rel=2 * ulp), (h2.cpu().numpy(), first_ref)

@@ -49,7 +49,7 @@ def _replay_run(f_t, y0, t, so, dev, *, rtol, atol, pipeline="sync", hook=True, 
     return got, s, states
 
 
-def _check(got, s, states, ref, so, ref_states, *, ratio_rtol, pipeline, ratio_atol=0.0, y_atol=1e-7, dense_atol=None):
+def _check(got, s, states, ref, so, ref_states, *, ratio_rtol, pipeline, ratio_atol=0.0, y_atol=1e-7, dense_atol=None, label=None):
     theirs = np.asarray([[r.t0, r.dt, r.ratio, float(r.accept)] for r in so.trace])
     mine = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
     assert mine.shape == theirs.shape, (mine.shape, theirs.shape)
@@ -70,6 +70,12 @@ def _check(got, s, states, ref, so, ref_states, *, ratio_rtol, pipeline, ratio_a
     assert got.dtype == ref.dtype == np.float32
     dense_atol = y_atol if dense_atol is None else dense_atol
     assert P.parity_ok(got, ref, rtol=1e-5, atol=dense_atol), ("solution", P.worst(got, ref, 1e-5, dense_atol))
+    if label is not None:  # what was actually observed, next to the bar (print the worst ulp count)
+        P.report(label, {"pipeline": pipeline, "attempts": int(mine.shape[0]),
+                         "worst_ulps_y1": max([P.worst_ulps(a, b) for a, b in zip(states, ref_states)], default=None) if pipeline == "sync" else None,
+                         "worst_ulps_rows": P.worst_ulps(got, ref), "allowed_ulps_y1": y_atol / float(np.spacing(np.float32(np.abs(ref).max()))),
+                         "allowed_ulps_rows": dense_atol / float(np.spacing(np.float32(np.abs(ref).max()))),
+                         "worst_ratio_rel": float((np.abs(mine[:, 2] - theirs[:, 2]) / np.maximum(np.abs(theirs[:, 2]), 1e-300)).max())})
 
 
 @pytest.mark.parametrize("pipeline", ["sync", "lag", "graph"])
@@ -86,7 +92,7 @@ def test_replay_config2_shape_fp32(dev, pipeline):
     # every step's y1, 4 ulp for the emitted rows — the dense-output quartic (ode_utils.py:28-49) forms its coefficients from
     # differences like 18 y0 + 14 y1 - 32 y_mid, which amplify a last-bit difference of their inputs (P.ulp_atol).
     _check(got, s, states, ref, so, ref_states, ratio_rtol=2e-2, ratio_atol=1e-4, pipeline=pipeline,
-           y_atol=P.ulp_atol(ref, 2), dense_atol=P.ulp_atol(ref, 4))
+           y_atol=P.ulp_atol(ref, 2), dense_atol=P.ulp_atol(ref, 4), label="replay_config2_shape_fp32")
 
 
 @pytest.mark.parametrize("controller", ["I", "PI"])
@@ -103,7 +109,7 @@ def test_replay_config5_vdp_fp32(dev, controller, pipeline):
     got, s, states = _replay_run(P.vdp_torch(mu), y0, t, so, dev, rtol=1e-5, atol=1e-7, pipeline=pipeline, controller=controller,
                                  max_num_steps=10**6)
     # element-wise func: identical k_j on both sides, the ratio differs only by the reduction order of 8192 squares
-    _check(got, s, states, ref, so, ref_states, ratio_rtol=1e-5, pipeline=pipeline)
+    _check(got, s, states, ref, so, ref_states, ratio_rtol=1e-5, pipeline=pipeline, label="replay_config5_vdp_fp32/" + controller)
 
 
 def test_replay_config3_forward_fp32(dev):
@@ -121,7 +127,7 @@ def test_replay_config3_forward_fp32(dev):
     # through zero: there the bar's absolute part, 1e-7, is below ONE fp32 ulp of the quantities the element was summed from
     # (ulp(2) = 2.4e-7), so the absolute part is 2 ulp of the state's scale here; the relative part stays 1e-5.
     _check(got, s, states, ref, so, ref_states, ratio_rtol=2e-2, ratio_atol=1e-4, pipeline="sync", y_atol=P.ulp_atol(ref, 2),
-           dense_atol=P.ulp_atol(ref, 4))
+           dense_atol=P.ulp_atol(ref, 4), label="replay_config3_forward_fp32")
 
 
 def test_replay_table_shorter_than_the_solve(dev):

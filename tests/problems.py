@@ -148,3 +148,22 @@ def ulp_atol(ref, k, floor=1e-7):
     Tests whose func is not bit-identical on both sides state the bar's absolute part in ulps of the state's scale instead;
     the relative part stays 1e-5."""
     return max(floor, k * float(np.spacing(np.float32(np.abs(np.asarray(ref)).max()))))
+
+
+def worst_ulps(got, ref):
+    """Largest |got - ref| in units of one fp32 ulp at the scale of `ref` (its largest magnitude)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / float(np.spacing(np.float32(np.abs(ref).max()))))
+
+
+def report(name, rec):
+    """Worst observed deviations of a parity test: printed, and appended to $XDE_PARITY_REPORT when set
+    (profiles/r03_parity_report.jsonl is one such run of the GPU suite)."""
+    import json
+    import os
+
+    print("parity report:", name, rec)
+    path = os.environ.get("XDE_PARITY_REPORT")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(json.dumps({"test": name, **rec}) + "\n")
