@@ -368,6 +368,109 @@ def rk4_workload(args):
     emit(out)
 
 
+def dense_workload(args):
+    """Dense output on config 2's state (A10: `_interp_fit` + `interp_evaluate`, base_adaptive_solver_rk.py:286-292, ode_utils.py:28-77 —
+    here ONE lazy launch per accepted step that covers an output time, coefficients never materialised).  The real solve:
+    65536 x 128 fp32, Dopri5, t in [0, 1], T = 11 output times, sync pipeline (so that only covering steps launch the kernel).
+    Algorithmic bytes per launch (9 N per output row): reads k0,k2..k6,y0,y1 = 8 N, writes `rows` N."""
+    from paddlexde_amd import Dopri5, _hip, odeint
+    from paddlexde_amd.utils import _rms_norm
+
+    dev = torch.device("cuda", 0)
+    B = 65536 if args.batch is None else args.batch
+    D = 128 if args.dim is None else args.dim
+    T = 11
+    A, y0 = make_problem(B, D, 0, dev)
+    AT = A.T.contiguous()
+    func = lambda t, y: y @ AT  # noqa: E731
+    t = torch.linspace(0.0, 1.0, T)
+    be = _hip.get_backend()
+    opts = {"norm": _rms_norm, "pipeline": "sync"}
+    with torch.no_grad():
+        odeint(func, y0, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options=opts)  # warm-up (allocator, GEMM tuning)
+        torch.cuda.synchronize()
+        reps = max(1, args.steps // 10)
+        be.prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sol = odeint(func, y0, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options=opts)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    prof = be.prof_collect()
+    be.prof_enable(False)
+    rec = prof["dense"]
+    N = B * D
+    rows = (T - 1) * reps
+    by = (8.0 * rec["launches"] + rows) * N * 4.0
+    a = by / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] > 0 else 0.0
+    # the same solve with 2 output times: what the 9 extra rows cost end to end
+    with torch.no_grad():
+        t2 = torch.tensor([0.0, 1.0])
+        odeint(func, y0, t2, solver=Dopri5, rtol=1e-5, atol=1e-7, options=opts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            odeint(func, y0, t2, solver=Dopri5, rtol=1e-5, atol=1e-7, options=opts)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+    emit({"metric": "dense-output rows per second (lazy xde_dense_eval inside a Dopri5 solve)", "value": rows / el, "unit": "rows/s", "n_gpus": 1,
+          "steps": reps, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+          "config": {"workload": "config 2's state {} x {} fp32, Dopri5 t in [0,1], T = {} output times, sync pipeline".format(B, D, T)},
+          "solve_ms_T11": 1e3 * el / reps, "solve_ms_T2": 1e3 * el2 / reps, "finite": bool(torch.isfinite(sol[-1]).all()),
+          "roofline": {"bound": "hbm", "kernel": "xde_dense_kernel<float, float, vec> (one launch per accepted step that covers output times)",
+                       "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
+                       "launches": rec["launches"], "rows": rows, "avg_launch_us": 1e3 * rec["ms"] / max(rec["launches"], 1),
+                       "bytes_per_launch": by / max(rec["launches"], 1)}})
+
+
+def dde_workload(args):
+    """The delay-equation caller's history gather (HistoryIndex, xde/base_dde.py:82-127 over the cubic-Hermite
+    spline of interpolation/interpolate.py:100-204) at the reference application's size (D3STN, PeMS04-like: 307 nodes x batch 32 =
+    9824 series, 288 history times, 64 channels, 12 learned lags): value AND time derivative at the lags in one pass,
+    xde_hermite_gather.  Algorithmic bytes: 3 history rows in + value + derivative out = 5 x (series x lags x channels) x 4 B.
+    A small instance is checked against the oracle's history_index first (checker only)."""
+    from oracle import xde_oracle as O
+    from paddlexde_amd import _hip
+
+    dev = torch.device("cuda", 0)
+    be = _hip.get_backend()
+    g = torch.Generator().manual_seed(0)
+    # parity at a small size (the oracle is a numpy loop over lags)
+    hs = torch.randn(37, 24, 8, generator=g)
+    ts = torch.linspace(0.0, 2.3, 24)
+    lg = torch.rand(5, generator=g) * 2.3
+    v, d = torch.empty(37, 5, 8, device=dev), torch.empty(37, 5, 8, device=dev)
+    be.hermite_gather(v, d, hs.to(dev), ts.to(dev), lg.to(dev))
+    want, _ = O.history_index(lg.numpy(), hs.numpy(), ts.numpy())
+    err = float(np.abs(v.cpu().numpy() - want).max() / np.abs(want).max())
+    assert err <= 2e-5, err
+    S, T, D, L = 9824, 288, 64, 12
+    his = torch.randn(S, T, D, generator=g).to(dev)
+    his_t = torch.linspace(0.0, 287.0, T).to(dev)
+    lags = (torch.rand(L, generator=g) * 287.0).to(dev)
+    val, der = torch.empty(S, L, D, device=dev), torch.empty(S, L, D, device=dev)
+    for _ in range(args.warmup):
+        be.hermite_gather(val, der, his, his_t, lags)
+    torch.cuda.synchronize()
+    be.prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        be.hermite_gather(val, der, his, his_t, lags)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rec = be.prof_collect()["dense"]
+    be.prof_enable(False)
+    by = 5.0 * S * L * D * 4.0
+    a = by * rec["launches"] / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] > 0 else 0.0
+    emit({"metric": "history-spline gathers per second (xde_hermite_gather, value + derivative)", "value": args.steps / el, "unit": "gathers/s",
+          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+          "config": {"workload": "D3STN-sized history: {} series x {} times x {} channels, {} lags".format(S, T, D, L)},
+          "parity_small_case_rel_err_vs_oracle": err,
+          "roofline": {"bound": "hbm", "kernel": "xde_hermite_vec_kernel<float>", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": a / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e3 * rec["ms"] / max(rec["launches"], 1),
+                       "bytes_per_launch": by, "history_bytes": float(S) * T * D * 4.0}})
+
+
 def time_unsharded(B, D, dtype, pipeline, device, steps, warmup):
     """One rank, no process group: attempted Dopri5 steps of the linear ODE at batch B x dim D.  Used by the N > 1 line for
     `n1_same_workload` (config 4's GLOBAL problem on one GPU — the N=1 point of the strong-scaling curve)."""

@@ -1,36 +1,47 @@
-"""``odeint_adjoint`` — O(1)-memory gradients by integrating the adjoint ODE backwards.
+"""``odeint_adjoint`` — O(1)-memory gradients: the adjoint ODE is integrated backwards, interval by interval, on the same kernels.
 
-Reference: paddlexde/functional/odeint_adjoint.py:11-167 (``OdeintAdjointMethod``), :170-257
-(``odeint_adjoint``), :260-277 (``find_parameters``), :280-327 (``handle_adjoint_norm_``).
+Reference behaviour restated here (paddlexde/functional/odeint_adjoint.py): the forward solve under ``no_grad`` and what is saved
+for the backward (:11-45); the backward sweep over the output intervals with the augmented state ``(adj_t, y, adj_y, *adj_theta)``,
+the cotangent ``-adj_y``, the reset ``y <- y_ans[i-1]`` and the jump ``adj_y += grad_y[i-1]`` (:47-167); argument defaults and
+validation with the reference's three messages (:170-257); which tensors count as adjoint parameters (:260-277); the default /
+``"seminorm"`` / user adjoint norms (:280-327).
 
-The control flow, argument validation, norm selection and the augmented dynamics are the reference's.
-Deviations, all documented in SURVEY.md:
-  D4  the augmented tuple state is flattened into one padded buffer (``functional/odeint.py``) — the
-      reference's backward cannot run as written because tuple support was removed;
-  D5  the reverse-time interval ``t_span[i-1:i+1].flip(0)`` runs natively with a signed dt;
-  D6  the gradient w.r.t. ``y0`` (``adj_y``) is returned instead of ``None`` (superset).
-"""
+How it is organised here (not the reference's layout):
+  * everything the backward needs is ONE immutable record (``_BackwardPlan``) built by ``odeint_adjoint`` and handed to the autograd
+    node, instead of a dozen positional arguments copied onto ``ctx`` one by one;
+  * the augmented state lives in the flat, 16-byte-segment layout the kernels integrate for the WHOLE sweep (``_AugmentedState``):
+    the reference rebuilds a tuple per interval, here the reset and the jump are two in-place copies into the flat buffer;
+  * the adjoint norm is an object (``SegmentMaxNorm``) that states what it is — "max over the first n segments of the per-segment
+    state norm" — so that the solver maps it onto ONE segmented reduction kernel without inspecting closures;
+  * the augmented dynamics can be replayed from a captured HIP graph (``adjoint_options["graph_func"]``), and a batch-sharded
+    backward sums the row-summed adjoints over the process group where the step control looks at them.
+Deviations documented in SURVEY.md: D4 (tuple state flattened), D5 (reverse-time intervals run natively with a signed dt), D6 (the
+gradient w.r.t. ``y0`` is returned instead of ``None``)."""
+import threading
 import warnings
 import weakref
+from typing import Any, NamedTuple, Optional
 
 import torch
 import torch.nn as nn
 
 from ..solver.base_fixed_solver import FixedSolver
-from ..utils.ode_utils import _mixed_norm, _rms_norm, native_norm_spec
+from ..utils.ode_utils import _rms_norm, native_norm_spec
 from .odeint import _odeint_packed, _pack, _segment_layout, odeint
+
+_N_LEADING = 3  # adj_t, y, adj_y come first in the augmented state; the parameter adjoints follow
 
 
 def _is_fixed(solver):
     return isinstance(solver, type) and issubclass(solver, FixedSolver)
 
 
-def _time_first(x, y0_shape, T, fixed):
-    """View of a solution/gradient with time on axis 0 (fixed layout: time folded into axis -2)."""
+def _time_first(x, y0_shape, n_times, fixed):
+    """View of a solution / its gradient with time on axis 0 (the fixed-step layout folds time into axis -2)."""
     if not fixed:
         return x
-    lead, L, D = tuple(y0_shape[:-2]), y0_shape[-2], y0_shape[-1]
-    return x.reshape(lead + (T, L, D)).movedim(len(lead), 0)
+    lead, rows, width = tuple(y0_shape[:-2]), y0_shape[-2], y0_shape[-1]
+    return x.reshape(lead + (n_times, rows, width)).movedim(len(lead), 0)
 
 
 def _group_sum(tensors, pg):
@@ -52,52 +63,122 @@ def _group_sum(tensors, pg):
     return outs
 
 
-def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, reduce_params=False):
-    """odeint_adjoint.py:89-124: dynamics of the original system augmented with the adjoint wrt y and an integrator
-    wrt t and the parameters.  ``y_aug = (adj_t, y, adj_y, *adj_params)``; only y and adj_y are read.
+# ----------------------------------------------------------------------------------------------------------------------
+# adjoint norm                                                               (reference: odeint_adjoint.py:280-327)
+# ----------------------------------------------------------------------------------------------------------------------
+class SegmentMaxNorm:
+    """``max`` over the leading ``n_segments`` tensors of the augmented state (``None``: all of them) of ``state_norm`` — with
+    ``|adj_t|`` for the scalar first segment, which is what any of the state norms gives for one element.
 
-    Batch-sharded run (``pg``): ``vjp_y`` and ``f`` are per-row quantities of this rank's rows, but ``vjp_t`` and the
-    ``vjp_params`` are sums over rows.  Where the step control looks at them — ``adj_t`` when time gradients are wanted,
-    the parameter adjoints under the default adjoint norm (``reduce_params``) — they are summed over the group here, so
-    that every rank integrates the GLOBAL ``adj_t`` / ``adj_params`` and the all-reduced norm is exactly the unsharded one."""
+    ``n_segments=None`` is the reference's default adjoint norm (:284-287: ``max(|t|, norm(y), norm(adj_y), mixed(adj_theta))``),
+    ``n_segments=3`` its "seminorm" (:301-309: the parameter adjoints do not steer the step size).  When ``state_norm`` is the native
+    RMS norm the object carries ``_xde_native = ("mixed", n_segments)`` and the adaptive solver evaluates it as one segmented
+    reduction launch; with any other state norm it is an ordinary callable applied to the tuple of segment views."""
+
+    def __init__(self, state_norm, n_segments: Optional[int]):
+        self.state_norm = state_norm
+        self.n_segments = n_segments
+        if native_norm_spec(state_norm) == ("rms",):
+            self._xde_native = ("mixed", n_segments)
+
+    def __call__(self, parts):
+        parts = tuple(parts) if self.n_segments is None else tuple(parts)[: self.n_segments]
+        worst = parts[0].abs()
+        for x in parts[1:_N_LEADING]:
+            worst = max(worst, self.state_norm(x))
+        for x in parts[_N_LEADING:]:  # the parameter adjoints: RMS each (the reference's _mixed_norm), whatever the state norm
+            worst = max(worst, _rms_norm(x))
+        return worst
+
+    @property
+    def watches_parameters(self):
+        return self.n_segments is None or self.n_segments > _N_LEADING
+
+
+def _resolve_adjoint_norm(adjoint_options, state_norm):
+    """The norm the backward solve runs with: absent -> the default, ``"seminorm"`` -> the semi-norm, a callable -> itself
+    (it receives ``(adj_t, y, adj_y, *adj_theta)``)."""
+    chosen = adjoint_options.get("norm")
+    if chosen is None:
+        return SegmentMaxNorm(state_norm, None)
+    if isinstance(chosen, str):
+        if chosen != "seminorm":
+            raise ValueError("adjoint_options['norm'] must be a callable or \"seminorm\", got {!r}".format(chosen))
+        return SegmentMaxNorm(state_norm, _N_LEADING)
+    return chosen
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# adjoint parameters                                                          (reference: odeint_adjoint.py:216-234,260-277)
+# ----------------------------------------------------------------------------------------------------------------------
+def _module_tensors(func):
+    """The tensors of ``func`` that gradients are wanted for.  A DataParallel replica keeps them as plain attributes of its
+    sub-modules rather than registered parameters (:263-275)."""
+    if not isinstance(func, nn.Module):
+        raise TypeError("expected an nn.Module")
+    if not getattr(func, "_is_replica", False):
+        return tuple(func.parameters())
+    live = lambda m: [(name, v) for name, v in vars(m).items() if torch.is_tensor(v) and v.requires_grad]  # noqa: E731
+    return tuple(v for _, v in func._named_members(get_members_fn=live))
+
+
+def _adjoint_parameters(func, given, norm_is_users):
+    params = _module_tensors(func) if given is None else tuple(given)
+    wanted = tuple(p for p in params if p.requires_grad)
+    if len(wanted) < len(params) and norm_is_users:
+        warnings.warn(
+            "An adjoint parameter was passed without requiring gradient. For efficiency this will be "
+            "excluded from the adjoint pass, and will not appear as a tensor in the adjoint norm."
+        )
+    return wanted
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# augmented dynamics                                                          (reference: odeint_adjoint.py:89-124)
+# ----------------------------------------------------------------------------------------------------------------------
+def _vjp_of(evaluate, t, y, wrt_params, cotangent, time_grad, retain):
+    """``f = evaluate(t, y)`` and ``cotangent^T df/d(t, y, params)``; missing gradients are zeros (:116-122)."""
+    with torch.enable_grad():
+        t_const = t.detach()
+        t_var = t_const.clone().requires_grad_(True)
+        y_var = y.detach().clone().requires_grad_(True)
+        # dL/dt is only resolved when asked for: func then sees a time it can be differentiated by
+        f = evaluate(t_var if time_grad else t_const, y_var)
+        grads = torch.autograd.grad(f, (t_var, y_var) + tuple(wrt_params), cotangent, allow_unused=True, retain_graph=retain)
+    filled = [torch.zeros_like(x) if g is None else g for x, g in zip((t_var, y_var) + tuple(wrt_params), grads)]
+    return f.detach(), filled[0], filled[1], filled[2:]
+
+
+def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, reduce_params=False):
+    """``d/dt (adj_t, y, adj_y, adj_theta) = (vjp_t, f, vjp_y, vjp_theta)`` with the cotangent ``-adj_y``; only ``y`` and
+    ``adj_y`` are read from the state.
+
+    Batch-sharded run (``pg``): ``f`` and ``vjp_y`` are per-row quantities of this rank's rows, ``vjp_t`` and ``vjp_theta`` are
+    sums over rows.  Where the step control looks at them — ``adj_t`` when time gradients are wanted, the parameter adjoints under
+    the default adjoint norm (``reduce_params``) — they are summed over the group here, so that every rank integrates the GLOBAL
+    ``adj_t`` / ``adj_theta`` and the all-reduced norm is exactly the unsharded one."""
 
     def augmented_dynamics(t, y_aug):
-        y = y_aug[1]
-        adj_y = y_aug[2]
-        with torch.enable_grad():
-            t_ = t.detach()
-            t = t_.clone().requires_grad_(True)
-            y = y.detach().clone().requires_grad_(True)
-            # If using an adaptive solver we don't want to waste time resolving dL/dt unless we need it
-            func_eval = func(t if t_requires_grad else t_, y)
-            vjp_t, vjp_y, *vjp_params = torch.autograd.grad(
-                func_eval, (t, y) + adjoint_params, -adj_y, allow_unused=True, retain_graph=True
-            )
-        # autograd.grad returns None if no gradient, set to zero.
-        vjp_t = torch.zeros_like(t) if vjp_t is None else vjp_t
-        vjp_y = torch.zeros_like(y) if vjp_y is None else vjp_y
-        vjp_params = [
-            torch.zeros_like(param) if vjp_param is None else vjp_param for param, vjp_param in zip(adjoint_params, vjp_params)
-        ]
-        if pg is not None and (t_requires_grad or (reduce_params and vjp_params)):
-            if t_requires_grad and reduce_params:
-                vjp_t, *vjp_params = _group_sum([vjp_t] + vjp_params, pg)
-            elif t_requires_grad:
-                (vjp_t,) = _group_sum([vjp_t], pg)
-            else:
-                vjp_params = _group_sum(vjp_params, pg)
-        return (vjp_t, func_eval.detach(), vjp_y, *vjp_params)
+        f, vjp_t, vjp_y, vjp_params = _vjp_of(func, t, y_aug[1], adjoint_params, -y_aug[2], t_requires_grad, retain=True)
+        if pg is not None:
+            shared = ([vjp_t] if t_requires_grad else []) + (list(vjp_params) if reduce_params else [])
+            if shared:
+                shared = _group_sum(shared, pg)
+                if t_requires_grad:
+                    vjp_t, shared = shared[0], shared[1:]
+                if reduce_params:
+                    vjp_params = shared
+        return (vjp_t, f, vjp_y, *vjp_params)
 
     return augmented_dynamics
 
 
 def _make_functional_dynamics(func, adjoint_params, t_requires_grad):
-    """The augmented dynamics for HIP-graph capture: identical arithmetic, but the vjp is taken w.r.t. fresh detached
-    aliases of the parameters (substituted with torch.func.functional_call) instead of the parameter leaves
-    themselves.  After a user's loss.backward() the real leaves own AccumulateGrad nodes bound to the default
-    stream, and differentiating w.r.t. them inside a later stream capture makes the engine synchronise with the
-    default stream — which crashes the capture.  Needs ``func`` to be an nn.Module whose parameters are the
-    adjoint parameters."""
+    """The augmented dynamics for HIP-graph capture: identical arithmetic, but the vjp is taken w.r.t. fresh detached aliases of
+    the parameters (substituted with torch.func.functional_call) instead of the parameter leaves themselves.  After a user's
+    loss.backward() the real leaves own AccumulateGrad nodes bound to the default stream, and differentiating w.r.t. them inside a
+    later stream capture makes the engine synchronise with the default stream — which crashes the capture.  Needs ``func`` to be an
+    nn.Module whose parameters are the adjoint parameters."""
     names = {id(p): n for n, p in func.named_parameters()}
     try:
         order = [names[id(p)] for p in adjoint_params]
@@ -105,32 +186,25 @@ def _make_functional_dynamics(func, adjoint_params, t_requires_grad):
         raise NotImplementedError(
             "adjoint_options['graph_func'] needs func to be an nn.Module and adjoint_params to be (a subset of) its parameters"
         )
-
     # the capture cache is keyed weakly by the module (_GRAPH_CACHE): what it stores must not keep the module alive
     func_ref = weakref.ref(func)
     del func
 
     def augmented_dynamics(t, y_aug):
-        y = y_aug[1]
-        adj_y = y_aug[2]
         module = func_ref()
         if module is None:
             raise RuntimeError("the module this captured dynamics was built for no longer exists")
-        with torch.enable_grad():
-            t_ = t.detach()
-            t = t_.clone().requires_grad_(True)
-            y = y.detach().clone().requires_grad_(True)
-            ps = tuple(p.detach().requires_grad_(True) for p in adjoint_params)  # aliases, no copy
-            func_eval = torch.func.functional_call(module, dict(zip(order, ps)), (t if t_requires_grad else t_, y))
-            vjp_t, vjp_y, *vjp_params = torch.autograd.grad(func_eval, (t, y) + ps, -adj_y, allow_unused=True)
-        vjp_t = torch.zeros_like(t) if vjp_t is None else vjp_t
-        vjp_y = torch.zeros_like(y) if vjp_y is None else vjp_y
-        vjp_params = [torch.zeros_like(p) if v is None else v for p, v in zip(adjoint_params, vjp_params)]
-        return (vjp_t, func_eval.detach(), vjp_y, *vjp_params)
+        aliases = tuple(p.detach().requires_grad_(True) for p in adjoint_params)  # same storage, no copy
+        evaluate = lambda t_, y_: torch.func.functional_call(module, dict(zip(order, aliases)), (t_, y_))  # noqa: E731
+        f, vjp_t, vjp_y, vjp_params = _vjp_of(evaluate, t, y_aug[1], aliases, -y_aug[2], t_requires_grad, retain=False)
+        return (vjp_t, f, vjp_y, *vjp_params)
 
     return augmented_dynamics
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# captured dynamics (adjoint_options["graph_func"])
+# ----------------------------------------------------------------------------------------------------------------------
 _GRAPH_CACHE = weakref.WeakKeyDictionary()  # func module -> {signature: GraphedFunc}; captures are reused across calls
 
 MAX_GRAPHS_PER_MODULE = 8  # captured dynamics kept per module (each holds static buffers of the state's size)
@@ -146,8 +220,6 @@ class _NoGraph:
 
 def _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options):
     """Whether adjoint_options["graph_func"] = "auto" captures the augmented dynamics for this call."""
-    import threading
-
     if not (isinstance(func, nn.Module) and torch.is_tensor(y0) and y0.is_cuda):
         return False
     if threading.current_thread() is not threading.main_thread() or torch.cuda.is_current_stream_capturing():
@@ -173,144 +245,193 @@ def _graph_time_examples(adjoint_method, adjoint_options, t_span, y0):
     return [torch.zeros((), dtype=d, device=dev) for d in dtypes]
 
 
+def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoint_params):
+    """Resolve ``adjoint_options["graph_func"]`` and return the captured FLAT augmented dynamics, or None for the eager one.
+
+    The augmented dynamics (func forward + autograd vjp, ~30 eager launches) is captured into one HIP graph per time-argument
+    signature and replayed (config 3's backward: 105 -> 34 ms).  True (or a dict that caches captures across calls) forces it;
+    False switches it off; absent / "auto" (the default) uses it when it pays and is safe: a small state (launch-bound), an nn.Module
+    func whose parameters are the adjoint parameters, several output intervals to amortise the capture over (or a capture already
+    cached for this module), the main thread, no capture in progress, no per-evaluation all-reduce — and falls back to the eager
+    dynamics if the capture fails.  The capture has to happen in the caller of the autograd node — on the calling thread and outside
+    the node: capturing from the engine's worker thread (where backward runs), or inside its forward while the parameters are its
+    inputs, crashes the runtime."""
+    mode = adjoint_options.pop("graph_func", "auto")
+    forced = mode is True or isinstance(mode, dict)
+    if mode == "auto":
+        mode = _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options)
+    if not mode:
+        return None
+    from ..utils.graphed import GraphedFunc
+
+    if not isinstance(func, nn.Module):
+        raise NotImplementedError("adjoint_options['graph_func'] needs func to be an nn.Module")
+    cache = mode if isinstance(mode, dict) else _GRAPH_CACHE.setdefault(func, {})
+    time_grad = bool(t_span.requires_grad)
+    fixed = _is_fixed(adjoint_solver)
+    # (the captured kernels address the parameters' storage: a parameter whose storage was swapped — `p.data = ...` — needs a new
+    # capture, an in-place update such as an optimiser step does not)
+    key = ("aug-flat", tuple(y0.shape), y0.dtype, str(y0.device), time_grad, fixed, tuple((id(p), p.data_ptr()) for p in adjoint_params))
+    graphed = cache.get(key)
+    if isinstance(graphed, _NoGraph):
+        return None
+    # the augmented state in the flat, 16-byte-segment layout the backward will use
+    example = [torch.zeros([], dtype=y0.dtype, device=y0.device), y0.detach(), torch.zeros_like(y0)] + [torch.zeros_like(p) for p in adjoint_params]
+    adt, segs, total = _segment_layout(example)
+    if graphed is None:
+        dyn = _make_functional_dynamics(func, adjoint_params, time_grad)
+        (s1, n1), (s2, n2) = segs[1], segs[2]
+        yshape, dev = tuple(y0.shape), y0.device
+
+        def flat_dynamics(t, yf):
+            # unpack views -> func + vjp -> pack, all inside ONE captured graph
+            v = yf[0] if fixed else yf
+            k = _pack(dyn(t, (None, v[s1 : s1 + n1].view(yshape), v[s2 : s2 + n2].view(yshape))), segs, total, adt, dev)
+            return k[None, :] if fixed else k
+
+        graphed = GraphedFunc(flat_dynamics, clone_outputs=True)
+        while len(cache) >= MAX_GRAPHS_PER_MODULE:  # a loop over many batch shapes must not pile up captures (oldest first)
+            cache.pop(next(iter(cache)))
+        cache[key] = graphed
+    flat_ex = _pack(example, segs, total, adt, y0.device)
+    flat_ex = flat_ex[None, :] if fixed else flat_ex
+    try:
+        for t_ex in _graph_time_examples(adjoint_solver, adjoint_options, t_span, y0):
+            graphed.prepare(t_ex, flat_ex)
+    except Exception:
+        if forced:
+            raise
+        # "auto": this func cannot be captured (host synchronisation, unsupported op, ...): eager dynamics, and no second attempt
+        # for this module and signature
+        cache[key] = _NoGraph()
+        return None
+    return None if graphed.refused else graphed
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the backward sweep                                                          (reference: odeint_adjoint.py:47-167)
+# ----------------------------------------------------------------------------------------------------------------------
+class _BackwardPlan(NamedTuple):
+    func: Any
+    solver: Any  # the adjoint solver class
+    rtol: float
+    atol: float
+    options: dict  # solver options of the backward solves ("norm" resolved)
+    time_grad: bool
+    graphed: Any  # captured flat dynamics or None
+    replay_intervals: Any  # parity harness: one prescribed (dt, accept) table per interval, in the order the intervals are run
+    forward_is_fixed: bool
+    y0_shape: tuple
+
+
+class _AugmentedState:
+    """``(adj_t, y, adj_y, *adj_theta)`` kept in ONE flat buffer with 16-byte-aligned segments for the whole sweep."""
+
+    def __init__(self, y_last, grad_last, adjoint_params):
+        parts = [torch.zeros([], dtype=y_last.dtype, device=y_last.device), y_last, grad_last]
+        parts += [torch.zeros_like(p) for p in adjoint_params]
+        self.shapes = [tuple(x.shape) for x in parts]
+        self.dtype, self.segs, self.total = _segment_layout(parts)
+        self.flat = _pack(parts, self.segs, self.total, self.dtype, y_last.device)
+
+    def _slice(self, i):
+        start, count = self.segs[i]
+        return self.flat[start : start + count]
+
+    def subtract_from_adj_t(self, value):
+        self._slice(0).sub_(value.to(self.dtype))
+
+    def restart_interval(self, y_saved, grad_here):
+        """After an interval's solve: the forward pass's own state replaces the re-integrated one (:155-156), the loss gradient at
+        this output time joins the adjoint (:157-159)."""
+        self._slice(1).copy_(y_saved.reshape(-1))
+        self._slice(2).add_(grad_here.reshape(-1))
+
+    def views(self):
+        return [self._slice(i).view(shape) for i, shape in enumerate(self.shapes)]
+
+
+def _check_sharded_backward(plan, pg, norm_spec, reduce_params):
+    fixed = _is_fixed(plan.solver)
+    if norm_spec is None and not fixed:
+        raise NotImplementedError(
+            "a batch-sharded odeint_adjoint needs the default adjoint norm or \"seminorm\" (a user norm callable "
+            "cannot be all-reduced)")
+    if plan.graphed is not None and (reduce_params or plan.time_grad):
+        raise NotImplementedError(
+            "adjoint_options['graph_func'] with a process_group needs the \"seminorm\" adjoint norm and no time "
+            "gradients (the captured dynamics cannot hold the per-evaluation all-reduce)")
+
+
+def _sweep(plan, t_span, y_ans, grad_y, adjoint_params):
+    """Integrate the augmented system from the last output time back to the first; returns ``(adj_y0, grad_t_span | None,
+    [adj_theta ...])``."""
+    n_times = len(t_span)
+    y_ans = _time_first(y_ans, plan.y0_shape, n_times, plan.forward_is_fixed)
+    grad_y = _time_first(grad_y, plan.y0_shape, n_times, plan.forward_is_fixed)
+    state = _AugmentedState(y_ans[-1], grad_y[-1], adjoint_params)
+
+    # batch-sharded backward: which of the row-summed adjoints are kept global during the solve (see _make_augmented_dynamics);
+    # the others are per-rank partial sums until the one all-reduce at the end
+    pg = plan.options.get("process_group")
+    norm = plan.options.get("norm")
+    spec = native_norm_spec(norm)
+    params_steer = not (isinstance(norm, SegmentMaxNorm) and not norm.watches_parameters)
+    reduce_params = pg is not None and not _is_fixed(plan.solver) and params_steer  # (a fixed grid has no step control)
+    if pg is not None:
+        _check_sharded_backward(plan, pg, spec, reduce_params)
+    dynamics = _make_augmented_dynamics(plan.func, adjoint_params, plan.time_grad, pg, reduce_params)
+    solve_options = dict(plan.options)
+    if plan.graphed is not None:
+        # the captured FLAT dynamics (same segment layout) replaces the unpack -> dynamics -> pack wrapper: 2 input copies + 1 replay
+        # + 1 clone per evaluation
+        solve_options["_xde_flat_func"] = plan.graphed
+
+    grad_t = torch.empty(n_times, dtype=t_span.dtype, device=t_span.device) if plan.time_grad else None
+    t_host = t_span.detach().to("cpu")  # one device->host read of the output times for all intervals
+    for i in range(n_times - 1, 0, -1):
+        if plan.time_grad:
+            # moving the output time t_i moves the loss by f(t_i, y_i) . dL/dy_i (:137-141)
+            moved = plan.func(t_span[i], y_ans[i]).reshape(-1).dot(grad_y[i].reshape(-1))
+            if pg is not None:  # a sum over rows: global, like adj_t itself
+                (moved,) = _group_sum([moved], pg)
+            state.subtract_from_adj_t(moved)
+            grad_t[i] = moved
+        if plan.replay_intervals is not None:
+            solve_options["_replay"] = plan.replay_intervals[n_times - 1 - i]
+        rows = _odeint_packed(dynamics, state.flat, state.segs, state.shapes, t_host[i - 1 : i + 1].flip(0), plan.solver,
+                              rtol=plan.rtol, atol=plan.atol, options=solve_options)
+        state.flat = rows[1]  # the value at t[i-1] (a fresh row: the solver never aliases its input)
+        state.restart_interval(y_ans[i - 1], grad_y[i - 1])
+
+    parts = state.views()
+    if plan.time_grad:
+        grad_t[0] = parts[0]
+    adj_params = parts[_N_LEADING:]
+    if pg is not None and not reduce_params and len(adj_params):
+        # per-rank partial sums so far ("seminorm" never looks at them): ONE all-reduce makes them the gradient of the global loss,
+        # identical on every rank — the same thing the default norm's path returns
+        adj_params = _group_sum(list(adj_params), pg)
+    return parts[2].reshape(plan.y0_shape), grad_t, list(adj_params)
+
+
 class OdeintAdjointMethod(torch.autograd.Function):
-    @staticmethod
-    def forward(
-        ctx,
-        func,
-        y0,
-        t_span,
-        rtol,
-        atol,
-        method,
-        options,
-        event_fn,
-        adjoint_rtol,
-        adjoint_atol,
-        adjoint_method,
-        adjoint_options,
-        t_requires_grad,
-        *adjoint_params,
-    ):
-        ctx.func = func
-        ctx.adjoint_rtol = adjoint_rtol
-        ctx.adjoint_atol = adjoint_atol
-        ctx.adjoint_method = adjoint_method
-        ctx.adjoint_options = adjoint_options
-        ctx.t_requires_grad = t_requires_grad
-        ctx.fixed_layout = _is_fixed(method)
-        ctx.y0_shape = tuple(y0.shape)
-
-        with torch.no_grad():
-            ans = odeint(func, y0, t_span, solver=method, rtol=rtol, atol=atol, options=options)
-            ctx.save_for_backward(t_span, ans, *adjoint_params)
-
-        return ans
+    """Forward: the plain solve, recording nothing (:37-43).  Backward: ``_sweep``."""
 
     @staticmethod
-    def backward(ctx, grad_y):
+    def forward(ctx, plan, forward_solve, y0, t_span, *adjoint_params):
+        ctx.plan = plan
         with torch.no_grad():
-            func = ctx.func
-            adjoint_rtol = ctx.adjoint_rtol
-            adjoint_atol = ctx.adjoint_atol
-            adjoint_method = ctx.adjoint_method
-            adjoint_options = ctx.adjoint_options
-            t_requires_grad = ctx.t_requires_grad
+            answer = forward_solve(y0, t_span)
+        ctx.save_for_backward(t_span, answer, *adjoint_params)
+        return answer
 
-            t_span, y_ans, *adjoint_params = ctx.saved_tensors
-            adjoint_params = tuple(adjoint_params)
-            T = len(t_span)
-            # [-1] indexing below assumes time-first (odeint_adjoint.py:75-79)
-            y_ans = _time_first(y_ans, ctx.y0_shape, T, ctx.fixed_layout)
-            grad_y = _time_first(grad_y, ctx.y0_shape, T, ctx.fixed_layout)
-
-            ##################################
-            #      Set up initial state      #
-            ##################################
-            # (adj_t, y, adj_y, *adj_params) — odeint_adjoint.py:85-87 — kept between intervals in the flat, 16-byte-segment
-            # layout the kernels integrate (the reference rebuilds the tuple each time; same values, ~15 launches fewer)
-            aug_state = [torch.zeros([], dtype=y_ans.dtype, device=y_ans.device), y_ans[-1], grad_y[-1]]
-            aug_state.extend([torch.zeros_like(param) for param in adjoint_params])
-            shapes = [tuple(x.shape) for x in aug_state]
-            adt, segs, total = _segment_layout(aug_state)
-            flat = _pack(aug_state, segs, total, adt, y_ans.device)
-            (s_t, _), (s_y, n_y), (s_a, n_a) = segs[0], segs[1], segs[2]
-
-            ##################################
-            #    Set up backward ODE func    #
-            ##################################
-            # batch-sharded backward: which of the row-summed adjoints are kept global during the solve (see
-            # _make_augmented_dynamics); the others are per-rank partial sums until the one all-reduce at the end
-            pg = adjoint_options.get("process_group")
-            spec = native_norm_spec(adjoint_options.get("norm"))
-            reduce_params = (pg is not None and not _is_fixed(adjoint_method)  # (a fixed grid has no step control)
-                             and not (spec is not None and spec[0] == "mixed" and spec[1] is not None))
-            if pg is not None and spec is None and not _is_fixed(adjoint_method):
-                raise NotImplementedError(
-                    "a batch-sharded odeint_adjoint needs the default adjoint norm or \"seminorm\" (a user norm callable "
-                    "cannot be all-reduced)")
-            if pg is not None and adjoint_options.get("_graphed") is not None and (reduce_params or t_requires_grad):
-                raise NotImplementedError(
-                    "adjoint_options['graph_func'] with a process_group needs the \"seminorm\" adjoint norm and no time "
-                    "gradients (the captured dynamics cannot hold the per-evaluation all-reduce)")
-            augmented_dynamics = _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg, reduce_params)
-            solver_options = {k: v for k, v in adjoint_options.items() if k not in ("graph_func", "_graphed", "_replay_intervals")}
-            # parity harness: one prescribed (dt, accept) table per interval's solve, in the order the intervals are run
-            replay_intervals = adjoint_options.get("_replay_intervals")
-            if adjoint_options.get("_graphed") is not None:
-                # the captured FLAT dynamics (same segment layout) replaces the unpack -> dynamics -> pack wrapper:
-                # 2 input copies + 1 replay + 1 clone per evaluation
-                solver_options["_xde_flat_func"] = adjoint_options["_graphed"]
-
-            ##################################
-            #       Solve adjoint ODE        #
-            ##################################
-            if t_requires_grad:
-                grad_t_span = torch.empty(T, dtype=t_span.dtype, device=t_span.device)
-            else:
-                grad_t_span = None
-            # one device->host read of the output times for all intervals (each inner odeint would otherwise do its own)
-            t_host = t_span.detach().to("cpu")
-            for i in range(T - 1, 0, -1):
-                if t_requires_grad:
-                    func_eval = func(t_span[i], y_ans[i])
-                    dLd_cur_t = func_eval.reshape(-1).dot(grad_y[i].reshape(-1))
-                    if pg is not None:  # a sum over rows: global, like adj_t itself
-                        (dLd_cur_t,) = _group_sum([dLd_cur_t], pg)
-                    flat[s_t] -= dLd_cur_t.to(adt)  # aug_state[0] = aug_state[0] - dLd_cur_t
-                    grad_t_span[i] = dLd_cur_t
-
-                if replay_intervals is not None:
-                    solver_options["_replay"] = replay_intervals[T - 1 - i]
-
-                # Run the augmented system backwards in time.
-                sol = _odeint_packed(
-                    augmented_dynamics,
-                    flat,
-                    segs,
-                    shapes,
-                    t_host[i - 1 : i + 1].flip(0),
-                    adjoint_method,
-                    rtol=adjoint_rtol,
-                    atol=adjoint_atol,
-                    options=solver_options,
-                )
-                flat = sol[1]  # extract just the t[i - 1] value (a fresh row: the solver never aliases its input)
-                flat[s_y : s_y + n_y].copy_(y_ans[i - 1].reshape(-1))  # use our forward-pass estimate of the state
-                flat[s_a : s_a + n_a].add_(grad_y[i - 1].reshape(-1))  # gradients wrt state at this time point
-
-            aug_state = [flat[s : s + n].view(shape) for (s, n), shape in zip(segs, shapes)]
-            if t_requires_grad:
-                grad_t_span[0] = aug_state[0]
-
-            adj_y = aug_state[2].reshape(ctx.y0_shape)  # D6: returned (the reference drops it)
-            adj_params = aug_state[3:]
-            if pg is not None and not reduce_params and len(adj_params):
-                # per-rank partial sums so far ("seminorm" never looks at them): ONE all-reduce makes them the gradient of
-                # the global loss, identical on every rank — the same thing the default norm's path returns
-                adj_params = _group_sum(list(adj_params), pg)
-
-        return (None, adj_y, grad_t_span, None, None, None, None, None, None, None, None, None, None, *adj_params)
+    @staticmethod
+    def backward(ctx, grad_answer):
+        t_span, answer, *adjoint_params = ctx.saved_tensors
+        with torch.no_grad():
+            adj_y0, grad_t, adj_params = _sweep(ctx.plan, t_span, answer, grad_answer, tuple(adjoint_params))
+        return (None, None, adj_y0, grad_t, *adj_params)  # D6: adj_y0 is returned (the reference drops it)
 
 
 def odeint_adjoint(
@@ -329,180 +450,42 @@ def odeint_adjoint(
     adjoint_options=None,
     adjoint_params=None,
 ):
-    # odeint_adjoint.py:186-193
+    """Same signature, defaults and error behaviour as the reference's (:170-257)."""
     if adjoint_params is None and not isinstance(func, nn.Module):
         raise ValueError(
             "func must be an instance of nn.Module to specify the adjoint parameters; alternatively they "
             "can be specified explicitly via the `adjoint_params` argument. If there are no parameters "
             "then it is allowable to set `adjoint_params=()`."
         )
-
-    if adjoint_rtol is None:
-        adjoint_rtol = rtol
-    if adjoint_atol is None:
-        adjoint_atol = atol
-    if adjoint_solver is None:
-        adjoint_solver = solver
-
-    if adjoint_solver != solver and options is not None and adjoint_options is None:
+    # the backward solve inherits what it was not given from the forward solve ...
+    adjoint_rtol = rtol if adjoint_rtol is None else adjoint_rtol
+    adjoint_atol = atol if adjoint_atol is None else adjoint_atol
+    inherit_solver = adjoint_solver is None
+    adjoint_solver = solver if inherit_solver else adjoint_solver
+    # ... except options across different solvers
+    if adjoint_options is None and options is not None and adjoint_solver != solver:
         raise ValueError(
             "If `adjoint_method != method` then we cannot infer `adjoint_options` from `options`. So as "
             "`options` has been passed then `adjoint_options` must be passed as well."
         )
-
     if adjoint_options is None:
-        adjoint_options = {k: v for k, v in options.items() if k != "norm"} if options is not None else {}
+        adjoint_options = {k: v for k, v in (options or {}).items() if k != "norm"}
     else:
-        adjoint_options = adjoint_options.copy()
+        adjoint_options = dict(adjoint_options)  # the caller's dict is never modified
 
-    if adjoint_params is None:
-        adjoint_params = tuple(find_parameters(func))
-    else:
-        adjoint_params = tuple(adjoint_params)
-
-    oldlen_ = len(adjoint_params)
-    adjoint_params = tuple(p for p in adjoint_params if p.requires_grad)
-    if len(adjoint_params) != oldlen_:
-        if "norm" in adjoint_options and callable(adjoint_options["norm"]):
-            warnings.warn(
-                "An adjoint parameter was passed without requiring gradient. For efficiency this will be "
-                "excluded from the adjoint pass, and will not appear as a tensor in the adjoint norm."
-            )
-
-    state_norm = options["norm"]
-    handle_adjoint_norm_(adjoint_options, None, state_norm)
-
+    wanted = _adjoint_parameters(func, adjoint_params, norm_is_users=callable(adjoint_options.get("norm")))
+    adjoint_options["norm"] = _resolve_adjoint_norm(adjoint_options, options["norm"])
     if not torch.is_tensor(t_span):
         t_span = torch.as_tensor(t_span)
 
-    # adjoint_options["graph_func"]: the augmented dynamics (func forward + autograd vjp, ~30 eager launches) captured into one
-    # HIP graph per time-argument signature and replayed (config 3's backward: 105 -> 34 ms).  True (or a dict that caches
-    # captures across calls) forces it; False switches it off; absent / "auto" (the default) uses it when it pays and is safe:
-    # a small state (launch-bound), an nn.Module func whose parameters are the adjoint parameters, several output intervals to
-    # amortise the capture over (or a capture already cached for this module), the main thread, no capture in progress, no
-    # per-evaluation all-reduce — and falls back to the eager dynamics if the capture fails.
-    # The capture has to happen HERE — on the calling thread and outside the autograd Function: capturing from the engine's
-    # worker thread (where backward runs), or inside Function.forward while the parameters are its inputs, crashes the runtime.
-    mode = adjoint_options.get("graph_func", "auto")
-    forced = mode is True or isinstance(mode, dict)
-    if mode == "auto":
-        adjoint_options.pop("graph_func", None)
-        mode = _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options)
-    if mode:
-        from ..utils.graphed import GraphedFunc
+    graphed = _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, wanted)
+    plan = _BackwardPlan(
+        func=func, solver=adjoint_solver, rtol=adjoint_rtol, atol=adjoint_atol,
+        options={k: v for k, v in adjoint_options.items() if k != "_replay_intervals"},
+        time_grad=bool(t_span.requires_grad), graphed=graphed, replay_intervals=adjoint_options.get("_replay_intervals"),
+        forward_is_fixed=_is_fixed(solver), y0_shape=tuple(y0.shape))
 
-        if not isinstance(func, nn.Module):
-            raise NotImplementedError("adjoint_options['graph_func'] needs func to be an nn.Module")
-        if isinstance(mode, dict):
-            cache = mode
-        else:
-            cache = _GRAPH_CACHE.setdefault(func, {})
-        t_rg = bool(t_span.requires_grad)
-        fixed = _is_fixed(adjoint_solver)
-        # (the captured kernels address the parameters' storage: a parameter whose storage was swapped — `p.data = ...` —
-        # needs a new capture, an in-place update such as an optimiser step does not)
-        key = ("aug-flat", tuple(y0.shape), y0.dtype, str(y0.device), t_rg, fixed,
-               tuple((id(p), p.data_ptr()) for p in adjoint_params))
-        graphed = cache.get(key)
-        if isinstance(graphed, _NoGraph):
-            mode = False
-    if mode and not isinstance(cache.get(key), _NoGraph):
-        # the augmented state (adj_t, y, adj_y, *adj_params) in the flat, 16-byte-segment layout odeint() will use
-        aug_example = [torch.zeros([], dtype=y0.dtype, device=y0.device), y0.detach(), torch.zeros_like(y0)]
-        aug_example += [torch.zeros_like(p) for p in adjoint_params]
-        adt, segs, total = _segment_layout(aug_example)
-        if graphed is None:
-            dyn = _make_functional_dynamics(func, adjoint_params, t_rg)
-            (s1, n1), (s2, n2) = segs[1], segs[2]
-            yshape = tuple(y0.shape)
-            dev = y0.device
+    def forward_solve(y_start, times):
+        return odeint(func, y_start, times, solver=solver, rtol=rtol, atol=atol, options=options)
 
-            def flat_dynamics(t, yf):
-                # unpack views -> func + vjp -> pack, all inside ONE captured graph
-                v = yf[0] if fixed else yf
-                outs = dyn(t, (None, v[s1 : s1 + n1].view(yshape), v[s2 : s2 + n2].view(yshape)))
-                k = _pack(outs, segs, total, adt, dev)
-                return k[None, :] if fixed else k
-
-            graphed = GraphedFunc(flat_dynamics, clone_outputs=True)
-            while len(cache) >= MAX_GRAPHS_PER_MODULE:  # a loop over many batch shapes must not pile up captures (oldest first)
-                cache.pop(next(iter(cache)))
-            cache[key] = graphed
-        flat_ex = _pack(aug_example, segs, total, adt, y0.device)
-        flat_ex = flat_ex[None, :] if fixed else flat_ex
-        try:
-            for t_ex in _graph_time_examples(adjoint_solver, adjoint_options, t_span, y0):
-                graphed.prepare(t_ex, flat_ex)
-            if not graphed.refused:
-                adjoint_options["_graphed"] = graphed
-        except Exception:
-            if forced:
-                raise
-            # "auto": this func cannot be captured (host synchronisation, unsupported op, ...): eager dynamics, and no
-            # second attempt for this module and signature
-            cache[key] = _NoGraph()
-        if isinstance(cache.get(key), _NoGraph):
-            adjoint_options.pop("_graphed", None)
-
-    solution = OdeintAdjointMethod.apply(
-        func,
-        y0,
-        t_span,
-        rtol,
-        atol,
-        solver,
-        options,
-        event_fn,
-        adjoint_rtol,
-        adjoint_atol,
-        adjoint_solver,
-        adjoint_options,
-        t_span.requires_grad,
-        *adjoint_params,
-    )
-    return solution
-
-
-def find_parameters(module):
-    """odeint_adjoint.py:260-277"""
-    assert isinstance(module, nn.Module)
-    if getattr(module, "_is_replica", False):
-
-        def find_tensor_attributes(module):
-            return [(k, v) for k, v in module.__dict__.items() if torch.is_tensor(v) and v.requires_grad]
-
-        gen = module._named_members(get_members_fn=find_tensor_attributes)
-        return [param for _, param in gen]
-    return list(module.parameters())
-
-
-def handle_adjoint_norm_(adjoint_options, shapes, state_norm):
-    """In-place modifies the adjoint options to choose or wrap the norm function (odeint_adjoint.py:280-327).
-
-    The default and "seminorm" adjoint norms are max-over-segments of per-segment RMS values; when the state
-    norm is the native RMS they are tagged so the solver runs them as ONE segmented reduction kernel."""
-    state_is_rms = native_norm_spec(state_norm) == ("rms",)
-
-    def default_adjoint_norm(tensor_tuple):
-        t, y, adj_y, *adj_params = tensor_tuple
-        return max(t.abs(), state_norm(y), state_norm(adj_y), _mixed_norm(adj_params))
-
-    if state_is_rms:
-        default_adjoint_norm._xde_native = ("mixed", None)
-
-    if "norm" not in adjoint_options:
-        adjoint_options["norm"] = default_adjoint_norm
-    else:
-        adjoint_norm = adjoint_options["norm"]
-        if adjoint_norm == "seminorm":
-
-            def adjoint_seminorm(tensor_tuple):
-                t, y, adj_y, *adj_params = tensor_tuple
-                return max(t.abs(), state_norm(y), state_norm(adj_y))
-
-            if state_is_rms:
-                adjoint_seminorm._xde_native = ("mixed", 3)
-            adjoint_options["norm"] = adjoint_seminorm
-        else:
-            # the user's own norm over (t, y, adj_y, *adj_params): passed through unchanged (shapes is None)
-            pass
+    return OdeintAdjointMethod.apply(plan, forward_solve, y0, t_span, *wanted)
