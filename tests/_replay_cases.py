@@ -72,8 +72,9 @@ def _check(got, s, states, ref, so, ref_states, *, ratio_rtol, pipeline, ratio_a
     assert P.parity_ok(got, ref, rtol=1e-5, atol=dense_atol), ("solution", P.worst(got, ref, 1e-5, dense_atol))
     if label is not None:  # what was actually observed, next to the bar (print the worst ulp count)
         P.report(label, {"pipeline": pipeline, "attempts": int(mine.shape[0]),
-                         "worst_ulps_y1": max([P.worst_ulps(a, b) for a, b in zip(states, ref_states)], default=None) if pipeline == "sync" else None,
-                         "worst_ulps_rows": P.worst_ulps(got, ref), "allowed_ulps_y1": y_atol / float(np.spacing(np.float32(np.abs(ref).max()))),
+                         "worst_ulps_near_zero_y1": max([P.worst_ulps(a, b) for a, b in zip(states, ref_states)], default=None) if pipeline == "sync" else None,
+                         "worst_ulps_near_zero_rows": P.worst_ulps(got, ref), "bar_fraction_rows": P.worst(got, ref, 1e-5, dense_atol),
+                         "allowed_ulps_y1": y_atol / float(np.spacing(np.float32(np.abs(ref).max()))),
                          "allowed_ulps_rows": dense_atol / float(np.spacing(np.float32(np.abs(ref).max()))),
                          "worst_ratio_rel": float((np.abs(mine[:, 2] - theirs[:, 2]) / np.maximum(np.abs(theirs[:, 2]), 1e-300)).max())})
 

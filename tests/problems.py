@@ -150,10 +150,16 @@ def ulp_atol(ref, k, floor=1e-7):
     return max(floor, k * float(np.spacing(np.float32(np.abs(np.asarray(ref)).max()))))
 
 
-def worst_ulps(got, ref):
-    """Largest |got - ref| in units of one fp32 ulp at the scale of `ref` (its largest magnitude)."""
+def worst_ulps(got, ref, near_zero=1e-2):
+    """Largest |got - ref| over the elements whose |ref| is below `near_zero` x the state's scale — the elements for which the
+    bar's ABSOLUTE part decides — in units of one fp32 ulp at that scale (its largest magnitude).  This is the number to hold
+    against `ulp_atol(ref, k)`'s k."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    return float(np.abs(got - ref).max() / float(np.spacing(np.float32(np.abs(ref).max()))))
+    scale = np.abs(ref).max()
+    small = np.abs(ref) <= near_zero * scale
+    if not small.any():
+        return 0.0
+    return float(np.abs(got - ref)[small].max() / float(np.spacing(np.float32(scale))))
 
 
 def report(name, rec):

@@ -89,7 +89,8 @@ def test_full_size_replayed_vs_golden(name):
     got = sol[:, torch.from_numpy(z["rows"]).to(dev)].cpu().numpy()
     # relative part 1e-5 strictly; absolute part 4 ulp of the state's scale (dense-output rows of a GEMM func: P.ulp_atol)
     atol = P.ulp_atol(z["sol_abs_max"], 4)
-    P.report("full_size_replayed_vs_golden/" + name, {"worst_ulps_rows": P.worst_ulps(got, z["sol_rows"]), "allowed_ulps_rows": 4})
+    P.report("full_size_replayed_vs_golden/" + name, {"worst_ulps_near_zero_rows": P.worst_ulps(got, z["sol_rows"]), "allowed_ulps_rows": 4,
+                                                              "bar_fraction_rows": P.worst(got, z["sol_rows"], 1e-5, atol)})
     assert P.parity_ok(got, z["sol_rows"], rtol=1e-5, atol=atol), P.worst(got, z["sol_rows"], 1e-5, atol)
 
 
