@@ -25,8 +25,10 @@ taken after the timed region, so a strong-scaling efficiency can be computed fro
 value = states/sec = (global batch * dim) / (wall time per attempted step), whole job.
 roofline: algorithmic bytes of the stage-combine kernel (sum over the 6 stages of (operands + 2) *
 N * 4 B = 32 N * 4 B per step) / its launch durations measured with HIP events on the launch stream.
-cpu_baseline: the numpy oracle (op-for-op restatement of the reference's eager op sequence) timed on the
-host cores of this box on a bounded sample (smaller batch, same dim/tolerances).
+cpu_baseline: "B1", the oracle's torch-CPU twin (op-for-op restatement of the reference's eager op sequence — the reference's
+Paddle CPU path itself cannot run: Paddle is not installed and the reference never travels to the GPU box), timed on the host cores
+of this box on a bounded sample (~10 s of attempted steps at the SAME batch x dim); cpu_baseline_fused: "B2", the same step on fused
+C/OpenMP kernels (oracle/xde_cpu_kernels.c) — the strong CPU baseline.
 """
 import argparse
 import json
@@ -124,7 +126,8 @@ def cpu_baseline(B, D, budget_s=10.0):
     }
     # B2: the strong CPU baseline — the same step on fused C + OpenMP kernels (oracle/xde_cpu_kernels.c: one
     # pass per stage, error estimate fused into the last stage and the norm pass, like the HIP path), func = the
-    # framework's multi-threaded CPU GEMM.  It is the reported cpu_baseline; B1 rides along as cpu_baseline_eager.
+    # framework's multi-threaded CPU GEMM.  B1 — the reference's own op sequence, which is what "the reference's CPU path"
+    # means — is the reported cpu_baseline; B2 rides along as cpu_baseline_fused.
     try:
         from oracle import xde_cpu_fused as F
 
@@ -148,8 +151,8 @@ def cpu_baseline(B, D, budget_s=10.0):
             "sample": "B2: fused C/OpenMP statement of the step (oracle/xde_cpu_kernels.c) + torch-CPU GEMM for func, {} attempted dopri5 "
                       "steps, batch {} x dim {} fp32, {:.1f} s, {} threads".format(n2, B, D, el2, cores),
         }
-        return fused, eager
-    except Exception as e:  # no compiler on the box: report the eager port
+        return eager, fused
+    except Exception as e:  # no compiler on the box: the eager port alone
         eager["sample"] += " (B2 unavailable: {})".format(type(e).__name__)
         return eager, None
 
@@ -785,9 +788,9 @@ def main():
         out["solver_only_states_per_s"] = N_local / (solver_ms * 1e-3) if solver_ms > 0 else None
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
-        out["cpu_baseline"], eager = cpu_baseline(B, D)
-        if eager is not None:
-            out["cpu_baseline_eager"] = eager
+        out["cpu_baseline"], fused = cpu_baseline(B, D)
+        if fused is not None:
+            out["cpu_baseline_fused"] = fused
 
     if world > 1 and scaling == "strong" and not args.no_n1 and rank == 0:
         # the same GLOBAL problem on this rank alone, so that a strong-scaling efficiency can be computed from this one line
