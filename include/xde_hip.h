@@ -386,6 +386,10 @@ int xde_graph_replace_memsets(void* hip_graph, int* n_replaced);
  * overwrites sums_dev with their sum (XDE_NORM_LINF: max for the first XDE_MAX_SEG entries) taken in RANK ORDER —
  * bit-identical on every rank.  Ranks must call it the same number of times (lock-step, as the solver's ranks are).
  *   peer_mailboxes: host array of `world` device pointers, peer_mailboxes[rank] == local_mailbox.
+ * Failure is group-wide: the rank whose wait ran out also marks every PEER's mailbox, so a peer still waiting stops inside
+ * its wait and a peer that had already completed that exchange stops at its next one — no rank runs on alone, none posts again.
+ *   xde_p2p_error: error_out[3] = {exchange number of the first failed exchange on this rank (0 = none), exchange number a
+ *   peer reported (0 = none), that peer's rank + 1}.
  */
 #define XDE_P2P_MAX_RANKS 16
 #define XDE_P2P_HANDLE_BYTES 64

@@ -14,8 +14,14 @@
 //   wait   rank p polls its own slot[q % S].flag[0..N) until all equal q (bounded: a peer that never arrives raises an
 //          error flag instead of hanging the GPU);
 //   sum    data[0] (+|max) data[1] ... data[N-1], left to right.
+//   fail   a rank whose wait runs out marks its own mailbox (`error`), tells every peer (`abort`, `abort_by` in THEIR mailboxes)
+//          and hands its controller a "stop" vector.  A peer that is still waiting sees `abort` inside its polling loop; a peer
+//          that had already completed exchange q sees it at the start of exchange q + 1.  Either way every rank of the group
+//          stops within one exchange of the first failure, and none of them posts again (a failed group never half-proceeds).
 // A rank can be at most one exchange ahead of another (it needs everybody's vector q to finish exchange q), so a ring of
 // S >= 2 slots is never overwritten while it is still being read; S = 4.
+
+#include <cstddef>
 
 #include "xde_common.hpp"
 
@@ -33,8 +39,10 @@ struct P2PSlot {
 
 struct P2PMailbox {
   int64_t xseq;   // exchanges started by the owner (device-resident so that a replayed hipGraph advances it)
-  int64_t error;  // exchange number of the first timeout, 0 = none (sticky)
-  int64_t pad[14];
+  int64_t error;  // exchange number of the first failed exchange on the owner, 0 = none (sticky)
+  int64_t abort;  // written by a PEER whose wait ran out: the exchange number it failed at (sticky)
+  int64_t abort_by;  // that peer's rank + 1
+  int64_t pad[12];
   P2PSlot slot[kP2PSlots];
 };
 
@@ -45,17 +53,22 @@ struct Peers {
 __global__ __launch_bounds__(64) void xde_p2p_exchange_kernel(double* sums, P2PMailbox* local, Peers peers, int world,
                                                               int rank, int norm_kind, int64_t spin_limit) {
   __shared__ int64_t s_seq;
-  __shared__ int s_timeout;
+  __shared__ int s_timeout;  // this rank's own wait ran out
+  __shared__ int s_aborted;  // a peer said so, or an earlier exchange had already failed here
   const int lane = threadIdx.x;
   if (lane == 0) {
     const int64_t q = local->xseq + 1;
     local->xseq = q;
     s_seq = q;
     s_timeout = 0;
+    s_aborted = (local->error != 0 || __hip_atomic_load(&local->abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1 : 0;
   }
   __syncthreads();
   const int64_t q = s_seq;
   const int sl = int(q % kP2PSlots);
+  const bool dead_on_entry = s_aborted != 0;  // (uniform: read before anybody can set it below)
+  __syncthreads();
+  if (!dead_on_entry) {
 
   // ---- post: 32 lanes x N peers write-through stores over xGMI (uncached destination) ----
   if (lane < kVec) {
@@ -72,6 +85,10 @@ __global__ __launch_bounds__(64) void xde_p2p_exchange_kernel(double* sums, P2PM
   if (lane < world) {
     int64_t spins = 0;
     while (__hip_atomic_load(&local->slot[sl].flag[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != q) {
+      if (__hip_atomic_load(&local->abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+        s_aborted = 1;
+        break;
+      }
       if (++spins > spin_limit) {
         s_timeout = 1;
         break;
@@ -79,14 +96,21 @@ __global__ __launch_bounds__(64) void xde_p2p_exchange_kernel(double* sums, P2PM
       __builtin_amdgcn_s_sleep(2);
     }
   }
+  }  // !dead_on_entry
   __syncthreads();
   __threadfence_system();
+  const bool failed = s_timeout != 0 || s_aborted != 0;
+  if (s_timeout != 0 && lane < world && lane != rank) {
+    // tell the peers: they stop at once (inside their wait) or at their next exchange, instead of one timeout later
+    __hip_atomic_store(&peers.p[lane]->abort_by, int64_t(rank) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&peers.p[lane]->abort, q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 
   // ---- sum in rank order ----
   if (lane < kVec) {
     double acc;
-    if (s_timeout) {
-      // a peer never arrived: make the controller stop the solve (non-finite count > 0 -> XDE_STATUS_NONFINITE); the host
+    if (failed) {
+      // a peer never arrived (or reported that one did not): make the controller stop the solve (non-finite count > 0 -> XDE_STATUS_NONFINITE); the host
       // finds the mailbox's error flag and reports the exchange, not the state
       acc = lane < XDE_MAX_SEG ? 0.0 : 1.0;
     } else {
@@ -101,7 +125,7 @@ __global__ __launch_bounds__(64) void xde_p2p_exchange_kernel(double* sums, P2PM
     }
     sums[lane] = acc;
   }
-  if (lane == 0 && s_timeout && local->error == 0) local->error = q;
+  if (lane == 0 && failed && local->error == 0) local->error = q;
 }
 
 }  // namespace
@@ -181,7 +205,9 @@ int xde_p2p_exchange(double* sums_dev, void* local_mailbox, void* const* peer_ma
 int xde_p2p_error(const void* local_mailbox, int64_t* error_out, void* stream) {
   if (!local_mailbox || !error_out) return fail(XDE_EBADARG, "xde_p2p_error: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  HIP_TRY(hipMemcpyAsync(error_out, &static_cast<const P2PMailbox*>(local_mailbox)->error, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  // {error, abort, abort_by} are adjacent words of the mailbox
+  static_assert(offsetof(P2PMailbox, abort_by) == offsetof(P2PMailbox, error) + 2 * sizeof(int64_t), "mailbox header layout");
+  HIP_TRY(hipMemcpyAsync(error_out, &static_cast<const P2PMailbox*>(local_mailbox)->error, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return XDE_OK;
 }

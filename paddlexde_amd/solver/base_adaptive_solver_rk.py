@@ -564,8 +564,10 @@ class AdaptiveRKSolver(AdaptiveSolver):
             raise AssertionError(_STATUS_MSG[c.status].format(c.dt))
         if c.status == _hip.STATUS_NONFINITE:
             if self.norm_exchange is not None and self.norm_exchange.error():
-                raise _hip.XdeError("peer-to-peer norm exchange {} timed out: a rank of the process group did not arrive "
-                                    "(died, or fell out of lock-step)".format(self.norm_exchange.error()))
+                q, by = self.norm_exchange.error_info()
+                raise _hip.XdeError("peer-to-peer norm exchange {} timed out{}: a rank of the process group did not arrive "
+                                    "(died, or fell out of lock-step); every rank of the group stops".format(
+                                        q, "" if by is None else " on rank {}, which told this rank".format(by)))
             raise AssertionError(_STATUS_MSG[c.status].format("{} non-finite element(s)".format(int(c.nonfinite))))
         if c.status == _hip.STATUS_MAX_STEPS:
             raise AssertionError(_STATUS_MSG[c.status].format(c.steps_in_interval, self.max_num_steps))

@@ -73,11 +73,16 @@ class PeerExchange:
                                        self.SPIN_LIMIT, _hip.HipBackend._stream(sums))
         self._check(rc, "xde_p2p_exchange")
 
+    def error_info(self):
+        """``(exchange, reported_by)``: the number of the first failed exchange on this rank (0: none) and the rank whose wait ran
+        out first when this rank was told by a peer (None: this rank's own wait ran out).  One blocking 24-byte read."""
+        e = (C.c_int64 * 3)()
+        self._check(self.lib.xde_p2p_error(self._local, e, _hip.HipBackend._stream(torch.empty(0, device=self.device))), "xde_p2p_error")
+        return int(e[0]), (int(e[2]) - 1 if e[1] != 0 and e[2] > 0 else None)
+
     def error(self):
-        """Exchange number of the first timed-out exchange on this rank, or 0 (one blocking 8-byte read)."""
-        e = C.c_int64(0)
-        self._check(self.lib.xde_p2p_error(self._local, C.byref(e), _hip.HipBackend._stream(torch.empty(0, device=self.device))), "xde_p2p_error")
-        return int(e.value)
+        """Exchange number of the first failed exchange on this rank, or 0."""
+        return self.error_info()[0]
 
     def close(self):
         import torch.distributed as dist

@@ -367,6 +367,79 @@ def test_peer_exchange_gives_up_when_a_rank_never_arrives(tmp_path):
     assert open(tmp_path / "timeout1.txt").read() == "skipped"
 
 
+def _p2p_abort_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+
+        from paddlexde_amd.utils import PeerExchange
+
+        ex = PeerExchange()
+        rec = {}
+        try:
+            sums = torch.arange(32, dtype=torch.float64, device="cuda:0") * (rank + 1)
+            ex.exchange(sums, 0)  # exchange 1: everybody arrives
+            torch.cuda.synchronize()
+            rec["first_ok"] = bool(ex.error() == 0 and float(sums[1]) == sum(r + 1 for r in range(world)))
+            dist.barrier()
+            if rank == 0:
+                ex.SPIN_LIMIT = 20_000  # gives up after about a millisecond: ranks 1 and 2 are not there yet
+                t0 = time.perf_counter()
+                ex.exchange(sums, 0)
+                torch.cuda.synchronize()
+                rec["seconds"] = time.perf_counter() - t0
+                rec["info"] = list(ex.error_info())
+                dist.barrier()  # (a) rank 0 has failed and told its peers
+                dist.barrier()  # (b)
+            elif rank == 1:
+                dist.barrier()  # (a)
+                # this rank had completed exchange 1 and arrives at exchange 2 AFTER rank 0 gave up: with a spin limit worth many
+                # seconds it must still stop at once, because rank 0 marked this mailbox
+                ex.SPIN_LIMIT = 2_000_000_000
+                t0 = time.perf_counter()
+                ex.exchange(sums, 0)
+                torch.cuda.synchronize()
+                rec["seconds"] = time.perf_counter() - t0
+                rec["info"] = list(ex.error_info())
+                rec["stop_vector"] = bool(sums[:16].abs().sum().item() == 0.0 and (sums[16:] == 1.0).all())
+                # ... and so does every later exchange (the failure is sticky, nothing is posted any more)
+                ex.exchange(sums, 0)
+                torch.cuda.synchronize()
+                rec["info_after"] = list(ex.error_info())
+                dist.barrier()  # (b)
+            else:
+                dist.barrier()  # (a)
+                dist.barrier()  # (b) this rank never posts exchange 2 at all
+                rec["info"] = list(ex.error_info())  # it was told as well: its next exchange would stop at once
+        finally:
+            ex.close()
+        import json
+
+        with open(os.path.join(out_dir, "abort{}.json".format(rank)), "w") as fh:
+            json.dump(rec, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_peer_exchange_failure_stops_every_rank_of_the_group(tmp_path):
+    """'on timeout only the timing-out rank stops'.  Now the rank whose wait runs out marks every peer's mailbox:
+    a peer that arrives later — or is still waiting with a much longer limit — stops at once with the stop vector, names the rank
+    that told it, and never posts again; no rank of a failed group runs on alone.  Three ranks on one GPU."""
+    import json
+
+    mp.spawn(_p2p_abort_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    r0, r1, r2 = [json.load(open(tmp_path / "abort{}.json".format(r))) for r in range(3)]
+    assert r0["first_ok"] and r1["first_ok"] and r2["first_ok"]
+    assert r0["info"] == [2, None]  # its own wait ran out at exchange 2
+    assert r1["info"] == [2, 0] and r1["stop_vector"] and r1["seconds"] < 2.0, r1  # told by rank 0, at once (its own limit: minutes)
+    assert r1["info_after"] == [2, 0]
+    assert r2["info"] == [0, 0]  # never ran exchange 2, so no failure of its own yet — but it has been told by rank 0 as well
+
+
 def _nccl_adjoint_worker(rank, world, port, out_dir, norm):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
