@@ -116,6 +116,11 @@ template <> struct Pack<float, true> {
   __device__ void store(float* p, int64_t i) const {
     reinterpret_cast<float4*>(p)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
+  // streaming store (global_store_dwordx4 ... nt): for data nobody re-reads soon (solution rows)
+  __device__ void store_nt(float* p, int64_t i) const {
+    v4f_t x = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(x, reinterpret_cast<v4f_t*>(p) + i);
+  }
 };
 template <> struct Pack<double, true> {
   static constexpr int W = 2;
@@ -131,6 +136,10 @@ template <> struct Pack<double, true> {
   __device__ void store(double* p, int64_t i) const {
     reinterpret_cast<double2*>(p)[i] = make_double2(v[0], v[1]);
   }
+  __device__ void store_nt(double* p, int64_t i) const {
+    v2d_t x = {v[0], v[1]};
+    __builtin_nontemporal_store(x, reinterpret_cast<v2d_t*>(p) + i);
+  }
 };
 template <typename T> struct Pack<T, false> {
   static constexpr int W = 1;
@@ -138,6 +147,7 @@ template <typename T> struct Pack<T, false> {
   __device__ static Pack load(const T* p, int64_t i) { return Pack{{p[i]}}; }
   __device__ static Pack load_nt(const T* p, int64_t i) { return Pack{{__builtin_nontemporal_load(p + i)}}; }
   __device__ void store(T* p, int64_t i) const { p[i] = v[0]; }
+  __device__ void store_nt(T* p, int64_t i) const { __builtin_nontemporal_store(v[0], p + i); }
 };
 
 // dt and the operand select of this launch, read from the device control block.  Both fields are requested BEFORE either is
@@ -261,6 +271,8 @@ struct DenseArgs {
   // rows were evaluated (the destinations ARE the y0 / k[0] operands: each lane reads an element before it overwrites it)
   void* commit_y0;
   void* commit_f0;
+  int f1_is_last_k;  // f1 == k[nk-1] (an FSAL pair's dense output: the last mid operand IS f1): loaded once
+  int nt;            // cache policy: bit 0 = stream the operands that die with this step (y0, k_0..), bit 1 = stream the row stores
 };
 
 // fuse(dy, dt, y0): BaseODE `dy*dt + y0` (xde/base_ode.py:58) or, with damping, BaseDDE

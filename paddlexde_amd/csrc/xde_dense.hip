@@ -21,72 +21,106 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // K4: dense output (quartic through y0, y_mid, y1, f0, f1), coefficients never materialised
 // ------------------------------------------------------------------------------------------
-template <typename T, typename TT, bool VEC, bool COMMIT = false>
-__global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
+// interp_fit (utils/ode_utils.py:44-49) + interp_evaluate (:69-77), same op order
+template <typename T>
+__device__ __forceinline__ T quartic_(T y0v, T y1v, T f0v, T f1v, T ymid, T x, T dt) {
+  T ca = T(2) * dt * (f1v - f0v) - T(8) * (y1v + y0v) + T(16) * ymid;
+  T cb = dt * (T(5) * f0v - T(3) * f1v) + T(18) * y0v + T(14) * y1v - T(32) * ymid;
+  T cc = dt * (f1v - T(4) * f0v) - T(11) * y0v - T(5) * y1v + T(16) * ymid;
+  T cd = dt * f0v;
+  T total = y0v + x * cd;
+  T xp = x;
+  xp = xp * x;
+  total = total + xp * cc;
+  xp = xp * x;
+  total = total + xp * cb;
+  xp = xp * x;
+  total = total + xp * ca;
+  return total;
+}
+
+// One element range of the launch.  NK > 0: the operand count is a compile-time constant — every stream of a vector
+// (k_0..k_{NK-1}, y0, y1, f1) is requested BEFORE the first one is used (round 2's runtime loop had one load in flight
+// per lane and reached 0.53 of the HBM peak: 71 us for 9 N 4 B at config 2).  NK == 0: the generic loop (Dopri8's 13 operands).
+template <typename T, typename TT, int NK, bool VEC, bool COMMIT>
+__device__ __forceinline__ void dense_body(const DenseArgs& a, const T* y0, const T* k0, int ob, int oe, T dt, TT t0, TT t1) {
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
-  const xde_ctrl_t* c = a.ctrl;
-  if (!c->accept) return;  // nothing to emit, nothing to commit
-  const bool expected = !(a.expect_step >= 0 && c->n_steps != a.expect_step);
-  const int ob = c->out_begin, oe = expected ? c->out_end : c->out_begin;
-  if (!COMMIT && oe <= ob) return;
-  const int sel = a.use_sel ? (c->sel_used ? 1 : 0) : 0;
-  // (no __restrict__ on the operands the COMMIT variant also writes)
-  const T* y0 = static_cast<const T*>(a.y0[sel]);
-  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  constexpr int MAXK = NK > 0 ? NK : 1;
   const T* __restrict__ y1 = static_cast<const T*>(a.y1);
   const T* __restrict__ f1p = static_cast<const T*>(a.f1);
   T* out = static_cast<T*>(a.out_base);
   T* cy = static_cast<T*>(a.commit_y0);
   T* cf = static_cast<T*>(a.commit_f0);
-  const T dt = T(TT(c->dt_last));  // `dt.astype(y0.dtype)`
-  const TT t0 = TT(c->t0), t1 = TT(c->t1);
-  const int nk = a.nk;
+  const int nk = NK > 0 ? NK : a.nk;
+  const bool dead_nt = !COMMIT && (a.nt & 1);  // y0 and the k_j die with this step (the COMMIT variant overwrites y0 / f0 in place)
+  const bool rows_nt = (a.nt & 2) != 0;
+  const bool f1_last = a.f1_is_last_k != 0;
   const int64_t nvec = a.n / W;
   const int64_t stride = int64_t(gridDim.x) * kBlock;
-
-  auto eval = [&](T y0v, T y1v, T f0v, T f1v, T ymid, T x) -> T {
-    // interp_fit (utils/ode_utils.py:44-49) + interp_evaluate (:69-77), same op order
-    T ca = T(2) * dt * (f1v - f0v) - T(8) * (y1v + y0v) + T(16) * ymid;
-    T cb = dt * (T(5) * f0v - T(3) * f1v) + T(18) * y0v + T(14) * y1v - T(32) * ymid;
-    T cc = dt * (f1v - T(4) * f0v) - T(11) * y0v - T(5) * y1v + T(16) * ymid;
-    T cd = dt * f0v;
-    T total = y0v + x * cd;
-    T xp = x;
-    xp = xp * x;
-    total = total + xp * cc;
-    xp = xp * x;
-    total = total + xp * cb;
-    xp = xp * x;
-    total = total + xp * ca;
-    return total;
-  };
+  const T* kp[MAXK];
+  T cm[MAXK];
+  if (NK > 0) {
+    kp[0] = k0;
+#pragma unroll
+    for (int j = 1; j < MAXK; ++j) kp[j] = static_cast<const T*>(a.k[j]);
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) cm[j] = dt * T(a.mid[j]);  // `dt * self.mid`
+  }
+  // the output times of this step, as fractions of it (at most a handful; recomputed per vector when there are many)
+  constexpr int kXs = 4;
+  T xs[kXs];
+#pragma unroll
+  for (int r = 0; r < kXs; ++r) xs[r] = (ob + r < oe) ? T((TT(a.t_span[ob + r]) - t0) / (t1 - t0)) : T(0);
 
   for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
-    P y1v = P::load(y1, i);
-    P f1v = P::load(f1p, i);
     if (COMMIT && oe <= ob) {  // the common replay: no output time inside this step, only the state hand-over
+      P y1v = P::load(y1, i);
+      P f1v = P::load(f1p, i);
       y1v.store(cy, i);
       f1v.store(cf, i);
       continue;
     }
-    P y0v = P::load(y0, i);
-    P f0v = P::load(k0, i);
-    P acc;
-    for (int j = 0; j < nk; ++j) {
-      const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
-      P kk = (j == 0) ? f0v : P::load(kj, i);
-      T cj = dt * T(a.mid[j]);  // `dt * self.mid`
+    P y1v, f1v, y0v, f0v, acc;
+    if (NK > 0) {
+      P kk[MAXK];
 #pragma unroll
-      for (int w = 0; w < W; ++w) acc.v[w] = (j == 0) ? kk.v[w] * cj : acc.v[w] + kk.v[w] * cj;
+      for (int j = MAXK - 1; j >= 1; --j) kk[j] = load_sel<P>(kp[j], i, dead_nt && !(f1_last && j == MAXK - 1));
+      y1v = P::load(y1, i);
+      if (!(f1_last && MAXK > 1)) f1v = P::load(f1p, i);
+      y0v = load_sel<P>(y0, i, dead_nt);
+      kk[0] = load_sel<P>(kp[0], i, dead_nt);
+      if (f1_last && MAXK > 1) f1v = kk[MAXK - 1];
+      f0v = kk[0];
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        T s_ = kk[0].v[w] * cm[0];
+#pragma unroll
+        for (int j = 1; j < MAXK; ++j) s_ = s_ + kk[j].v[w] * cm[j];
+        acc.v[w] = s_;
+      }
+    } else {
+      y1v = P::load(y1, i);
+      f1v = P::load(f1p, i);
+      y0v = P::load(y0, i);
+      f0v = P::load(k0, i);
+      for (int j = 0; j < nk; ++j) {
+        const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
+        P kk = (j == 0) ? f0v : P::load(kj, i);
+        T cj = dt * T(a.mid[j]);
+#pragma unroll
+        for (int w = 0; w < W; ++w) acc.v[w] = (j == 0) ? kk.v[w] * cj : acc.v[w] + kk.v[w] * cj;
+      }
     }
     for (int r = ob; r < oe; ++r) {
-      TT xt = (TT(a.t_span[r]) - t0) / (t1 - t0);
-      T x = T(xt);
+      const T x = (r - ob < kXs) ? xs[r - ob] : T((TT(a.t_span[r]) - t0) / (t1 - t0));
       P o;
 #pragma unroll
-      for (int w = 0; w < W; ++w) o.v[w] = eval(y0v.v[w], y1v.v[w], f0v.v[w], f1v.v[w], y0v.v[w] + acc.v[w], x);
-      o.store(out + int64_t(r) * a.n, i);
+      for (int w = 0; w < W; ++w) o.v[w] = quartic_<T>(y0v.v[w], y1v.v[w], f0v.v[w], f1v.v[w], y0v.v[w] + acc.v[w], x, dt);
+      if (rows_nt)
+        o.store_nt(out + int64_t(r) * a.n, i);
+      else
+        o.store(out + int64_t(r) * a.n, i);
     }
     if (COMMIT) {
       y1v.store(cy, i);
@@ -102,15 +136,41 @@ __global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
         T term = kj[i] * (dt * T(a.mid[j]));
         acc = (j == 0) ? term : acc + term;
       }
+      const T y0s = y0[i], y1s = y1[i], f0s = k0[i], f1s = f1p[i];
       for (int r = ob; r < oe; ++r) {
         TT xt = (TT(a.t_span[r]) - t0) / (t1 - t0);
-        out[int64_t(r) * a.n + i] = eval(y0[i], y1[i], k0[i], f1p[i], y0[i] + acc, T(xt));
+        out[int64_t(r) * a.n + i] = quartic_<T>(y0s, y1s, f0s, f1s, y0s + acc, T(xt), dt);
       }
       if (COMMIT) {
-        cy[i] = y1[i];
-        cf[i] = f1p[i];
+        cy[i] = y1s;
+        cf[i] = f1s;
       }
     }
+  }
+}
+
+template <typename T, typename TT, bool VEC, bool COMMIT = false>
+__global__ __launch_bounds__(kBlock) void xde_dense_kernel(DenseArgs a) {
+  const xde_ctrl_t* c = a.ctrl;
+  if (!c->accept) return;  // nothing to emit, nothing to commit
+  const bool expected = !(a.expect_step >= 0 && c->n_steps != a.expect_step);
+  const int ob = c->out_begin, oe = expected ? c->out_end : c->out_begin;
+  if (!COMMIT && oe <= ob) return;
+  const int sel = a.use_sel ? (c->sel_used ? 1 : 0) : 0;
+  // (no __restrict__ on the operands the COMMIT variant also writes)
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  const T dt = T(TT(c->dt_last));  // `dt.astype(y0.dtype)`
+  const TT t0 = TT(c->t0), t1 = TT(c->t1);
+  switch (a.nk) {
+    case 1: dense_body<T, TT, 1, VEC, COMMIT>(a, y0, k0, ob, oe, dt, t0, t1); break;
+    case 2: dense_body<T, TT, 2, VEC, COMMIT>(a, y0, k0, ob, oe, dt, t0, t1); break;
+    case 3: dense_body<T, TT, 3, VEC, COMMIT>(a, y0, k0, ob, oe, dt, t0, t1); break;
+    case 4: dense_body<T, TT, 4, VEC, COMMIT>(a, y0, k0, ob, oe, dt, t0, t1); break;
+    case 5: dense_body<T, TT, 5, VEC, COMMIT>(a, y0, k0, ob, oe, dt, t0, t1); break;
+    case 6: dense_body<T, TT, 6, VEC, COMMIT>(a, y0, k0, ob, oe, dt, t0, t1); break;
+    case 7: dense_body<T, TT, 7, VEC, COMMIT>(a, y0, k0, ob, oe, dt, t0, t1); break;
+    default: dense_body<T, TT, 0, VEC, COMMIT>(a, y0, k0, ob, oe, dt, t0, t1); break;
   }
 }
 
@@ -290,6 +350,10 @@ static int dense_launch(const char* who_c, void* out_base, const void* const* k,
   a.nk = nk;
   a.time_dtype = time_dtype;
   a.expect_step = expect_step;
+  a.f1_is_last_k = (f1 == k[nk - 1] && nk > 1 && !commit_y0) ? 1 : 0;
+  // cache policy (results never depend on it): the step's y0 and k_j are read here for the last time; y1 / f1 become the next
+  // step's (y0, f0) and stay cacheable; solution rows are not re-read by the solve
+  a.nt = (nt_policy() & 1) ? 3 : 0;
   const int width = dtype == XDE_F32 ? 4 : 2;
   // every output row starts at out_base + r*n elements: rows stay 16-byte aligned only if n % width == 0
   bool vec = aligned16(out_base) && (n % width == 0) && aligned16(y0) && aligned16(a.y0[1]) && aligned16(y1) &&
@@ -305,7 +369,8 @@ static int dense_launch(const char* who_c, void* out_base, const void* const* k,
   int64_t blocks = (work + kBlock - 1) / kBlock;
   // predicated launch: most launches of the speculative pipeline exit at once, so keep the grid small (a no-op
   // launch costs ~5 us with 2048 workgroups); the streaming rate does not depend on the grid between 512 and 4096
-  const int64_t dense_cap = grid_cap() < 512 ? grid_cap() : 512;
+  static const int dense_grid = env_int("XDE_DENSE_GRID", 512);
+  const int64_t dense_cap = grid_cap() < dense_grid ? grid_cap() : dense_grid;
   if (blocks > dense_cap) blocks = dense_cap;
   if (blocks < 1) blocks = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
