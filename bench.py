@@ -561,9 +561,12 @@ def main():
                     help="auto = the library default (resolves to 'lag' at the headline size)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="state dtype (the headline metric is quoted on f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "p2p"],
-                    help="N>1: how the per-attempt norm sums travel — torch.distributed all-reduce (RCCL, default) or the one-shot "
-                         "peer-to-peer mailbox exchange (utils.PeerExchange; rehearsed on one GPU only so far)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "allreduce", "p2p"],
+                    help="N>1: how the per-attempt norm sums travel — 'rccl': ncclAllReduce issued directly on the solver's stream "
+                         "(utils.RcclExchange: no process-group stream hop, ~20 us per step less); 'allreduce': torch.distributed "
+                         "all_reduce over the nccl (= RCCL) backend; 'p2p': the one-shot peer-to-peer mailbox exchange "
+                         "(utils.PeerExchange; rehearsed on one GPU only so far); 'auto' (default): rccl over an nccl group, falling "
+                         "back to allreduce if the communicator cannot be built; allreduce in a gloo rehearsal")
     ap.add_argument("--graph-func", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="c3: replay the augmented dynamics from a captured HIP graph (auto = the library default, which captures here)")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "rk4", "c4-shard", "c4-n1", "dense", "dde"],
@@ -668,11 +671,28 @@ def main():
 
     t_span = torch.tensor([0.0, 1.0e9])
     xde = BaseODE(func, y0=y0, t_span=t_span)
-    exchange = None
-    if args.exchange == "p2p" and (world > 1 or force_dist):
-        from paddlexde_amd.utils import PeerExchange
+    exchange, exchange_name = None, "all-reduce (torch.distributed)"
+    if world > 1 or force_dist:
+        if args.exchange == "p2p":
+            from paddlexde_amd.utils import PeerExchange
 
-        exchange = PeerExchange()
+            exchange, exchange_name = PeerExchange(), "peer-to-peer mailbox exchange"
+        elif args.exchange == "rccl" or (args.exchange == "auto" and not rehearsal):
+            from paddlexde_amd.utils import RcclExchange
+
+            try:
+                exchange, exchange_name = RcclExchange(), "in-stream ncclAllReduce (RCCL)"
+                ok = torch.ones(1, device=device)
+            except Exception as e:
+                if args.exchange == "rccl":
+                    raise
+                print("bench.py: RcclExchange unavailable ({}: {}); using torch.distributed all_reduce".format(type(e).__name__, e), file=sys.stderr)
+                ok = torch.zeros(1, device=device)
+            # every rank must take the same transport: one that could not build its communicator sends all of them back
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0 and exchange is not None:
+                exchange.close()
+                exchange, exchange_name = None, "all-reduce (torch.distributed)"
     solver = Dopri5(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=args.pipeline,
                     process_group=(True if (world > 1 or force_dist) else None), norm_exchange=exchange)
     solver.y0 = y0
@@ -738,9 +758,10 @@ def main():
             "rows_per_gpu": B,
             "dim": D,
             "pipeline": args.pipeline if args.pipeline != "auto" else "auto -> " + str(solver._auto_state),
-            "parallelism": "batch-sharded x{} (error-norm {} only)".format(world, "peer-to-peer exchange" if exchange is not None else "all-reduce")
+            "parallelism": "batch-sharded x{} (error-norm {} only)".format(world, exchange_name)
                            if world > 1 else "single GPU",
         },
+        "norm_exchange": exchange_name if (world > 1 or force_dist) else None,
         "rccl_ranks": rccl_ranks,  # ranks of the nccl (= RCCL) group the norm sums were all-reduced over; 0 = no RCCL group (one GPU, or a gloo rehearsal)
         "solver": {"n_steps": int(c.n_steps), "n_accept": int(c.n_accept), "n_reject": int(c.n_reject), "t": float(c.t1),
                    "dt": float(c.dt), "settle_steps": settle},

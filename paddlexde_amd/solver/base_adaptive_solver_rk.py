@@ -139,7 +139,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
             raise ValueError("controller must be 'I' (reference) or 'PI' (opt-in)")
         if dtype not in (torch.float32, torch.float64):
             raise TypeError("dtype (time dtype) must be torch.float32 or torch.float64")
-        if pipeline == "graph" and process_group is not None and norm_exchange is None:
+        if pipeline == "graph" and process_group is not None and not getattr(norm_exchange, "capturable", False):
             raise NotImplementedError("pipeline='graph' with a process_group needs the peer-to-peer norm exchange "
                                       "(norm_exchange=PeerExchange(...)): a torch.distributed all-reduce cannot be replayed "
                                       "from a captured step; or use 'sync' / 'lag'")

@@ -15,6 +15,7 @@ from .. import _hip
 
 
 class PeerExchange:
+    capturable = True  # the exchange is one kernel launch whose counter lives in device memory: valid inside a replayed hipGraph
     SPIN_LIMIT = 20_000_000  # polls of ~60 ns before an exchange gives up (about a second): a peer died or fell out of step
 
     def __init__(self, group=None, device=None):

@@ -221,7 +221,7 @@ def test_sharded_solver_refuses_a_user_norm(cpu_double):
 # ----------------------------------------------------------------------------------------------
 # the production transport: torch.distributed "nccl" (= RCCL) carrying the norm all-reduce
 # ----------------------------------------------------------------------------------------------
-def _nccl_worker(rank, world, port, out_dir, pipeline):
+def _nccl_worker(rank, world, port, out_dir, pipeline, direct=False, norm_name="rms"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -229,7 +229,17 @@ def _nccl_worker(rank, world, port, out_dir, pipeline):
     try:
         B, D = 4096, 64
         A, y0 = _problem(B, D)
-        sol, s = _solve(y0.to("cuda:0"), A.to("cuda:0"), True, "rms", pipeline)
+        ex = None
+        if direct:  # ncclAllReduce issued on the solver's own stream instead of torch.distributed.all_reduce
+            from paddlexde_amd.utils import RcclExchange
+
+            ex = RcclExchange()
+            probe = torch.arange(32, dtype=torch.float64, device="cuda:0")
+            ex.exchange(probe, 1)  # linf: max of the first 16, sum of the last 16 (one rank: the identity)
+            assert torch.equal(probe.cpu(), torch.arange(32, dtype=torch.float64)) and ex.async_error() is None
+        sol, s = _solve(y0.to("cuda:0"), A.to("cuda:0"), True, norm_name, pipeline, exchange=ex)
+        if ex is not None:
+            ex.close()
         np.savez(os.path.join(out_dir, "nccl.npz"), sol=sol.cpu().numpy(), trace=np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace]))
     finally:
         dist.destroy_process_group()
@@ -249,6 +259,34 @@ def test_rccl_backend_world_size_one(tmp_path, pipeline):
     tr = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
     assert np.array_equal(tr, r["trace"])
     assert np.array_equal(full.cpu().numpy(), r["sol"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm_name,pipeline", [("rms", "sync"), ("rms", "lag"), ("linf", "lag")])
+def test_direct_rccl_exchange_world_size_one(tmp_path, norm_name, pipeline):
+    """`norm_exchange=RcclExchange()`: its own communicator (unique id by broadcast_object_list, ncclCommInitRank) and
+    ncclAllReduce on the solver's stream, one rank — bit-identical to the unsharded run, like the torch.distributed transport."""
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path), pipeline, True, norm_name), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl.npz")
+    B, D = 4096, 64
+    A, y0 = _problem(B, D)
+    full, s = _solve(y0.to("cuda:0"), A.to("cuda:0"), None, norm_name, pipeline)
+    tr = np.asarray([[a, b, c, float(d)] for a, b, c, d in s.trace])
+    assert np.array_equal(tr, r["trace"])
+    assert np.array_equal(full.cpu().numpy(), r["sol"])
+
+
+def test_direct_rccl_exchange_is_not_offered_to_the_graph_pipeline(cpu_double):
+    from paddlexde_amd import Dopri5
+    from paddlexde_amd.utils import PeerExchange, RcclExchange
+    from paddlexde_amd.xde import BaseODE
+
+    assert PeerExchange.capturable and not RcclExchange.capturable
+    y0 = torch.ones(4, 2)
+    stand_in = type("X", (), {"capturable": False})()
+    with pytest.raises(NotImplementedError, match="peer-to-peer norm exchange"):
+        Dopri5(xde=BaseODE(lambda t_, y: -y, y0=y0, t_span=torch.tensor([0.0, 1.0])), y0=y0, rtol=1e-5, atol=1e-7,
+               norm=__import__("paddlexde_amd").utils._rms_norm, process_group=True, norm_exchange=stand_in, pipeline="graph")
 
 
 # ----------------------------------------------------------------------------------------------
