@@ -27,7 +27,7 @@ _NCCL_SUM, _NCCL_MAX = 0, 2  # rccl.h: ncclSum, ncclMax
 
 
 class _UniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * _NCCL_UNIQUE_ID_BYTES)]
+    _fields_ = [("internal", C.c_ubyte * _NCCL_UNIQUE_ID_BYTES)]  # (c_ubyte, not c_char: the id is binary, a c_char array reads as a C string)
 
 
 _lib = None
@@ -81,9 +81,11 @@ class RcclExchange:
         uid = _UniqueId()
         if self.rank == 0:
             self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [bytes(uid.internal) if self.rank == 0 else None]
+        box = [C.string_at(C.addressof(uid), _NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None]
         src = 0 if group is None else dist.get_global_rank(group, 0)
         dist.broadcast_object_list(box, src=src, group=group)
+        if not isinstance(box[0], bytes) or len(box[0]) != _NCCL_UNIQUE_ID_BYTES:
+            raise _hip.XdeError("RcclExchange: the communicator id did not arrive intact")
         C.memmove(C.addressof(uid), box[0], _NCCL_UNIQUE_ID_BYTES)
         comm = C.c_void_p()
         with torch.cuda.device(self.device):
