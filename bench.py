@@ -781,9 +781,13 @@ def main():
         achieved = comb["bytes"] / (comb["ms"] * 1e-3) / 1e9 if comb["ms"] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_combine.json")
-        if os.path.exists(tpath) and (B, D, args.dtype) == (65536, 128, "f32") and world == 1:  # the PMC passes were taken at the default workload size
+        if os.path.exists(tpath) and world == 1:  # the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) were taken per size, on one GPU
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                key = "{}x{}/{}".format(B, D, args.dtype)
+                traffic = tj.get("by_size", {}).get(key, {}).get("hbm_bytes_per_launch")
+                if traffic is None and key == "65536x128/f32":
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out["roofline"] = {

@@ -24,7 +24,15 @@ done
 # 4. `python bench.py --gpus 2` with NO launcher (rehearsal: both ranks on this GPU over gloo) and the refusal without the flag
 XDE_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/self_launch_n2.json 2> $OUT/self_launch_n2.err; echo "rc=$?" >> $OUT/self_launch_n2.err; say n2
 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/self_launch_refused.out 2> $OUT/self_launch_refused.err; echo "rc=$?" >> $OUT/self_launch_refused.err; say refused
-XDE_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline > $OUT/force_dist.json 2> $OUT/force_dist.err; say force_dist
+XDE_BENCH_REHEARSAL=1 python3 bench.py --gpus 4 --steps 20 --warmup 5 > $OUT/self_launch_n4.json 2> $OUT/self_launch_n4.err; echo "rc=$?" >> $OUT/self_launch_n4.err; say n4
+# the sharded code path with ONE rank over the nccl backend: what finalize -> all-reduce -> controller-on-sums costs per step, with
+# the all-reduce through torch.distributed and as an in-stream ncclAllReduce (RcclExchange); and the host's enqueue floor (tiny state)
+for x in allreduce rccl; do
+  XDE_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --exchange $x > $OUT/force_dist_$x.json 2> $OUT/force_dist_$x.err
+  XDE_BENCH_FORCE_DIST=1 python3 bench.py --workload c4-shard --no-cpu-baseline --exchange $x > $OUT/force_dist_c4shard_$x.json 2>> $OUT/force_dist_$x.err
+  XDE_BENCH_FORCE_DIST=1 python3 bench.py --batch 256 --dim 64 --pipeline lag --no-kernel-events --no-cpu-baseline --steps 2000 --warmup 200 --exchange $x > $OUT/host_floor_dist_$x.json 2>> $OUT/force_dist_$x.err
+done
+python3 bench.py --batch 256 --dim 64 --pipeline lag --no-kernel-events --no-cpu-baseline --steps 2000 --warmup 200 > $OUT/host_floor.json 2>/dev/null; say force_dist
 # 5. side workloads
 for p in graph auto; do python3 bench.py --workload c5 --pipeline $p > $OUT/c5_$p.json 2>/dev/null; done; say c5
 python3 bench.py --workload c3 > $OUT/c3_auto.json 2>/dev/null; say c3
