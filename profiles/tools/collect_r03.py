@@ -41,7 +41,8 @@ def main():
     for w in ("c4-shard", "c4-n1"):
         shutil.copy(os.path.join(S, w + "_pmc_traffic.json"), os.path.join(D, "r03_" + w.replace("-", "_") + "_pmc_traffic.json"))
     for sub in ("c4-shard_stats", "c4-n1_stats", "dense_stats", "dde_stats"):
-        src = glob.glob(os.path.join(S, sub, "**", "*kernel_stats.csv"), recursive=True)[0]
+        # (gpurun merges a call's output INTO gpurun_out/: an earlier call's file of another pid may still be there — take the newest)
+        src = max(glob.glob(os.path.join(S, sub, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
         fields, keep = xde_rows(src)
         with open(os.path.join(D, "r03_" + sub.replace("-", "_").replace("_stats", "_kernel_stats.csv")), "w", newline="") as fh:
             w = csv.DictWriter(fh, fieldnames=list(fields))
