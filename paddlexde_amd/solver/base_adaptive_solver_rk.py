@@ -87,12 +87,25 @@ def _build_plans(tab, mid):
     later = set(sol_plan[0]) if not fsal else set()
     if not fuse_err:
         later |= set(err_plan[0])
+    # XDE_STAGE_NT_MODE (measurement knob, results never depend on it): "lastuse" (default) as described; "old" = every operand
+    # but the newest derivative (which the framework's GEMM has just written) is streamed, y0 included (bit 31); "all"; "none"
+    mode = os.environ.get("XDE_STAGE_NT_MODE", "lastuse")
     stage_nt = []
     for i, (idx_i, _) in enumerate(stage_plan):
         m = 0
         for pos, j in enumerate(idx_i):
-            if last_use[j] == i and j not in later:
+            if mode == "lastuse":
+                hit = last_use[j] == i and j not in later
+            elif mode == "old":
+                hit = pos != len(idx_i) - 1 or (last_use[j] == i and j not in later)
+            elif mode == "oldk":
+                hit = pos != len(idx_i) - 1 or (last_use[j] == i and j not in later)
+            else:
+                hit = mode == "all"
+            if hit:
                 m |= 1 << pos
+        if mode in ("old", "all"):
+            m |= 1 << 31
         stage_nt.append(m)
     return n_stage, stage_plan, fsal, sol_plan, err_plan, mid_plan, fuse_err, err2_coef, stage_nt
 
