@@ -203,6 +203,11 @@ __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
   }
 }
 
+// (8..14 operands — Dopri8's later stages, the Adams predictor's long histories — take combine_generic's runtime loop.  A separate
+// kernel with compile-time counts was measured in round 3 and is NOT faster here: 63.9 vs 62.6 us per launch on Dopri8's four
+// long stages at config 2's size (0.80 of the HBM peak either way; the loop body is short enough for the compiler to keep several
+// loads in flight at 8 waves/SIMD).  The error-norm pass is different: see xde_errnorm_wide_kernel.)
+
 // ------------------------------------------------------------------------------------------
 // fan-out: outs[j] = g * factor_j  (backward of the combine)
 // ------------------------------------------------------------------------------------------
@@ -322,12 +327,12 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   const int kid = mode == XDE_COMBINE_RK ? XDE_KID_COMBINE : (mode == XDE_COMBINE_FUSE ? XDE_KID_COMBINE_FUSE : XDE_KID_COMBINE_WFUSE);
   ProfScope prof(kid, double(nk + 2 + (out2 ? 1 : 0)) * double(n) * elt);
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
-#define LAUNCH_COMBINE(T, MODE)                                                     \
-  do {                                                                              \
-    if (vec)                                                                        \
-      XDE_LAUNCH((xde_combine_kernel<T, MODE, true, false>), g, b, st, prof, a);    \
-    else                                                                            \
-      XDE_LAUNCH((xde_combine_kernel<T, MODE, false, false>), g, b, st, prof, a);   \
+#define LAUNCH_COMBINE(T, MODE)                                                       \
+  do {                                                                                \
+    if (vec)                                                                          \
+      XDE_LAUNCH((xde_combine_kernel<T, MODE, true, false>), g, b, st, prof, a);      \
+    else                                                                              \
+      XDE_LAUNCH((xde_combine_kernel<T, MODE, false, false>), g, b, st, prof, a);     \
   } while (0)
 #define LAUNCH_COMBINE2(T)                                                                   \
   do {                                                                                       \

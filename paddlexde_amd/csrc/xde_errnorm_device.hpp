@@ -144,6 +144,22 @@ __device__ void errnorm_generic(const ErrArgs& a, const T* __restrict__ y0, cons
   nf_out = nf;
 }
 
+// 9..14 operands (Dopri8's error estimate reads 11 derivatives): compile-time counts as well, but in a kernel of their own
+// (xde_errnorm_wide_kernel) — inside the common kernel their 14 x 16-byte registers per lane cost it 236 VGPRs and scratch.
+template <typename T, int NORM, bool VEC>
+__device__ __forceinline__ void errnorm_dispatch_wide(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt,
+                                                      int seg, int lb, int nb, double& acc, int& nf) {
+  switch (a.nk) {
+    case 9: if (a.nt) errnorm_body<T, 9, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 9, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 10: if (a.nt) errnorm_body<T, 10, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 10, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 11: if (a.nt) errnorm_body<T, 11, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 11, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 12: if (a.nt) errnorm_body<T, 12, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 12, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 13: if (a.nt) errnorm_body<T, 13, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 13, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    case 14: if (a.nt) errnorm_body<T, 14, NORM, VEC, true>(a, y0, k0, dt, seg, lb, nb, acc, nf); else errnorm_body<T, 14, NORM, VEC, false>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+    default: errnorm_generic<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf); break;
+  }
+}
+
 template <typename T, int NORM, bool VEC>
 __device__ __forceinline__ void errnorm_dispatch(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt,
                                                  int seg, int lb, int nb, double& acc, int& nf) {

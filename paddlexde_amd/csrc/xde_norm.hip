@@ -45,6 +45,31 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
   block_reduce_store<NORM>(acc, double(nf), a.slot, seg);
 }
 
+template <typename T, int NORM, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_errnorm_wide_kernel(ErrArgs a) {
+  int sel = 0;
+  T dt;
+  if (a.ctrl) {
+    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
+  } else {
+    dt = T(a.dt_host);
+  }
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  const int seg = find_segment(a.map, blockIdx.x);
+  const int lb = blockIdx.x - a.map.seg_blk[seg];
+  const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
+  double acc = 0.0;
+  int nf = 0;
+  errnorm_dispatch_wide<T, NORM, VEC>(a, y0, k0, dt, seg, lb, nb, acc, nf);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.slot->nblocks = gridDim.x;
+    a.slot->n_seg = a.map.n_seg;
+    a.slot->norm_kind = NORM;
+  }
+  block_reduce_store<NORM>(acc, double(nf), a.slot, seg);
+}
+
 // ------------------------------------------------------------------------------------------
 // scaled norms for select_initial_step:  norm(a / scale)  or  norm((a - b) / scale)
 // ------------------------------------------------------------------------------------------
@@ -214,7 +239,9 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   dim3 g(nblocks), b(kBlock);
 #define LAUNCH_ERR(T, NORM)                                                       \
   do {                                                                            \
-    if (vec)                                                                      \
+    if (vec && nk > 8 && !e_pre)                                                  \
+      XDE_LAUNCH((xde_errnorm_wide_kernel<T, NORM, true>), g, b, st, prof, a);    \
+    else if (vec)                                                                 \
       XDE_LAUNCH((xde_errnorm_kernel<T, NORM, true>), g, b, st, prof, a);    \
     else                                                                          \
       XDE_LAUNCH((xde_errnorm_kernel<T, NORM, false>), g, b, st, prof, a);   \
