@@ -826,6 +826,11 @@ def main():
         if fused is not None:
             out["cpu_baseline_fused"] = fused
 
+    if exchange is not None:  # every rank leaves the per-step transport together, before rank 0 goes off on its own below
+        if dist is not None:
+            dist.barrier()
+        exchange.close()
+        exchange = None
     if world > 1 and scaling == "strong" and not args.no_n1 and rank == 0:
         # the same GLOBAL problem on this rank alone, so that a strong-scaling efficiency can be computed from this one line
         # (the driver's own `--gpus 1` line is config 2, a different amount of work); the other ranks wait at the barrier below
