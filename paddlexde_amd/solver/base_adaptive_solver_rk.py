@@ -581,6 +581,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
                 raise _hip.XdeError("peer-to-peer norm exchange {} timed out{}: a rank of the process group did not arrive "
                                     "(died, or fell out of lock-step); every rank of the group stops".format(
                                         q, "" if by is None else " on rank {}, which told this rank".format(by)))
+            comm_error = getattr(self.norm_exchange, "async_error", lambda: None)()
+            if comm_error:  # a failed collective leaves garbage in the sums: report the transport, not the state
+                raise _hip.XdeError("the norm exchange's RCCL communicator reports: {}".format(comm_error))
             raise AssertionError(_STATUS_MSG[c.status].format("{} non-finite element(s)".format(int(c.nonfinite))))
         if c.status == _hip.STATUS_MAX_STEPS:
             raise AssertionError(_STATUS_MSG[c.status].format(c.steps_in_interval, self.max_num_steps))
