@@ -263,15 +263,18 @@ def test_initial_step_vs_oracle_select_initial_step(dev, dtype, direction):
     s = Solver(xde=BaseODE(f_t, y0=y0d, t_span=torch.from_numpy(t_span)), y0=y0d, rtol=rtol, atol=atol, norm=_rms_norm, dtype=tdt)
     s.y0 = y0d
     s._before_integrate(t_span.astype(np.float32 if dtype == np.float32 else np.float64))
-    res, hs = s._first_step_dbg
-    res, hs = res.cpu().numpy(), hs.cpu().numpy()
     rel = 3e-6 if dtype == np.float32 else 1e-12
-    # (1) the norms
-    assert hs[0] == pytest.approx(d0_ref, rel=rel) and hs[1] == pytest.approx(d1_ref, rel=rel)
-    assert abs(res[0]) == pytest.approx(n3_ref, rel=30 * rel)  # f1 - f0 at h0 ~ 1e-5: a cancellation, and h0 differs in its last bits
-    # (3) the whole device path
-    assert hs[2] == pytest.approx(h0_ref, rel=2 * rel)
-    assert hs[3] == pytest.approx(float(first_ref), rel=30 * rel)
+    if hasattr(s, "_first_step_dbg"):  # (absent under XDE_HOST_FIRST_STEP=1, which takes the host statement of the heuristic)
+        res, hs = s._first_step_dbg
+        res, hs = res.cpu().numpy(), hs.cpu().numpy()
+        # (1) the norms
+        assert hs[0] == pytest.approx(d0_ref, rel=rel) and hs[1] == pytest.approx(d1_ref, rel=rel)
+        assert abs(res[0]) == pytest.approx(n3_ref, rel=30 * rel)  # f1 - f0 at h0 ~ 1e-5: a cancellation, and h0 differs in its last bits
+        # (3) the whole device path
+        assert hs[2] == pytest.approx(h0_ref, rel=2 * rel)
+        assert hs[3] == pytest.approx(float(first_ref), rel=30 * rel)
+    else:
+        assert abs(float(s.rk_state.dt)) == pytest.approx(float(first_ref), rel=30 * rel)
 
     # (2) the scalar arithmetic alone, on the oracle's norm values
     p = s._params
