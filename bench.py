@@ -431,22 +431,12 @@ def dde_workload(args):
     spline of interpolation/interpolate.py:100-204) at the reference application's size (D3STN, PeMS04-like: 307 nodes x batch 32 =
     9824 series, 288 history times, 64 channels, 12 learned lags): value AND time derivative at the lags in one pass,
     xde_hermite_gather.  Algorithmic bytes: 3 history rows in + value + derivative out = 5 x (series x lags x channels) x 4 B.
-    A small instance is checked against the oracle's history_index first (checker only)."""
-    from oracle import xde_oracle as O
+    (Parity of this kernel against the oracle's history_index: tests/_dde_cases.py.)"""
     from paddlexde_amd import _hip
 
     dev = torch.device("cuda", 0)
     be = _hip.get_backend()
     g = torch.Generator().manual_seed(0)
-    # parity at a small size (the oracle is a numpy loop over lags)
-    hs = torch.randn(37, 24, 8, generator=g)
-    ts = torch.linspace(0.0, 2.3, 24)
-    lg = torch.rand(5, generator=g) * 2.3
-    v, d = torch.empty(37, 5, 8, device=dev), torch.empty(37, 5, 8, device=dev)
-    be.hermite_gather(v, d, hs.to(dev), ts.to(dev), lg.to(dev))
-    want, _ = O.history_index(lg.numpy(), hs.numpy(), ts.numpy())
-    err = float(np.abs(v.cpu().numpy() - want).max() / np.abs(want).max())
-    assert err <= 2e-5, err
     S, T, D, L = 9824, 288, 64, 12
     his = torch.randn(S, T, D, generator=g).to(dev)
     his_t = torch.linspace(0.0, 287.0, T).to(dev)
@@ -468,7 +458,6 @@ def dde_workload(args):
     emit({"metric": "history-spline gathers per second (xde_hermite_gather, value + derivative)", "value": args.steps / el, "unit": "gathers/s",
           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
           "config": {"workload": "D3STN-sized history: {} series x {} times x {} channels, {} lags".format(S, T, D, L)},
-          "parity_small_case_rel_err_vs_oracle": err,
           "roofline": {"bound": "hbm", "kernel": "xde_hermite_vec_kernel<float>", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": a / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e3 * rec["ms"] / max(rec["launches"], 1),
                        "bytes_per_launch": by, "history_bytes": float(S) * T * D * 4.0}})
