@@ -45,6 +45,7 @@ extern "C" {
 #define XDE_MAX_SEG 16 /* segments of a tuple state */
 #define XDE_MAX_STAGE 13
 #define XDE_MAX_PARTIALS 4096 /* upper bound on blocks of a norm launch */
+#define XDE_MAX_PACK 64 /* members one xde_pack_segments launch writes */
 
 /* combine modes (xde_stage_combine) */
 #define XDE_COMBINE_RK 0    /* out = y0 + sum_j k_j * (coef_j * dt)            base_adaptive_solver_rk.py:166-168 */
@@ -373,6 +374,21 @@ int xde_commit(const xde_ctrl_t* ctrl, void* y0_dst, const void* y1_src, void* f
  * dependencies and dependents.  *n_replaced = how many there were.
  */
 int xde_graph_replace_memsets(void* hip_graph, int* n_replaced);
+
+/*
+ * Multi-tensor pack: the members of a tuple state written into ONE flat buffer whose segments start 16-byte aligned, pads zero —
+ * the layout every tuple-state entry point above integrates.  Replaces the per-member fill + copy launches of a framework-op
+ * pack (the reference's tuple support — utils/misc.py:1-13 flat_to_shape, the commented-out concat of functional/odeint.py — was
+ * removed; its intent is one concatenated buffer): odeint_adjoint's augmented dynamics (functional/odeint_adjoint.py:89-124)
+ * returns a tuple on every evaluation, and packing it was 8 launches per evaluation for config 3's state.
+ *   srcs[s]: lens[s] contiguous elements of `dtype`; starts[s]: element offset in flat_out, a multiple of the 16-byte vector width,
+ *   ordered and disjoint, starts[0] == 0; total: elements of flat_out (a multiple of the vector width).  Elements of flat_out that no
+ *   segment covers are written as zero.  scales (optional): member s is written as srcs[s] * scales[s] — the adjoint takes its vjp with
+ *   the cotangent +adj_y and has the members that the reference computes from -adj_y (:108-114) negated here, exactly, instead of
+ *   spending a launch on the negation.
+ */
+int xde_pack_segments(void* flat_out, const void* const* srcs, const int64_t* starts, const int64_t* lens, const double* scales,
+                      int n_seg, int64_t total, int dtype, void* stream);
 
 /*
  * One-shot peer-to-peer exchange of the norm sums between the GPUs of ONE node (new; the reference has no multi-GPU

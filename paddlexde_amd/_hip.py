@@ -17,6 +17,7 @@ XDE_MIRROR_SLOTS = 16
 ABI_VERSION = 4
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
+XDE_MAX_PACK = 64
 XDE_P2P_MAX_RANKS, XDE_P2P_HANDLE_BYTES = 16, 64
 COMBINE_RK, COMBINE_FUSE, COMBINE_WFUSE = 0, 1, 2
 NORM_RMS, NORM_LINF = 0, 1
@@ -50,6 +51,7 @@ SYMBOLS = (
     "xde_ctrl_wait",
     "xde_dense_eval",
     "xde_commit",
+    "xde_pack_segments",
     "xde_dense_commit",
     "xde_hermite_gather",
     "xde_scale_fanout",
@@ -248,6 +250,8 @@ def load_library():
         lib.xde_p2p_close.argtypes = [vp]
         lib.xde_p2p_exchange.restype = i32
         lib.xde_p2p_exchange.argtypes = [vp, vp, vpp, i32, i32, i32, i64, vp]
+        lib.xde_pack_segments.restype = i32
+        lib.xde_pack_segments.argtypes = [vp, vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp, i32, i64, i32, vp]
         lib.xde_p2p_error.restype = i32
         lib.xde_p2p_error.argtypes = [vp, C.POINTER(C.c_int64), vp]
         lib.xde_prof_enable.restype = i32
@@ -557,6 +561,23 @@ class HipBackend:
         rc = self.lib.xde_hermite_gather(val.data_ptr(), der.data_ptr(), his.data_ptr(), his_t.data_ptr(), lags.data_ptr(), outer,
                                          T, D, lags.numel(), dtype_code(his.dtype), self._stream(his))
         self._check(rc, "xde_hermite_gather")
+
+    def pack_segments(self, flat, tensors, segs, scales=None):
+        """``flat`` (16-byte-aligned segments, pads zero) <- the contiguous device tensors ``tensors`` at ``segs`` = [(start, len)], one
+        launch.  Returns False (nothing done) when the call does not fit the kernel: the caller packs with framework ops then."""
+        n = len(tensors)
+        if n < 1 or n > XDE_MAX_PACK or not flat.is_cuda or flat.dtype not in (torch.float32, torch.float64):
+            return False
+        for x in tensors:
+            if x.dtype != flat.dtype or x.device != flat.device or not x.is_contiguous():
+                return False
+        srcs = (C.c_void_p * n)(*[x.data_ptr() if x.numel() else None for x in tensors])
+        starts = (C.c_int64 * n)(*[int(s) for s, _ in segs])
+        lens = (C.c_int64 * n)(*[int(l) for _, l in segs])
+        sc = _dbl_array(scales) if scales is not None else None
+        rc = self.lib.xde_pack_segments(flat.data_ptr(), srcs, starts, lens, sc, n, flat.numel(), dtype_code(flat.dtype), self._stream(flat))
+        self._check(rc, "xde_pack_segments")
+        return True
 
     def dense_commit(self, out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype):
         """dense_eval + commit in one launch (graph pipeline): rows of the last accepted step, then (y0, ks[0]) <- (y1, f1)."""

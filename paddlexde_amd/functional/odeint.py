@@ -94,11 +94,42 @@ def _segment_layout(tensors):
 
 
 def _pack(tensors, segs, total, dtype, device):
+    """The members of a tuple state in one flat buffer (16-byte-aligned segments, pads zero).  On the device this is ONE launch
+    (xde_pack_segments) instead of a fill + one copy per member — odeint_adjoint's augmented dynamics packs its 7-member result on
+    every evaluation; the framework-op path stays for what the kernel does not take (mixed dtypes, strided members, members that
+    carry an autograd graph, the CPU test double)."""
+    scales = getattr(tensors, "scales", None)  # ScaledTuple: member s counts as tensors[s] * scales[s]
+    tensors = list(tensors)
+    if (torch.device(device).type == "cuda" and len(tensors) == len(segs)
+            and not (torch.is_grad_enabled() and any(x.requires_grad for x in tensors))):
+        from .. import _hip
+
+        be = _hip.get_backend()
+        if hasattr(be, "pack_segments"):
+            flat = torch.empty(total, dtype=dtype, device=device)
+            if be.pack_segments(flat, tensors, segs, scales):
+                return flat
     flat = torch.zeros(total, dtype=dtype, device=device)
-    for x, (s, n) in zip(tensors, segs):
+    for i, (x, (s, n)) in enumerate(zip(tensors, segs)):
         if n:
             flat[s : s + n].copy_(x.reshape(-1))
+            if scales is not None and scales[i] != 1.0:
+                flat[s : s + n].mul_(scales[i])
     return flat
+
+
+class ScaledTuple(tuple):
+    """A tuple of tensors whose member ``s`` stands for ``self[s] * self.scales[s]``: `_pack` applies the factors while it writes the
+    flat buffer (in the pack kernel: for free).  Only ever produced and consumed inside this package."""
+
+    scales = None
+
+    @classmethod
+    def of(cls, members, scales):
+        out = cls(members)
+        out.scales = tuple(float(x) for x in scales)
+        assert len(out.scales) == len(out)
+        return out
 
 
 def _odeint_tuple(func, y0, t_span, solver, *, rtol, atol, options):

@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from ..solver.base_fixed_solver import FixedSolver
 from ..utils.ode_utils import _rms_norm, native_norm_spec
-from .odeint import _odeint_packed, _pack, _segment_layout, odeint
+from .odeint import ScaledTuple, _odeint_packed, _pack, _segment_layout, odeint
 
 _N_LEADING = 3  # adj_t, y, adj_y come first in the augmented state; the parameter adjoints follow
 
@@ -139,19 +139,42 @@ def _adjoint_parameters(func, given, norm_is_users):
 def _vjp_of(evaluate, t, y, wrt_params, cotangent, time_grad, retain):
     """``f = evaluate(t, y)`` and ``cotangent^T df/d(t, y, params)``; missing gradients are zeros (:116-122)."""
     with torch.enable_grad():
+        # fresh autograd leaves that ALIAS the inputs (the reference copies them, paddle.assign: two more launches per evaluation);
+        # nothing writes to either between here and the grad call below, and no graph outlives this function
         t_const = t.detach()
-        t_var = t_const.clone().requires_grad_(True)
-        y_var = y.detach().clone().requires_grad_(True)
+        t_var = t.detach().requires_grad_(True)
+        y_var = y.detach().requires_grad_(True)
         # dL/dt is only resolved when asked for: func then sees a time it can be differentiated by
         f = evaluate(t_var if time_grad else t_const, y_var)
         grads = torch.autograd.grad(f, (t_var, y_var) + tuple(wrt_params), cotangent, allow_unused=True, retain_graph=retain)
-    filled = [torch.zeros_like(x) if g is None else g for x, g in zip((t_var, y_var) + tuple(wrt_params), grads)]
+    filled = [_zeros_like(x) if g is None else g for x, g in zip((t_var, y_var) + tuple(wrt_params), grads)]
     return f.detach(), filled[0], filled[1], filled[2:]
 
 
+_ZEROS = {}  # (shape, dtype, device) -> a zero tensor that is only ever READ (stand-in for a gradient autograd did not produce)
+
+
+def _zeros_like(x):
+    key = (tuple(x.shape), x.dtype, x.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) > 256:
+            _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros(key[0], dtype=x.dtype, device=x.device)
+    return z
+
+
+def _negated_vjp(vjp_t, f, vjp_y, vjp_params):
+    """The augmented dynamics' value ``(-vjp_t, f, -vjp_y, -vjp_theta...)`` where the vjp was taken with the cotangent ``+adj_y``:
+    the reference's ``-adj_y`` (:108-114) is a launch of its own, a vjp is linear in its cotangent (exactly: every operation of a
+    backward graph is sign-symmetric in IEEE arithmetic), and the pack that follows applies the sign for free."""
+    members = (vjp_t, f, vjp_y, *vjp_params)
+    return ScaledTuple.of(members, [-1.0, 1.0, -1.0] + [-1.0] * len(vjp_params))
+
+
 def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, reduce_params=False):
-    """``d/dt (adj_t, y, adj_y, adj_theta) = (vjp_t, f, vjp_y, vjp_theta)`` with the cotangent ``-adj_y``; only ``y`` and
-    ``adj_y`` are read from the state.
+    """``d/dt (adj_t, y, adj_y, adj_theta) = (vjp_t, f, vjp_y, vjp_theta)`` with the cotangent ``-adj_y`` (taken as ``+adj_y`` and
+    negated while the result is packed, see ``_negated_vjp``); only ``y`` and ``adj_y`` are read from the state.
 
     Batch-sharded run (``pg``): ``f`` and ``vjp_y`` are per-row quantities of this rank's rows, ``vjp_t`` and ``vjp_theta`` are
     sums over rows.  Where the step control looks at them — ``adj_t`` when time gradients are wanted, the parameter adjoints under
@@ -159,7 +182,7 @@ def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, red
     ``adj_t`` / ``adj_theta`` and the all-reduced norm is exactly the unsharded one."""
 
     def augmented_dynamics(t, y_aug):
-        f, vjp_t, vjp_y, vjp_params = _vjp_of(func, t, y_aug[1], adjoint_params, -y_aug[2], t_requires_grad, retain=True)
+        f, vjp_t, vjp_y, vjp_params = _vjp_of(func, t, y_aug[1], adjoint_params, y_aug[2], t_requires_grad, retain=True)
         if pg is not None:
             shared = ([vjp_t] if t_requires_grad else []) + (list(vjp_params) if reduce_params else [])
             if shared:
@@ -168,7 +191,7 @@ def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, red
                     vjp_t, shared = shared[0], shared[1:]
                 if reduce_params:
                     vjp_params = shared
-        return (vjp_t, f, vjp_y, *vjp_params)
+        return _negated_vjp(vjp_t, f, vjp_y, vjp_params)
 
     return augmented_dynamics
 
@@ -196,8 +219,8 @@ def _make_functional_dynamics(func, adjoint_params, t_requires_grad):
             raise RuntimeError("the module this captured dynamics was built for no longer exists")
         aliases = tuple(p.detach().requires_grad_(True) for p in adjoint_params)  # same storage, no copy
         evaluate = lambda t_, y_: torch.func.functional_call(module, dict(zip(order, aliases)), (t_, y_))  # noqa: E731
-        f, vjp_t, vjp_y, vjp_params = _vjp_of(evaluate, t, y_aug[1], aliases, -y_aug[2], t_requires_grad, retain=False)
-        return (vjp_t, f, vjp_y, *vjp_params)
+        f, vjp_t, vjp_y, vjp_params = _vjp_of(evaluate, t, y_aug[1], aliases, y_aug[2], t_requires_grad, retain=False)
+        return _negated_vjp(vjp_t, f, vjp_y, vjp_params)
 
     return augmented_dynamics
 

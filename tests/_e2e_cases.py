@@ -1603,3 +1603,41 @@ def test_fixed_auto_pipeline(dev, name):
     sol = odeint(P.spiral_torch, y0g, t[:8], solver=FIXED[name])
     sol.sum().backward()
     assert y0g.grad is not None and torch.isfinite(y0g.grad).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_augmented_dynamics_equals_the_reference_formulation_bit_for_bit(dev, dtype):
+    """The reference evaluates the augmented dynamics with the cotangent `-adj_y` on copies of (t, y)
+    (functional/odeint_adjoint.py:96-114).  Here the vjp is taken with `+adj_y` on aliases and the sign is applied while the result is
+    packed (one launch instead of a negation, two copies, a fill and seven member copies): the packed derivative must be the SAME
+    bits — a vjp is linear in its cotangent and every operation of the backward graph is sign-symmetric in IEEE arithmetic."""
+    import importlib
+
+    OA = importlib.import_module("paddlexde_amd.functional.odeint_adjoint")
+    from paddlexde_amd.functional.odeint import _pack, _segment_layout
+
+    m = ODEFunc(dtype).to(dev)
+    params = tuple(m.parameters())
+    g = torch.Generator().manual_seed(4)
+    y = (torch.rand(512, 2, generator=g, dtype=dtype) * 4 - 2).to(dev)
+    adj_y = torch.randn(512, 2, generator=g, dtype=dtype).to(dev)
+    t = torch.tensor(0.3, dtype=dtype, device=dev)
+
+    # the reference's formulation, with plain framework ops
+    with torch.enable_grad():
+        t_ = t.detach().clone().requires_grad_(True)
+        y_ = y.detach().clone().requires_grad_(True)
+        f = m(t.detach(), y_)
+        vjp_t, vjp_y, *vjp_p = torch.autograd.grad(f, (t_, y_) + params, -adj_y, allow_unused=True)
+    vjp_t = torch.zeros_like(t_) if vjp_t is None else vjp_t
+    ref_members = [vjp_t, f.detach(), vjp_y] + list(vjp_p)
+    adt, segs, total = _segment_layout(ref_members)
+    want = torch.zeros(total, dtype=adt, device=y.device)
+    for x, (s0, n) in zip(ref_members, segs):
+        want[s0 : s0 + n].copy_(x.reshape(-1))
+
+    for make in (OA._make_augmented_dynamics, OA._make_functional_dynamics):
+        dyn = make(m, params, False)
+        with torch.no_grad():
+            got = _pack(dyn(t, (None, y, adj_y)), segs, total, adt, y.device)
+        assert torch.equal(got, want), make.__name__  # (-0.0 == +0.0: the scalar time adjoint's derivative is a signed zero)

@@ -115,6 +115,7 @@ def test_every_entry_point_rejects_null_arguments():
         "xde_dense_eval": lambda: lib.xde_dense_eval(None, None, None, None, 1, None, None, None, None, None, None, 0, 8, 0, -1, None),
         "xde_dense_commit": lambda: lib.xde_dense_commit(None, None, None, 1, None, None, None, None, None, None, 0, 8, 0, None),
         "xde_commit": lambda: lib.xde_commit(None, None, None, None, None, 8, 0, None),
+        "xde_pack_segments": lambda: lib.xde_pack_segments(None, None, None, None, None, 1, 8, 0, None),
         "xde_hermite_gather": lambda: lib.xde_hermite_gather(None, None, None, None, None, 1, 4, 2, 1, 0, None),
         "xde_scale_fanout": lambda: lib.xde_scale_fanout(None, None, None, 1, None, 8, 0, None),
         "xde_graph_replace_memsets": lambda: lib.xde_graph_replace_memsets(None, C.byref(n)),

@@ -549,3 +549,55 @@ def test_dense_eval_and_error_norm_randomised_sweep(be, dbl):
             got.append(sums.cpu().numpy().copy())
         np.testing.assert_allclose(got[0], got[1], rtol=(2e-6 if dtype == "f32" else 1e-12), atol=0,
                                    err_msg=str(("errnorm", case, dtype, n, nk, norm_kind, seg_list)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_pack_segments_equals_the_framework_op_pack(dtype):
+    """xde_pack_segments: the members of a tuple state in one flat buffer with 16-byte-aligned segments and zero pads, ONE launch —
+    bit-identical to the fill + per-member copy it replaces (functional/odeint.py::_pack), for odd lengths, a 0-dim member, an empty
+    member, a member whose storage is not 16-byte aligned, many members, and a pre-dirtied destination."""
+    from paddlexde_amd import _hip
+    from paddlexde_amd.functional.odeint import _pack, _segment_layout
+
+    dev = torch.device("cuda:0")
+    be = _hip.get_backend()
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(4099, generator=g, dtype=dtype).to(dev)
+    members = [torch.randn((), generator=g, dtype=dtype).to(dev), torch.randn(8192, 2, generator=g, dtype=dtype).to(dev),
+               big[1:4098],  # contiguous, but its storage pointer is not 16-byte aligned
+               torch.empty(0, dtype=dtype, device=dev), torch.randn(2, 50, generator=g, dtype=dtype).to(dev)]
+    members += [torch.randn(n, generator=g, dtype=dtype).to(dev) for n in (1, 2, 3, 5, 50, 100, 7, 33)] * 4  # 37 members
+    adt, segs, total = _segment_layout(members)
+    want = torch.zeros(total, dtype=adt, device=dev)
+    for x, (s0, n) in zip(members, segs):
+        if n:
+            want[s0 : s0 + n].copy_(x.reshape(-1))
+    got = torch.full((total,), float("nan"), dtype=adt, device=dev)
+    assert be.pack_segments(got, members, segs)
+    assert torch.equal(got, want)
+    with torch.no_grad():
+        assert torch.equal(_pack(members, segs, total, adt, dev), want)  # the product path takes the kernel
+    # what the kernel does not take goes the framework way, same result: a strided member, a member of another dtype
+    odd = list(members)
+    odd[1] = torch.randn(2, 8192, generator=g, dtype=dtype).to(dev).t()
+    assert not be.pack_segments(got, odd, segs)
+    odd[1] = members[1].to(torch.float64 if dtype == torch.float32 else torch.float32)
+    assert not be.pack_segments(got, odd, segs)
+    assert be.pack_segments(got, members[:1], segs[:1]) is True
+    # bad layouts are refused before any launch
+    lib = be.lib
+    import ctypes as C
+    srcs = (C.c_void_p * 2)(members[1].data_ptr(), members[4].data_ptr())
+    bad_starts = (C.c_int64 * 2)(0, 3)  # not a multiple of the vector width
+    lens = (C.c_int64 * 2)(3, 3)
+    assert lib.xde_pack_segments(got.data_ptr(), srcs, bad_starts, lens, None, 2, 8, 0 if dtype == torch.float32 else 1, None) == _hip.XDE_EBADARG
+    # per-member factors (the adjoint's sign): exactly the framework-op result
+    from paddlexde_amd.functional.odeint import ScaledTuple
+
+    scales = [(-1.0 if i % 2 == 0 else 1.0) for i in range(len(members))]
+    want2 = want.clone()
+    for sc, (s0, n) in zip(scales, segs):
+        if n and sc != 1.0:
+            want2[s0 : s0 + n].mul_(sc)
+    with torch.no_grad():
+        assert torch.equal(_pack(ScaledTuple.of(members, scales), segs, total, adt, dev), want2)
