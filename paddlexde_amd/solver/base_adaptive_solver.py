@@ -55,8 +55,16 @@ class AdaptiveSolver(metaclass=abc.ABCMeta):
         t_host = t_span_to_host(t_span, np_dtype(self.dtype))  # t_span.astype(self.dtype)
         solution = torch.empty((len(t_host),) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
         solution[0] = y0
-        if len(t_host) < 2:
+        if len(t_host) < 2 or y0.numel() == 0:  # (an empty state has nothing to integrate: every row is the empty tensor)
             return solution
+        # The reference walks the output times in order and evaluates its interpolant on the step that has just reached each of
+        # them; a time that lies BEHIND the previous one is outside that step and fails `interp_evaluate`'s assertion
+        # (utils/ode_utils.py:65-67).  The device controller would extrapolate the last step's quartic instead — so the same
+        # condition is checked here, before anything is launched (same exception type and message shape).
+        d0 = -1 if t_host[1] < t_host[0] else 1
+        for i in range(2, len(t_host)):
+            assert d0 * t_host[i] >= d0 * t_host[i - 1], "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(
+                t_host[i - 1], t_host[i], t_host[i - 1])
         try:
             self._before_integrate(t_host)
             # rows whose time equals the start time need no step (`while next_t > rk_state.t1` is false at once,

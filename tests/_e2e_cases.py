@@ -1641,3 +1641,21 @@ def test_augmented_dynamics_equals_the_reference_formulation_bit_for_bit(dev, dt
         with torch.no_grad():
             got = _pack(dyn(t, (None, y, adj_y)), segs, total, adt, y.device)
         assert torch.equal(got, want), make.__name__  # (-0.0 == +0.0: the scalar time adjoint's derivative is a signed zero)
+
+
+def test_output_times_behind_the_previous_one_are_refused_like_the_reference(dev):
+    """The reference evaluates each output time on the step that has just reached it; a time BEHIND the previous one lies outside
+    that step and trips `interp_evaluate`'s assertion (utils/ode_utils.py:65-67) — so does the oracle.  The device controller could
+    extrapolate instead; the host refuses first, with the same exception type and message shape.  Equal consecutive times are fine,
+    and an empty state integrates to empty rows."""
+    y0 = torch.ones(3, 2, device=dev)
+    f = lambda t, y: -y  # noqa: E731
+    for bad in ([0.0, 1.0, 0.5], [1.0, 0.2, 0.6], [0.0, 0.0, -1.0]):
+        with pytest.raises(AssertionError, match="invalid interpolation"):
+            odeint(f, y0, torch.tensor(bad), solver=Dopri5, rtol=1e-5, atol=1e-7)
+        with pytest.raises(AssertionError, match="invalid interpolation"):
+            O.odeint(lambda t, y: -y, np.ones((3, 2), dtype=np.float32), np.asarray(bad, dtype=np.float32), "dopri5", rtol=1e-5, atol=1e-7)
+    ok = odeint(f, y0, torch.tensor([0.0, 0.5, 0.5, 1.0]), solver=Dopri5, rtol=1e-6, atol=1e-8)
+    assert torch.equal(ok[1], ok[2]) and abs(float(ok[3, 0, 0]) - np.exp(-1.0)) < 1e-5
+    empty = odeint(f, torch.zeros(0, 2, device=dev), torch.tensor([0.0, 0.5, 1.0]), solver=Dopri5)
+    assert tuple(empty.shape) == (3, 0, 2)
