@@ -630,7 +630,7 @@ def main():
 
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:

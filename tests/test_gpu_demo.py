@@ -32,13 +32,19 @@ def test_dde_demo_trains_weights_and_lags():
 def test_sharded_demo_runs_with_two_ranks_on_one_gpu():
     """examples/sharded_demo.py under torch.distributed.run, rehearsed with two ranks on this GPU (gloo) and with one rank over nccl
     (where the per-step all-reduce is RcclExchange's in-stream ncclAllReduce)."""
+    import socket
     import subprocess
+
+    def free_port():
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     demo = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "sharded_demo.py")
     for n, extra in ((2, {"XDE_DEMO_REHEARSAL": "1"}), (1, {})):
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-                            "--master-port", "29713", demo], capture_output=True, text=True, timeout=300, env=dict(env, **extra))
+                            "--master-port", str(free_port()), demo], capture_output=True, text=True, timeout=300, env=dict(env, **extra))
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("ranks")][0]
         assert "ranks {} ".format(n) in line and float(line.split()[-1]) < 1e-4, line
