@@ -151,15 +151,16 @@ def _vjp_of(evaluate, t, y, wrt_params, cotangent, time_grad, retain):
     return f.detach(), filled[0], filled[1], filled[2:]
 
 
-_ZEROS = {}  # (shape, dtype, device) -> a zero tensor that is only ever READ (stand-in for a gradient autograd did not produce)
+# (shape, dtype, device) -> a zero tensor that is only ever READ: the stand-in for a gradient autograd did not produce (the time
+# adjoint of an autonomous func, on every evaluation).  Entries are NEVER evicted: a captured HIP graph keeps the raw address of the
+# one it was recorded with.  One entry per distinct shape of t / of a parameter — a handful per model.
+_ZEROS = {}
 
 
 def _zeros_like(x):
     key = (tuple(x.shape), x.dtype, x.device)
     z = _ZEROS.get(key)
     if z is None:
-        if len(_ZEROS) > 256:
-            _ZEROS.clear()
         z = _ZEROS[key] = torch.zeros(key[0], dtype=x.dtype, device=x.device)
     return z
 
