@@ -406,6 +406,9 @@ def _sweep(plan, t_span, y_ans, grad_y, adjoint_params):
         _check_sharded_backward(plan, pg, spec, reduce_params)
     dynamics = _make_augmented_dynamics(plan.func, adjoint_params, plan.time_grad, pg, reduce_params)
     solve_options = dict(plan.options)
+    if not _is_fixed(plan.solver):
+        # one evaluation of the augmented dynamics (func forward + vjp) less per interval: the heuristic's f0 is the state's f0
+        solve_options.setdefault("reuse_f0", True)
     if plan.graphed is not None:
         # the captured FLAT dynamics (same segment layout) replaces the unpack -> dynamics -> pack wrapper: 2 input copies + 1 replay
         # + 1 clone per evaluation

@@ -139,6 +139,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         record_trace=False,
         _replay=None,
         _step_hook=None,
+        reuse_f0=False,
         _xde_segments=None,
         _xde_segment_shapes=None,
         **kwargs,
@@ -185,6 +186,11 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # and a callable(index, y0, y1, ks, ctrl) invoked after every attempt of the "sync" pipeline
         self._replay = None if _replay is None else [(float(h), bool(a)) for h, a in _replay]
         self._step_hook = _step_hook
+        # The reference evaluates func(t0, y0) twice before the first attempt: once for the state (`_before_integrate`, :83) and
+        # once more inside `select_initial_step` (f0=None, :84-87).  Same arguments, same value.  reuse_f0=True hands the first
+        # result to the heuristic instead (NFE is still counted as the reference counts it; func is called once less).  Off by
+        # default; odeint_adjoint switches it on for its backward intervals, where that evaluation is one of nine per interval.
+        self._reuse_f0 = bool(reuse_f0)
         if self._replay is not None and step_t is not None:
             raise NotImplementedError("a prescribed step sequence and step_t clipping do not combine")
         if _step_hook is not None:
@@ -442,10 +448,13 @@ class AdaptiveRKSolver(AdaptiveSolver):
         first_dev = None
         if self.first_step is None:
             # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
+            f0_again = f0 if self._reuse_f0 else None
+            if f0_again is not None:
+                self.nfe += 1  # (counted as the reference counts it)
             if self._custom_norm or not self._device_first_step:
-                first_step = self.select_initial_step(t_span[0], y0, self.order - 1, self.rtol, self.atol)
+                first_step = self.select_initial_step(t_span[0], y0, self.order - 1, self.rtol, self.atol, f0=f0_again)
             else:
-                first_step, first_dev = None, self._select_initial_step_device(t_span[0], y0)
+                first_step, first_dev = None, self._select_initial_step_device(t_span[0], y0, f0=f0_again)
         else:
             first_step = self.first_step
         self.rk_state = _RungeKuttaState(y0, f0, t_span[0], t_span[0], first_step, None)
@@ -457,7 +466,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         if w is not None and self.pipeline != "graph" and self._auto_state != "graph":  # a captured graph keeps addressing its buffers
             self.backend.release_work(w)
 
-    def _select_initial_step_device(self, t0, y0):
+    def _select_initial_step_device(self, t0, y0, f0=None):
         """``select_initial_step`` (base_adaptive_solver.py:33-72) with its scalar arithmetic on the device: the three
         norms feed two one-thread launches (xde_initial_step) instead of two blocking reads; the first step never visits
         the host.  Same op order and dtypes as the host version above it in the class hierarchy."""
@@ -465,7 +474,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         dev = y0.device
         sdt = _hip.dtype_code(y0.dtype)
         t0h = np_dtype(self.dtype)(t0)
-        f0 = self._eval(self._scalar_t(t0h, self.dtype), y0)
+        if f0 is None:
+            f0 = self._eval(self._scalar_t(t0h, self.dtype), y0)
         res = torch.empty(2, dtype=torch.float64, device=dev)
         hs = torch.zeros(4, dtype=torch.float64, device=dev)
 
