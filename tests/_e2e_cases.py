@@ -1659,3 +1659,54 @@ def test_output_times_behind_the_previous_one_are_refused_like_the_reference(dev
     assert torch.equal(ok[1], ok[2]) and abs(float(ok[3, 0, 0]) - np.exp(-1.0)) < 1e-5
     empty = odeint(f, torch.zeros(0, 2, device=dev), torch.tensor([0.0, 0.5, 1.0]), solver=Dopri5)
     assert tuple(empty.shape) == (3, 0, 2)
+
+
+def test_reuse_f0_calls_func_once_less_and_changes_nothing_else(dev):
+    """The reference evaluates func(t0, y0) twice before the first attempt (base_adaptive_solver_rk.py:83 and, with f0=None, :84-87).
+    `reuse_f0=True` hands the first value to the initial-step heuristic: one call less, the same solution bit for bit, the same step
+    trace, NFE reported as the reference counts it.  odeint_adjoint switches it on for its backward intervals (and lets the caller
+    switch it off); plain odeint leaves it off."""
+    from paddlexde_amd.xde import BaseODE
+
+    A = P.skew_matrix(8).double().to(dev)
+    y0 = torch.randn(16, 8, generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(dev)
+    t = torch.linspace(0.0, 1.0, 4, dtype=torch.float64)
+    calls = [0]
+
+    def f(t_, y):
+        calls[0] += 1
+        return y @ A.T
+
+    out = {}
+    for reuse in (False, True):
+        calls[0] = 0
+        s = Dopri5(xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-7, atol=1e-9, norm=_rms_norm, dtype=torch.float64, record_trace=True,
+                   pipeline="sync", reuse_f0=reuse)
+        sol = s.integrate(t)
+        out[reuse] = (sol.clone(), list(s.trace), s.stats["nfe"], calls[0])
+    assert torch.equal(out[False][0], out[True][0]) and out[False][1] == out[True][1]
+    assert out[False][2] == out[True][2] == out[False][3]  # NFE as the reference counts it = the calls it makes
+    assert out[True][3] == out[False][3] - 1
+
+    m = ODEFunc(torch.float64).to(dev)
+    counted = [0]
+    hook = m.register_forward_hook(lambda *_: counted.__setitem__(0, counted[0] + 1))
+    yg = (torch.rand(32, 2, generator=torch.Generator().manual_seed(0), dtype=torch.float64) * 4 - 2).to(dev)
+    tt = torch.linspace(0.0, 1.0, 5, dtype=torch.float64).to(dev)
+    grads, n_calls = {}, {}
+    for reuse in (None, False):
+        for p_ in m.parameters():
+            p_.grad = None
+        y = yg.clone().requires_grad_(True)
+        adj = {"dtype": torch.float64, "graph_func": False}
+        if reuse is not None:
+            adj["reuse_f0"] = reuse
+        sol = odeint_adjoint(m, y, tt, solver=Dopri5, rtol=1e-7, atol=1e-9, options={"norm": _rms_norm, "dtype": torch.float64}, adjoint_options=adj)
+        counted[0] = 0
+        sol.abs().mean().backward()
+        grads[reuse] = [y.grad.clone()] + [p_.grad.clone() for p_ in m.parameters()]
+        n_calls[reuse] = counted[0]
+    hook.remove()
+    for a, b in zip(grads[None], grads[False]):
+        assert torch.equal(a, b)
+    assert n_calls[None] == n_calls[False] - (len(tt) - 1)  # one evaluation of the augmented dynamics less per output interval
