@@ -67,7 +67,9 @@ class RcclExchange:
     """In-stream RCCL all-reduce of the solver's 2*XDE_MAX_SEG norm sums; same protocol as ``PeerExchange``
     (``exchange(sums, norm_kind)``, ``error()``, ``close()``)."""
 
-    capturable = False  # (a captured RCCL collective has not been exercised across GPUs here: 'sync' / 'lag' pipelines only)
+    # Whether pipeline="graph" may record the exchange into a hipGraph.  Off: a captured RCCL collective has not been exercised
+    # across GPUs here.  XDE_RCCL_CAPTURE=1 (or setting the attribute on an instance) allows it — measured with one rank only.
+    capturable = os.environ.get("XDE_RCCL_CAPTURE", "0") == "1"
 
     def __init__(self, group=None, device=None):
         import torch.distributed as dist

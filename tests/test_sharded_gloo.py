@@ -221,6 +221,51 @@ def test_sharded_solver_refuses_a_user_norm(cpu_double):
 # ----------------------------------------------------------------------------------------------
 # the production transport: torch.distributed "nccl" (= RCCL) carrying the norm all-reduce
 # ----------------------------------------------------------------------------------------------
+def _nccl_graph_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from paddlexde_amd import Dopri5
+        from paddlexde_amd.utils import RcclExchange, _rms_norm
+        from paddlexde_amd.xde import BaseODE
+
+        A = P.skew_matrix(16).to("cuda:0")
+        y0 = torch.randn(64, 16, generator=torch.Generator().manual_seed(0)).to("cuda:0")
+        t = torch.linspace(0.0, 30.0, 7)
+
+        def solve(pipeline, pg, ex):
+            s = Dopri5(xde=BaseODE(lambda t_, y: y @ A.T, y0=y0, t_span=t), y0=y0, rtol=1e-7, atol=1e-9, norm=_rms_norm, pipeline=pipeline,
+                       process_group=pg, norm_exchange=ex, record_trace=True)
+            return s.integrate(t), list(s.trace)
+
+        ref, tr0 = solve("sync", None, None)
+        ex = RcclExchange()
+        refused = False
+        try:
+            solve("graph", True, ex)
+        except NotImplementedError:
+            refused = True  # off by default: a captured RCCL collective has not been exercised across GPUs
+        ex.capturable = True
+        got, tr1 = solve("graph", True, ex)
+        torch.cuda.synchronize()
+        ex.close()
+        np.savez(os.path.join(out_dir, "nccl_graph.npz"), equal=bool(torch.equal(got, ref)), same_trace=tr1 == tr0, attempts=len(tr1), refused=refused)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_direct_rccl_exchange_can_be_captured_with_one_rank(tmp_path):
+    """Opt-in (`exchange.capturable = True` / XDE_RCCL_CAPTURE=1): pipeline="graph" records the in-stream ncclAllReduce together with
+    the attempt's kernels and replays it — with ONE rank (all a one-GPU box can run) ~200 attempts replay bit-identically to the
+    unsharded solve.  By default the combination is refused."""
+    mp.spawn(_nccl_graph_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl_graph.npz")
+    assert bool(r["refused"]) and bool(r["equal"]) and bool(r["same_trace"]) and int(r["attempts"]) > 100
+
+
 def _nccl_worker(rank, world, port, out_dir, pipeline, direct=False, norm_name="rms"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
