@@ -89,8 +89,8 @@ template <typename T, int NORM, bool VEC>
 __global__ __launch_bounds__(kSingleBlock) void xde_errnorm_control_single_kernel(ErrArgs a, CtrlTail tl, int flags) {
   __shared__ double seg_val[XDE_MAX_SEG];
   __shared__ double seg_nf[XDE_MAX_SEG];
-  __shared__ double w_val[kSingleWaves];
-  __shared__ double w_nf[kSingleWaves];
+  __shared__ double w_val[kSingleWaves][XDE_MAX_SEG];
+  __shared__ double w_nf[kSingleWaves][XDE_MAX_SEG];
   __shared__ xde_ctrl_t zs;
   __shared__ TimePrefetch pfs;
   control_prologue(tl.ctrl, tl.p, tl.t_span, tl.step_t, tl.mirror, flags, &zs, &pfs);
@@ -110,23 +110,24 @@ __global__ __launch_bounds__(kSingleBlock) void xde_errnorm_control_single_kerne
       acc = merge_<NORM>(acc, __shfl_down(acc, off, 64));
       nf += __shfl_down(nf, off, 64);
     }
-    if (lane == 0) {
-      w_val[wave] = acc;
-      w_nf[wave] = nf;
+    if (lane == 0) {  // parked per segment; the cross-wave step runs once for all segments below (it ran per segment, two barriers each)
+      w_val[wave][seg] = acc;
+      w_nf[wave][seg] = nf;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double v = w_val[0], f = w_nf[0];
-#pragma unroll
-      for (int w = 1; w < kSingleWaves; ++w) {
-        v = merge_<NORM>(v, w_val[w]);
-        f += w_nf[w];
-      }
-      seg_val[seg] = v;
-      seg_nf[seg] = f;
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  if (int(threadIdx.x) < a.map.n_seg) {
+    const int seg = threadIdx.x;
+    double v = w_val[0][seg], f = w_nf[0][seg];
+#pragma unroll
+    for (int w = 1; w < kSingleWaves; ++w) {
+      v = merge_<NORM>(v, w_val[w][seg]);
+      f += w_nf[w][seg];
+    }
+    seg_val[seg] = v;
+    seg_nf[seg] = f;
+  }
+  __syncthreads();
   control_tail(tl.ctrl, tl.p, seg_val, seg_nf, tl.t_span, tl.step_t, tl.t_stage_out, tl.mirror, flags, &zs, &pfs);
 }
 
