@@ -143,3 +143,22 @@ def test_dopri5_through_raw_c_abi():
 
     ref = odeint(func, y0, torch.tensor(t_span), solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "first_step": first_step})
     assert torch.equal(sol, ref)
+
+
+def test_cpp_host_program_through_the_c_abi(tmp_path):
+    """examples/cabi_dopri5.cpp: a complete adaptive Dopri5 solve driven from plain C++/HIP through libxde_hip.so — hipMalloc'd buffers,
+    a HIP kernel as the user's func, no Python and no torch in the process.  Built here with hipcc against include/xde_hip.h and run;
+    it checks its result against the closed form and exits 0."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "cabi_dopri5")
+    lib_dir = os.path.join(ROOT, "paddlexde_amd", "lib")
+    build = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", "cabi_dopri5.cpp"), "-L", lib_dir, "-lxde_hip", "-Wl,-rpath," + lib_dir, "-o", exe],
+                           capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout, run.stderr[-2000:])
+    assert "accepted" in run.stdout and "worst |error|" in run.stdout, run.stdout
