@@ -208,3 +208,21 @@ def test_a_stale_segments_mirror_gets_ebadarg():
     assert "xde_segments_t layout mismatch" in lib.xde_last_error().decode()
     assert lib.xde_error_norm_partial(kk, None, ce, 1, dummy, None, dummy, 1e-3, 1e-6, 0.1, None, sref, 0, 0, dummy, None, None) == _hip.XDE_EBADARG
     assert "xde_segments_t layout mismatch" in lib.xde_last_error().decode()
+
+
+def test_header_is_plain_c_and_the_cpp_example_builds(tmp_path):
+    """include/xde_hip.h is the boundary a foreign host binds: it must be valid C (and C++), and examples/cabi_dopri5.cpp — a whole
+    solve from plain C++/HIP — must build against it and the in-tree library (hipcc cross-compiles without a GPU; it RUNS in the GPU
+    suite)."""
+    import shutil
+    import subprocess
+
+    for cc, lang, std in (("gcc", "c", "c99"), ("g++", "c++", "c++11")):
+        r = subprocess.run([cc, "-fsyntax-only", "-x", lang, "-std=" + std, "-Wall", "-Wextra", "-Werror", HEADER], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib_dir = os.path.join(ROOT, "paddlexde_amd", "lib")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "cabi_dopri5.cpp"), "-L", lib_dir, "-lxde_hip", "-o", str(tmp_path / "cabi_dopri5")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
