@@ -35,7 +35,7 @@ def xde_rows(stats_csv):
 def main():
     names = ["bench_default", "c4-shard", "c4-n1", "dense", "dde", "self_launch_n2", "self_launch_n4", "force_dist_allreduce", "force_dist_rccl",
              "force_dist_c4shard_allreduce", "force_dist_c4shard_rccl", "host_floor", "host_floor_dist_allreduce", "host_floor_dist_rccl",
-             "c5_graph", "c5_auto", "c3_auto", "c1", "rk4"]
+             "c5_graph", "c5_auto", "c3_auto", "c3_eager", "c1", "rk4"]
     for n in names:
         save(n + ".json", "r03_" + n.replace("-", "_") + ".json")
     for w in ("c4-shard", "c4-n1"):
