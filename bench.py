@@ -497,13 +497,97 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+class Watchdog:
+    """Per-rank stage clock.  `stage(name, seconds)` says what this rank is doing now and how long it may take; a daemon thread
+    ends the process (os._exit, after saying on stderr which stage of which rank ran out) when a stage outlives its limit — a
+    rendezvous that never completes, a communicator initialisation a peer never joins, a kernel that never returns.  Every
+    stage change is also written to $XDE_BENCH_STATUS_DIR/rank<r>.json, which the launching parent reads when it has to kill the
+    job.  XDE_BENCH_STAGE_SCALE multiplies every limit."""
+
+    def __init__(self, rank):
+        import threading
+
+        self.rank = rank
+        self.dir = os.environ.get("XDE_BENCH_STATUS_DIR")
+        self.scale = float(os.environ.get("XDE_BENCH_STAGE_SCALE", "1"))
+        self._lock = threading.Lock()
+        self._stage, self._since, self._deadline, self._on_expire = None, None, None, None
+        self._history = []
+        threading.Thread(target=self._run, name="bench-watchdog", daemon=True).start()
+
+    def _write(self, note=None):
+        if not self.dir:
+            return
+        try:
+            tmp = os.path.join(self.dir, "rank{}.json.tmp".format(self.rank))
+            with open(tmp, "w") as fh:
+                json.dump({"rank": self.rank, "pid": os.getpid(), "stage": self._stage, "since": self._since, "note": note,
+                           "history": self._history}, fh)
+            os.replace(tmp, os.path.join(self.dir, "rank{}.json".format(self.rank)))
+        except Exception:
+            pass
+
+    def stage(self, name, seconds, on_expire=None):
+        now = time.time()
+        with self._lock:
+            if self._stage is not None:
+                self._history.append([self._stage, round(now - self._since, 3)])
+            self._stage, self._since = name, now
+            self._deadline = None if seconds is None else now + seconds * self.scale
+            self._on_expire = on_expire
+            self._write()
+
+    def done(self):
+        self.stage("done", None)
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            with self._lock:
+                late = self._deadline is not None and time.time() > self._deadline
+                if late:
+                    stage, since, hook = self._stage, self._since, self._on_expire
+                    self._deadline = None
+            if late:
+                print("bench.py[rank {}]: stage '{}' has run for {:.0f} s, over its limit — giving up (stages so far: {})".format(
+                    self.rank, stage, time.time() - since, self._history), file=sys.stderr, flush=True)
+                self._write(note="stage limit exceeded")
+                code = 70
+                if hook is not None:
+                    try:
+                        code = hook()
+                    except Exception as e:
+                        print("bench.py[rank {}]: {}".format(self.rank, e), file=sys.stderr, flush=True)
+                os._exit(70 if code is None else code)
+
+
+def _stage_report(status_dir, n):
+    """What the ranks of a job last said they were doing (the parent's diagnosis when it has to stop the job)."""
+    rows = []
+    for r in range(n):
+        try:
+            j = json.load(open(os.path.join(status_dir, "rank{}.json".format(r))))
+            rows.append("  rank {}: in stage '{}' for {:.0f} s{}; before that: {}".format(
+                r, j.get("stage"), time.time() - (j.get("since") or time.time()), " ({})".format(j["note"]) if j.get("note") else "",
+                ", ".join("{} {:.1f}s".format(a, b) for a, b in j.get("history", [])) or "-"))
+        except Exception:
+            rows.append("  rank {}: never reported a stage (it did not get as far as bench.py's main)".format(r))
+    return "\n".join(rows)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) invoked WITHOUT a launcher (the reference's own recipe is one command too,
     example/D3STN/README.md:53-59): start one rank per GPU with `python -m torch.distributed.run` as a CHILD process, relay rank 0's
     JSON line, return non-zero if any rank fails or the line does not say `n_gpus == N`.  The parent never initialises the GPU
     and never re-execs itself.  On a box with fewer than N GPUs this refuses, unless XDE_BENCH_REHEARSAL=1 (all ranks share
-    cuda:0, gloo carries the collectives: a functional rehearsal, not a scaling number)."""
+    cuda:0, gloo carries the collectives: a functional rehearsal, not a scaling number).
+
+    The parent is also the job's wall clock: the child runs in its own process group, and when XDE_BENCH_TIMEOUT seconds (default
+    1500) pass without the job ending, that group is killed (TERM, then KILL), the stage every rank last reported is printed, and the
+    exit code is 124.  Nothing is retried."""
+    import signal
     import subprocess
+    import tempfile
 
     n = args.gpus
     rehearsal = os.environ.get("XDE_BENCH_REHEARSAL", "0") == "1"
@@ -518,13 +602,36 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    status_dir = tempfile.mkdtemp(prefix="xde_bench_status_")
+    env["XDE_BENCH_STATUS_DIR"] = status_dir
+    limit = float(os.environ.get("XDE_BENCH_TIMEOUT", "1500"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode != 0:
-        print("bench.py: the {}-rank job exited with {}".format(n, r.returncode), file=sys.stderr)
-        return r.returncode or 1
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the {}-rank job is still running after {:.0f} s (XDE_BENCH_TIMEOUT): stopping it.  Last reported stages:\n{}".format(
+            n, limit, _stage_report(status_dir, n)), file=sys.stderr, flush=True)
+        for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+            try:
+                os.killpg(proc.pid, sig)  # the child's own process group: the launcher and every rank it started, nothing else
+            except ProcessLookupError:
+                break
+            try:
+                proc.communicate(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0:
+        print("bench.py: the {}-rank job exited with {}.  Last reported stages:\n{}".format(n, proc.returncode, _stage_report(status_dir, n)),
+              file=sys.stderr)
+        return proc.returncode or 1
+    import shutil
+
+    shutil.rmtree(status_dir, ignore_errors=True)
     if len(lines) != 1:
         print("bench.py: expected ONE JSON line from rank 0, got {}".format(len(lines)), file=sys.stderr)
         return 3
@@ -539,6 +646,141 @@ def self_launch(args):
     return 0
 
 
+def pmc_traffic(B, D, dtype):
+    """HBM bytes per launch of the stage-combine kernel from the committed rocprofv3 counter passes (`--pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE`, separate runs, reduced by profiles/tools/pmc_summarise.py) -> (bytes or None, where it comes from).
+    A counter pass cannot run inside this process, so the figure is a RECORDED measurement of this exact kernel source: the file
+    carries the stamp of the kernel's sources (csrc/build.py::kernel_stamp) it was taken with, and a figure whose stamp is not the
+    stamp of the sources this library was built from is reported as null, with the reason."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_combine.json")
+    key = "{}x{}/{}".format(B, D, dtype)
+    try:
+        from paddlexde_amd.csrc.build import kernel_stamp
+
+        rec = json.load(open(tpath)).get("by_size", {}).get(key)
+        if rec is None:
+            return None, "no counter pass recorded for {} in profiles/traffic_combine.json".format(key)
+        now = kernel_stamp("combine")
+        src = {"file": rec.get("source"), "round": rec.get("round"), "kernel_stamp": rec.get("kernel_stamp"), "current_kernel_stamp": now}
+        if rec.get("kernel_stamp") != now:
+            src["stale"] = "the stage-combine kernel's sources changed after this counter pass was taken: not reported"
+            return None, src
+        return rec.get("hbm_bytes_per_launch"), src
+    except Exception as e:
+        return None, "{}: {}".format(type(e).__name__, e)
+
+
+def odeint_calls(func, y0, args, reps=5):
+    """What a USER call costs at the headline size (SURVEY 8(d) timing (i); reference functional/odeint.py:9-35 ->
+    solver/base_adaptive_solver.py:24-31): `odeint(func, y0, t_span, solver=Dopri5, rtol=1e-5, atol=1e-7)` on t in [0, 1] with T = 2 and
+    T = 11 output times, through the public entry point — initial-step selection (3 func evaluations, 3 norm passes), every attempt,
+    dense output rows, the speculative pipeline's spare attempt, the result tensor.  Median of `reps` calls after one warm-up call, with
+    the attempts and func evaluations each call made.  Outside the headline `value`."""
+    from paddlexde_amd import Dopri5, odeint
+    from paddlexde_amd.utils import _rms_norm
+
+    out = {}
+    for T in (2, 11):
+        t = torch.linspace(0.0, 1.0, T)
+        times, st = [], None
+        for rep in range(reps + 1):
+            st = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                sol = odeint(func, y0, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "pipeline": args.pipeline, "stats_out": st})
+            torch.cuda.synchronize()
+            if rep:
+                times.append(time.perf_counter() - t0)
+        times.sort()
+        out["odeint_ms_T{}".format(T)] = 1e3 * times[len(times) // 2]
+        out["odeint_T{}".format(T)] = {"calls": reps, "min_ms": 1e3 * times[0], "max_ms": 1e3 * times[-1], "attempts": st["n_steps"],
+                                       "accepted": st["n_accept"], "rejected": st["n_reject"], "nfe": st["nfe"],
+                                       "states_per_s_per_attempt": y0.numel() * st["n_steps"] / times[len(times) // 2],
+                                       "rows": list(sol.shape), "finite": bool(torch.isfinite(sol[-1]).all())}
+    return out
+
+
+def run_p2p_probe(dist, rank, world):
+    """First contact of the peer-to-peer transport with this machine, made in CHILD processes (one per rank, started before this
+    rank has touched its GPU): they form their own gloo group on a fresh port, map each other's mailboxes, push known vectors through
+    the exchange and a short sharded solve through the fused controller launch.  A child that crashes, faults or hangs takes
+    nothing of this job with it; the ranks then agree on the outcome.  -> {"ok": bool, "why": str, "seconds": float}"""
+    import subprocess
+
+    from paddlexde_amd.utils import exchange as X
+
+    box = [_free_port() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(box[0])
+    env.pop("XDE_BENCH_STATUS_DIR", None)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # the children rendezvous on their own store (rank 0's child hosts it)
+    t0 = time.perf_counter()
+    why = None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-p2p", "--gpus", str(world)], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=200)
+        ok = r.returncode == 0
+        if not ok:
+            tail = (r.stderr or "").strip().splitlines()[-3:]
+            why = "rank {}'s probe exited with {}: {}".format(rank, r.returncode, " | ".join(tail)[-400:])
+    except subprocess.TimeoutExpired:
+        ok, why = False, "rank {}'s probe did not finish in 200 s".format(rank)
+    except Exception as e:
+        ok, why = False, "rank {}: {}: {}".format(rank, type(e).__name__, e)
+    all_ok = X.agree(ok)
+    whys = [None] * world
+    dist.all_gather_object(whys, why)
+    return {"ok": all_ok, "why": "; ".join(w for w in whys if w) or None, "seconds": time.perf_counter() - t0}
+
+
+def p2p_probe_child():
+    """The probe itself (`bench.py --probe-p2p`, started by run_p2p_probe with RANK / WORLD_SIZE / LOCAL_RANK of its parent rank)."""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if os.environ.get("XDE_BENCH_REHEARSAL", "0") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    wd = Watchdog(rank)
+    wd.stage("probe: rendezvous", 90)
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from paddlexde_amd import Dopri5
+    from paddlexde_amd.utils import PeerExchange, _rms_norm
+    from paddlexde_amd.utils import exchange as X
+    from paddlexde_amd.xde import BaseODE
+
+    wd.stage("probe: mailboxes", 60)
+    ex = PeerExchange(None, dev)
+    ex.SPIN_LIMIT = 2_000_000  # ~0.1 s: a probe that cannot see its peers' stores must say so quickly
+    wd.stage("probe: exchange self-test", 60)
+    ok, why = X.selftest(ex, None, rounds=8)
+    if ok:
+        # the fused finalize -> exchange -> controller launch inside a short sharded solve: every rank must take the same steps
+        wd.stage("probe: sharded solve", 60)
+        A, y0 = make_problem(256, 16, rank, dev)
+        AT = A.T.contiguous()
+        t = torch.tensor([0.0, 0.5])
+        s = Dopri5(xde=BaseODE(lambda t_, y: y @ AT, y0=y0, t_span=t), y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline="lag",
+                   process_group=True, norm_exchange=ex, record_trace=True)
+        with torch.no_grad():
+            sol = s.integrate(t)
+        torch.cuda.synchronize()
+        traces = [None] * world
+        dist.all_gather_object(traces, [tuple(x) for x in s.trace])
+        ok = bool(torch.isfinite(sol).all()) and len(s.trace) > 2 and all(tr == traces[0] for tr in traces) and ex.error() == 0
+        why = None if ok else "the ranks of the probe's sharded solve did not stay in lock-step"
+        ok = X.agree(ok)
+    wd.stage("probe: close", 60)
+    ex.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        print("p2p probe failed: {}".format(why), file=sys.stderr)
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -551,11 +793,12 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="state dtype (the headline metric is quoted on f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "allreduce", "p2p"],
-                    help="N>1: how the per-attempt norm sums travel — 'rccl': ncclAllReduce issued directly on the solver's stream "
-                         "(utils.RcclExchange: no process-group stream hop, ~20 us per step less); 'allreduce': torch.distributed "
-                         "all_reduce over the nccl (= RCCL) backend; 'p2p': the one-shot peer-to-peer mailbox exchange "
-                         "(utils.PeerExchange; rehearsed on one GPU only so far); 'auto' (default): rccl over an nccl group, falling "
-                         "back to allreduce if the communicator cannot be built; allreduce in a gloo rehearsal")
+                    help="N>1: how the per-attempt norm sums travel — 'p2p': one-shot stores into IPC-mapped mailboxes over xGMI, "
+                         "finalize + exchange + controller as ONE launch (utils.PeerExchange); 'rccl': ncclAllReduce issued directly "
+                         "on the solver's stream (utils.RcclExchange); 'allreduce': torch.distributed all_reduce over the nccl (= RCCL) "
+                         "backend; 'auto' (default): p2p if its first contact with this machine — made in child processes — "
+                         "succeeds, else rccl, else allreduce; every candidate is self-tested and the whole group moves together "
+                         "(utils/exchange.py).  The line says what was used and why (norm_exchange, norm_exchange_report)")
     ap.add_argument("--graph-func", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help="c3: replay the augmented dynamics from a captured HIP graph (auto = the library default, which captures here)")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "rk4", "c4-shard", "c4-n1", "dense", "dde"],
@@ -564,6 +807,9 @@ def main():
                          "mu=1000 batch 4096 (step-rejection stress, reports accepted/rejected and us per step)")
     ap.add_argument("--solver", default="dopri5", choices=["dopri5", "dopri8", "bosh3", "fehlberg2", "adaptive_heun"],
                     help="embedded pair of the c2-family workloads (the headline metric is quoted on dopri5)")
+    ap.add_argument("--no-ab", action="store_true", help="N>1: skip the short runs on the other norm-exchange transports (exchange_ab)")
+    ap.add_argument("--no-odeint", action="store_true", help="N=1 headline: skip the whole-odeint() calls (odeint_ms_T2 / odeint_ms_T11)")
+    ap.add_argument("--probe-p2p", action="store_true", help=argparse.SUPPRESS)  # internal: the child of a rank, see run_p2p_probe
     ap.add_argument("--no-n1", action="store_true", help="N>1: skip rank 0's extra single-GPU run of the same global problem (n1_same_workload)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-tunable-op", action="store_true",
@@ -575,6 +821,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.probe_p2p:
+        raise SystemExit(p2p_probe_child())
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` with no launcher: this process becomes the launcher.  Nothing here has touched the
         # GPU (importing torch and counting devices do not initialise HIP), so starting children is safe.
@@ -611,21 +859,24 @@ def main():
         raise SystemExit("--gpus {} but WORLD_SIZE={}: launch one rank per GPU (or run `python bench.py --gpus N` with no "
                          "launcher, which starts the ranks itself)".format(args.gpus, world))
     # rehearsal on a one-GPU box (XDE_BENCH_REHEARSAL=1): all ranks share cuda:0 and gloo carries the collectives
-    # (RCCL refuses several ranks on one device); the driver's real runs use one GPU per rank over nccl (= RCCL)
+    # (RCCL refuses several ranks on one device); the driver's real runs use one GPU per rank
     rehearsal = os.environ.get("XDE_BENCH_REHEARSAL", "0") == "1"
     if rehearsal:
         local_rank = 0
     elif torch.cuda.device_count() < world:
         raise SystemExit("--gpus {} but this box has {} GPU(s) (XDE_BENCH_REHEARSAL=1 rehearses on one GPU over gloo)".format(
             world, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    wd = Watchdog(rank)
     dist = None
+    nccl_pg = None
     rccl_ranks = 0
-    # XDE_BENCH_FORCE_DIST=1: take the sharded code path (finalize -> RCCL all-reduce -> controller) even with one
+    p2p_probe = None
+    # XDE_BENCH_FORCE_DIST=1: take the sharded code path (finalize -> exchange -> controller) even with one
     # rank, to measure its per-step overhead on a one-GPU box
     force_dist = os.environ.get("XDE_BENCH_FORCE_DIST", "0") == "1"
-    if world > 1 or force_dist:
+    sharded = world > 1 or force_dist
+    if sharded:
         import torch.distributed as dist
 
         if world == 1:
@@ -633,11 +884,27 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
-        rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+        # The job's control plane is a gloo group (host memory, no GPU): flags, handles, the timing barrier.  Nothing below has
+        # touched the GPU yet, so the first contact of the peer-to-peer transport with this machine can be made in CHILD processes.
+        wd.stage("rendezvous (gloo control group)", 300)
+        dist.init_process_group("gloo")
+        if args.exchange in ("auto", "p2p"):
+            wd.stage("peer-to-peer probe (child processes)", 260)
+            p2p_probe = run_p2p_probe(dist, rank, world)
+            if rank == 0 and not p2p_probe["ok"]:
+                print("bench.py: the peer-to-peer probe failed ({}); not using that transport".format(p2p_probe["why"]), file=sys.stderr)
+            if args.exchange == "p2p" and not p2p_probe["ok"]:
+                raise SystemExit("--exchange p2p, but the peer-to-peer probe failed: {}".format(p2p_probe["why"]))
+        wd.stage("device + nccl group", 300)
+    torch.cuda.set_device(local_rank)
+    if sharded and not rehearsal:
+        try:
+            nccl_pg = dist.new_group(backend="nccl", device_id=device)
+        except TypeError:  # (an older signature)
+            nccl_pg = dist.new_group(backend="nccl")
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe, group=nccl_pg)  # the RCCL communicator exists and works before anything is timed
+        rccl_ranks = dist.get_world_size(nccl_pg) if float(probe.item()) == world else 0
 
     import paddlexde_amd
     from paddlexde_amd import _hip
@@ -667,33 +934,30 @@ def main():
 
     t_span = torch.tensor([0.0, 1.0e9])
     xde = BaseODE(func, y0=y0, t_span=t_span)
-    exchange, exchange_name = None, "all-reduce (torch.distributed)"
-    if world > 1 or force_dist:
-        if args.exchange == "p2p":
-            from paddlexde_amd.utils import PeerExchange
-
-            exchange, exchange_name = PeerExchange(), "peer-to-peer mailbox exchange"
-        elif args.exchange == "rccl" or (args.exchange == "auto" and not rehearsal):
-            from paddlexde_amd.utils import RcclExchange
-
-            try:
-                exchange, exchange_name = RcclExchange(), "in-stream ncclAllReduce (RCCL)"
-                ok = torch.ones(1, device=device)
-            except Exception as e:
-                if args.exchange == "rccl":
-                    raise
-                print("bench.py: RcclExchange unavailable ({}: {}); using torch.distributed all_reduce".format(type(e).__name__, e), file=sys.stderr)
-                ok = torch.zeros(1, device=device)
-            # every rank must take the same transport: one that could not build its communicator sends all of them back
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok.item()) == 0.0 and exchange is not None:
-                exchange.close()
-                exchange, exchange_name = None, "all-reduce (torch.distributed)"
-    solver = Solver(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=args.pipeline,
-                    process_group=(True if (world > 1 or force_dist) else None), norm_exchange=exchange)
-    solver.y0 = y0
-    solver._before_integrate(np.asarray([0.0, 1.0e9], dtype=np.float32))
     be = _hip.get_backend()
+
+    # -- how the per-attempt norm sums travel (N > 1): negotiated for the whole group, self-tested, with a stated fall-back ------
+    from paddlexde_amd.utils import exchange as X
+
+    exchange, exchange_kind, exchange_report = None, None, None
+    if sharded:
+        wd.stage("norm-exchange negotiation", 300)
+        if args.exchange == "auto":
+            prefer = (["p2p"] if (p2p_probe and p2p_probe["ok"]) else []) + ([] if rehearsal else ["rccl"]) + ["allreduce"]
+        else:
+            prefer = [args.exchange]
+        exchange, exchange_kind, exchange_report = X.negotiate(None, device, prefer=tuple(prefer), log=(
+            (lambda m: print("bench.py: " + m, file=sys.stderr)) if rank == 0 else None))
+
+    def group_for(kind):
+        """The process group a solver gets: the all-reduce transport needs the nccl group itself (the control group is gloo: its
+        all-reduce goes through the host); the other transports only use the group once per solve, for the global element count."""
+        return (nccl_pg if (kind == "allreduce" and nccl_pg is not None) else True) if sharded else None
+
+    def exchange_label(kind):
+        if kind == "allreduce" and nccl_pg is None:
+            return "all-reduce (torch.distributed, gloo through the host: rehearsal)"
+        return X.NAMES[kind] + (" over the nccl (= RCCL) backend" if kind == "allreduce" else "")
 
     def barrier():
         torch.cuda.synchronize()
@@ -701,32 +965,43 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # pipeline="auto" on a small state starts eagerly and captures its hipGraph after AUTO_GRAPH_AFTER attempts: let it settle
-    # (setup, like the GEMM tuning) before the W warm-up steps, so that no capture falls into the timed region
-    settle = 0
-    while args.pipeline == "auto" and solver._auto_state in (None, "sync-then-graph") and settle < 64:
-        solver.advance(4)
-        settle += 4
-    if solver._auto_state == "graph" or args.pipeline == "graph":
-        solver.advance(solver.GRAPH_ATTEMPTS + 1)  # both graphs a budgeted advance replays (4 attempts, 1 attempt) now exist
-        settle += solver.GRAPH_ATTEMPTS + 1
-    solver.advance(args.warmup)
-    barrier()
-    if not args.no_kernel_events:
-        be.prof_enable(args.event_period)
-    t0 = time.perf_counter()
-    c = solver.advance(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = None
-    if not args.no_kernel_events:
-        prof = be.prof_collect()
-        be.prof_enable(False)
+    def timed_run(kind, ex, steps, warmup, events):
+        """Build a solver on transport `kind`, let it settle, warm up, and time EXACTLY `steps` attempted steps between barriers:
+        every rank's own clock stops after its stream has drained, the job's time is the MAX over the ranks."""
+        solver = Solver(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=args.pipeline, process_group=group_for(kind),
+                        norm_exchange=ex)
+        solver.y0 = y0
+        solver._before_integrate(np.asarray([0.0, 1.0e9], dtype=np.float32))
+        # pipeline="auto" on a small state starts eagerly and captures its hipGraph after AUTO_GRAPH_AFTER attempts: let it settle
+        # (setup, like the GEMM tuning) before the W warm-up steps, so that no capture falls into the timed region
+        settle = 0
+        while args.pipeline == "auto" and solver._auto_state in (None, "sync-then-graph") and settle < 64:
+            solver.advance(4)
+            settle += 4
+        if solver._auto_state == "graph" or args.pipeline == "graph":
+            solver.advance(solver.GRAPH_ATTEMPTS + 1)  # both graphs a budgeted advance replays (4 attempts, 1 attempt) now exist
+            settle += solver.GRAPH_ATTEMPTS + 1
+        solver.advance(warmup)
+        barrier()
+        if events:
+            be.prof_enable(args.event_period)
+        t0 = time.perf_counter()
+        c = solver.advance(steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        prof = None
+        if events:
+            prof = be.prof_collect()
+            be.prof_enable(False)
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return solver, c, elapsed, prof, settle
 
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    wd.stage("set-up + warm-up + timed region", 600)
+    solver, c, elapsed, prof, settle = timed_run(exchange_kind, exchange, args.steps, args.warmup, not args.no_kernel_events)
 
     N_local = B * D
     N_global = N_local * world
@@ -754,11 +1029,13 @@ def main():
             "rows_per_gpu": B,
             "dim": D,
             "pipeline": args.pipeline if args.pipeline != "auto" else "auto -> " + str(solver._auto_state),
-            "parallelism": "batch-sharded x{} (error-norm {} only)".format(world, exchange_name)
+            "parallelism": "batch-sharded x{} (error-norm sums only: {})".format(world, exchange_label(exchange_kind))
                            if world > 1 else "single GPU",
         },
-        "norm_exchange": exchange_name if (world > 1 or force_dist) else None,
-        "rccl_ranks": rccl_ranks,  # ranks of the nccl (= RCCL) group the norm sums were all-reduced over; 0 = no RCCL group (one GPU, or a gloo rehearsal)
+        "norm_exchange": exchange_label(exchange_kind) if sharded else None,
+        # ranks of the nccl (= RCCL) group this job formed and checked (it carries the sums when the transport is "rccl" / "allreduce", and is the
+        # fall-back otherwise); 0 = no RCCL group (one GPU, or a gloo rehearsal)
+        "rccl_ranks": rccl_ranks,
         "solver": {"n_steps": int(c.n_steps), "n_accept": int(c.n_accept), "n_reject": int(c.n_reject), "t": float(c.t1),
                    "dt": float(c.dt), "settle_steps": settle},
     }
@@ -775,17 +1052,7 @@ def main():
         out["kernels"] = kern
         comb = prof["combine"]
         achieved = comb["bytes"] / (comb["ms"] * 1e-3) / 1e9 if comb["ms"] > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_combine.json")
-        if os.path.exists(tpath) and world == 1:  # the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) were taken per size, on one GPU
-            try:
-                tj = json.load(open(tpath))
-                key = "{}x{}/{}".format(B, D, args.dtype)
-                traffic = tj.get("by_size", {}).get(key, {}).get("hbm_bytes_per_launch")
-                if traffic is None and key == "65536x128/f32":
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic(B, D, args.dtype) if world == 1 else (None, "PMC passes are taken on one GPU")
         out["roofline"] = {
             "bound": "hbm",
             "kernel": "xde_combine_kernel<{}, RK, vec> (one launch per stage; with an FSAL pair the last one also emits the partial error sum)".format(
@@ -795,6 +1062,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "bytes_per_launch": comb["bytes"] / max(comb["launches"], 1),
             "avg_launch_us": 1e3 * comb["ms"] / max(comb["launches"], 1),
         }
@@ -805,40 +1073,86 @@ def main():
                                        "avg_launch_us": 1e3 * en["ms"] / en["launches"]}
         combines = comb["launches"] / max(prof["errnorm"]["launches"], 1)  # stage combines (+ the solution combine of a non-FSAL pair) per attempt
         per_step = {"combine": combines if prof["errnorm"]["launches"] else n_stage, "errnorm": 1, "control": 1,
-                    "finalize": 1 if (world > 1 or force_dist) else 0}
+                    "finalize": 1 if (sharded and exchange_kind != "p2p") else 0}
         solver_ms = sum(per_step[k] * prof[k]["ms"] / prof[k]["launches"] for k in per_step if prof[k]["launches"])
         out["solver_kernel_ms_per_step"] = solver_ms
         out["solver_only_states_per_s"] = N_local / (solver_ms * 1e-3) if solver_ms > 0 else None
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
+    def emit_main_line():  # (also what a watchdog does when an EXTRA measurement below outlives its limit: the line is never lost to one)
+        if rank == 0:
+            emit(out)
+        return 0
+
+    if sharded:
+        # who ran where: one row per rank, and whether each rank's device can address each other rank's (hipDeviceCanAccessPeer)
+        mine = {"rank": rank, "device": device.index, "name": torch.cuda.get_device_name(device),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None)}
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        out["devices"] = rows
+        out["peer_access"] = [[1 if (a["device"] == b_["device"] or torch.cuda.can_device_access_peer(a["device"], b_["device"])) else 0
+                               for b_ in rows] for a in rows] if not rehearsal else "rehearsal: every rank on device 0"
+        out["norm_exchange_report"] = {"asked": args.exchange, "tried": exchange_report, "p2p_probe": p2p_probe}
+
+    del solver
+    if world > 1 and not args.no_ab:
+        # The other transports on the same ranks, same shard, straight after the timed region (short runs, outside `value`): one visit to
+        # a multi-GPU node answers which transport is fastest there.
+        wd.stage("extra: the other norm-exchange transports", 420, on_expire=emit_main_line)
+        ab = {exchange_kind: {"ms_per_step": ms_per_step, "steps": args.steps, "headline": True}}
+        others = [k for k in ("p2p", "rccl", "allreduce") if k != exchange_kind and not (k == "p2p" and not (p2p_probe and p2p_probe["ok"]))
+                  and not (k == "rccl" and rehearsal)]
+        for kind in others:
+            try:
+                ex2, k2, _ = X.negotiate(None, device, prefer=(kind,))
+            except Exception as e:  # (group-consistent: every rank lands here together)
+                ab[kind] = {"error": "{}: {}".format(type(e).__name__, e)[:300]}
+                continue
+            steps2 = min(args.steps, 60)
+            _s, _c, el2, _p, _ = timed_run(kind, ex2, steps2, min(args.warmup, 10), False)
+            ab[kind] = {"ms_per_step": 1e3 * el2 / steps2, "steps": steps2}
+            del _s
+            if ex2 is not None:
+                ex2.close()
+        out["exchange_ab"] = ab
+
+    if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline and args.dtype == "f32":
+        wd.stage("cpu baseline", 600, on_expire=emit_main_line)
         out["cpu_baseline"], fused = cpu_baseline(B, D)
         if fused is not None:
             out["cpu_baseline_fused"] = fused
+    if rank == 0 and world == 1 and not sharded and not args.no_odeint and (B, D) == (65536, 128) and args.solver == "dopri5":
+        wd.stage("whole odeint() calls", 300, on_expire=emit_main_line)
+        try:
+            out.update(odeint_calls(func, y0, args))
+        except Exception as e:  # never lose the headline to the extra measurement
+            out["odeint_calls_error"] = "{}: {}".format(type(e).__name__, e)
 
     if exchange is not None:  # every rank leaves the per-step transport together, before rank 0 goes off on its own below
-        if dist is not None:
-            dist.barrier()
+        wd.stage("closing the exchange", 120, on_expire=emit_main_line)
+        dist.barrier()
         exchange.close()
         exchange = None
-    if world > 1 and scaling == "strong" and not args.no_n1 and rank == 0:
-        # the same GLOBAL problem on this rank alone, so that a strong-scaling efficiency can be computed from this one line
-        # (the driver's own `--gpus 1` line is config 2, a different amount of work); the other ranks wait at the barrier below
-        del solver
-        torch.cuda.empty_cache()
-        try:
-            out["n1_same_workload"] = time_unsharded(GLOBAL_C4, DIM_C4, args.dtype, args.pipeline, device, min(args.steps, 60), min(args.warmup, 10))
-            if rehearsal:
-                out["n1_same_workload"]["note"] = "rehearsal: measured while the other ranks idle on the SAME GPU"
-        except Exception as e:  # never lose the N-rank line to the extra measurement
-            out["n1_same_workload"] = {"error": "{}: {}".format(type(e).__name__, e)}
+    if world > 1 and scaling == "strong" and not args.no_n1:
+        wd.stage("extra: the same global problem on one GPU", 420, on_expire=emit_main_line)
+        if rank == 0:
+            # the same GLOBAL problem on this rank alone, so that a strong-scaling efficiency can be computed from this one line
+            # (the driver's own `--gpus 1` line is config 2, a different amount of work); the other ranks wait at the barrier below
+            torch.cuda.empty_cache()
+            try:
+                out["n1_same_workload"] = time_unsharded(GLOBAL_C4, DIM_C4, args.dtype, args.pipeline, device, min(args.steps, 60), min(args.warmup, 10))
+                if rehearsal:
+                    out["n1_same_workload"]["note"] = "rehearsal: measured while the other ranks idle on the SAME GPU"
+            except Exception as e:  # never lose the N-rank line to the extra measurement
+                out["n1_same_workload"] = {"error": "{}: {}".format(type(e).__name__, e)}
+        dist.barrier()
 
-    if exchange is not None:
-        exchange.close()
+    emit_main_line()
     if dist is not None:
+        wd.stage("teardown", 90, on_expire=lambda: 0)  # the line is out: a teardown that hangs must not turn it into a failure
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        emit(out)
+    wd.done()
 
 
 if __name__ == "__main__":

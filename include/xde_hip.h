@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XDE_ABI_VERSION 4
+#define XDE_ABI_VERSION 5
 
 #define XDE_OK 0
 #define XDE_EBADARG 1
@@ -295,6 +295,23 @@ int xde_ctrl_retarget(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const d
 int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde_ctrl_params_t* params,
                      double t_start, void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl, void* stream);
 
+/*
+ * The same heuristic for SMALL states with its three norm passes inside (ABI 5): one workgroup per phase instead of
+ * xde_scaled_norm_partial + xde_norm_finalize + xde_norm_result (x3) + xde_initial_step (x2) + xde_ctrl_init — 12 launches become 2
+ * (+ the Euler probe's xde_stage_combine between them).  odeint_adjoint's backward pass starts one solve per output interval
+ * (functional/odeint_adjoint.py:134-159), each with this heuristic in front (solver/base_adaptive_solver.py:33-72).
+ *   phase 0: a = f0.  d0 = norm(y0/scale), d1 = norm(f0/scale) in ONE pass (scale = atol + |y0| rtol, :50-53), then phase 0 of
+ *            xde_initial_step: hs_dev[0..2] = {d0, d1, h0}, ctrl->dt = direction*h0, *t_probe_out = t_start + direction*h0.
+ *   phase 1: a = f1, b = f0.  norm((f1 - f0)/scale) (:64), phase 1 of xde_initial_step (hs_dev[3] = the first step, hs_dev[4] =
+ *            that norm), and the control block's construction exactly as xde_ctrl_init(first_step_dev = hs_dev + 3) does it.
+ *   rtol / atol / norm kind / segment counts come from params; segs as in xde_scaled_norm_partial; hs_dev: 5 doubles.
+ *   States above 2^20 elements are refused (one workgroup): use the separate calls.
+ */
+int xde_initial_step_fused(int phase, const void* a, const void* b, const void* y0, const xde_segments_t* segs, int dtype, double* hs_dev,
+                           const xde_ctrl_params_t* params, double t_start, void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl,
+                           int32_t n_out, const double* t_span_dev, const double* step_t_dev, void* t_stage_out, int64_t seq0,
+                           void* stream);
+
 /* Blocking device->host copy of the control block (hipMemcpyAsync + stream synchronise). */
 int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream);
 
@@ -404,8 +421,15 @@ int xde_pack_segments(void* flat_out, const void* const* srcs, const int64_t* st
  *   peer_mailboxes: host array of `world` device pointers, peer_mailboxes[rank] == local_mailbox.
  * Failure is group-wide: the rank whose wait ran out also marks every PEER's mailbox, so a peer still waiting stops inside
  * its wait and a peer that had already completed that exchange stops at its next one — no rank runs on alone, none posts again.
- *   xde_p2p_error: error_out[3] = {exchange number of the first failed exchange on this rank (0 = none), exchange number a
- *   peer reported (0 = none), that peer's rank + 1}.
+ *   xde_p2p_error: *error_out = exchange number of the first failed exchange on this rank (0 = none) — ONE word, as in ABI <= 3.
+ *   xde_p2p_error_info (ABI 5; ABI 4 wrote these three words through xde_p2p_error, overrunning a caller built against ABI 3):
+ *   info_out[n_out = 3] = {that number, the exchange number a peer reported (0 = none), that peer's rank + 1}.
+ *
+ * xde_p2p_rk_control (ABI 5) — the sharded attempt's finalize -> exchange -> controller as ONE launch: xde_norm_finalize's fixed-order
+ * reduction of the error-norm launch's partial records in `ws` (slot 0), the mailbox exchange of the per-segment sums (as
+ * xde_p2p_exchange: same protocol, same counter, same failure behaviour — the two calls may be mixed), and xde_rk_control on the
+ * global sums, by one workgroup.  Bit-identical to the three launches; one dependent launch per attempt instead of three, and still
+ * capturable into a hipGraph.  norm_kind comes from params.
  */
 #define XDE_P2P_MAX_RANKS 16
 #define XDE_P2P_HANDLE_BYTES 64
@@ -418,6 +442,10 @@ int xde_p2p_close(void* ptr);
 int xde_p2p_exchange(double* sums_dev, void* local_mailbox, void* const* peer_mailboxes, int world, int rank,
                      int norm_kind, int64_t spin_limit, void* stream);
 int xde_p2p_error(const void* local_mailbox, int64_t* error_out, void* stream);
+int xde_p2p_error_info(const void* local_mailbox, int64_t* info_out, int n_out, void* stream);
+int xde_p2p_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void* ws, void* local_mailbox,
+                       void* const* peer_mailboxes, int world, int rank, int64_t spin_limit, const double* t_span_dev,
+                       const double* step_t_dev, void* t_stage_out, xde_ctrl_t* host_mirror, void* stream);
 
 /*
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the

@@ -14,7 +14,7 @@ import torch
 
 XDE_OK, XDE_EBADARG, XDE_EHIP, XDE_ETIMEOUT = 0, 1, 2, 3
 XDE_MIRROR_SLOTS = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
 XDE_MAX_PACK = 64
@@ -45,6 +45,7 @@ SYMBOLS = (
     "xde_ctrl_init",
     "xde_ctrl_retarget",
     "xde_initial_step",
+    "xde_initial_step_fused",
     "xde_ctrl_read",
     "xde_host_alloc",
     "xde_host_free",
@@ -64,6 +65,8 @@ SYMBOLS = (
     "xde_p2p_close",
     "xde_p2p_exchange",
     "xde_p2p_error",
+    "xde_p2p_error_info",
+    "xde_p2p_rk_control",
     "xde_prof_enable",
     "xde_prof_collect",
 )
@@ -217,6 +220,9 @@ def load_library():
         lib.xde_ctrl_retarget.argtypes = [vp, C.POINTER(XdeCtrlParams), vp, C.c_int32, vp, vp]
         lib.xde_initial_step.restype = i32
         lib.xde_initial_step.argtypes = [i32, vp, vp, C.POINTER(XdeCtrlParams), dbl, vp, i32, vp, vp]
+        lib.xde_initial_step_fused.restype = i32
+        lib.xde_initial_step_fused.argtypes = [i32, vp, vp, vp, C.POINTER(XdeSegments), i32, vp, C.POINTER(XdeCtrlParams), dbl, vp, i32, vp,
+                                               C.c_int32, vp, vp, vp, i64, vp]
         lib.xde_host_alloc.restype = i32
         lib.xde_host_alloc.argtypes = [i64, C.POINTER(C.c_void_p)]
         lib.xde_host_free.restype = i32
@@ -254,6 +260,10 @@ def load_library():
         lib.xde_pack_segments.argtypes = [vp, vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp, i32, i64, i32, vp]
         lib.xde_p2p_error.restype = i32
         lib.xde_p2p_error.argtypes = [vp, C.POINTER(C.c_int64), vp]
+        lib.xde_p2p_error_info.restype = i32
+        lib.xde_p2p_error_info.argtypes = [vp, C.POINTER(C.c_int64), i32, vp]
+        lib.xde_p2p_rk_control.restype = i32
+        lib.xde_p2p_rk_control.argtypes = [vp, C.POINTER(XdeCtrlParams), vp, vp, vpp, i32, i32, i64, vp, vp, vp, vp, vp]
         lib.xde_prof_enable.restype = i32
         lib.xde_prof_enable.argtypes = [i32]
         lib.xde_prof_collect.restype = i32
@@ -481,12 +491,38 @@ class HipBackend:
         if m is not None and not self._is_capturing():
             m.seq += 1
 
+    def p2p_rk_control(self, ctrl, params, ws, exchange, t_span_dev, step_t_dev, t_stage):
+        """finalize -> peer-to-peer exchange -> controller of a sharded attempt as ONE launch (``exchange``: a utils.PeerExchange)."""
+        self._require_device(ctrl, ws, t_span_dev, t_stage)
+        m = self._mirrors.get(ctrl.data_ptr())
+        rc = self.lib.xde_p2p_rk_control(ctrl.data_ptr(), C.byref(params), ws.data_ptr(), exchange._local, exchange._peers,
+                                         exchange.world, exchange.rank, exchange.SPIN_LIMIT, t_span_dev.data_ptr(), _ptr(step_t_dev),
+                                         t_stage.data_ptr(), m.ptr if m is not None else None, self._stream(ctrl))
+        self._check(rc, "xde_p2p_rk_control")
+        if m is not None and not self._is_capturing():
+            m.seq += 1
+
     def initial_step(self, phase, res, hs, params, t_start, t_probe, ctrl):
         """Scalar part of select_initial_step on the device (phase 0: h0; phase 1: the first step)."""
         self._require_device(res, hs, ctrl, t_probe)
         rc = self.lib.xde_initial_step(int(phase), res.data_ptr(), hs.data_ptr(), C.byref(params), float(t_start), _ptr(t_probe),
                                        dtype_code(t_probe.dtype) if t_probe is not None else XDE_F32, ctrl.data_ptr(), self._stream(ctrl))
         self._check(rc, "xde_initial_step")
+
+    def initial_step_fused(self, phase, a, b, y0, segs, hs, params, t_start, t_probe, ctrl, n_out=0, t_span_dev=None, step_t_dev=None,
+                           t_stage=None):
+        """The initial-step heuristic of a small state, one workgroup per phase (phase 1 also constructs the control block, like
+        ctrl_init with the device-resident first step)."""
+        self._require_device(a, b, y0, hs, ctrl, t_probe, t_span_dev, t_stage)
+        m = self._mirrors.get(ctrl.data_ptr()) if phase == 1 else None
+        seq0 = m.seq if m is not None else 0
+        rc = self.lib.xde_initial_step_fused(int(phase), a.data_ptr(), _ptr(b), y0.data_ptr(), C.byref(segs), dtype_code(y0.dtype), hs.data_ptr(),
+                                             C.byref(params), float(t_start), _ptr(t_probe),
+                                             dtype_code(t_probe.dtype) if t_probe is not None else XDE_F32, ctrl.data_ptr(), int(n_out),
+                                             _ptr(t_span_dev), _ptr(step_t_dev), _ptr(t_stage), seq0, self._stream(y0))
+        self._check(rc, "xde_initial_step_fused")
+        if m is not None:
+            m.seq0 = seq0
 
     def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None):
         self._require_device(ctrl, t_span_dev, t_stage)
@@ -568,8 +604,12 @@ class HipBackend:
         n = len(tensors)
         if n < 1 or n > XDE_MAX_PACK or not flat.is_cuda or flat.dtype not in (torch.float32, torch.float64):
             return False
-        for x in tensors:
-            if x.dtype != flat.dtype or x.device != flat.device or not x.is_contiguous():
+        if len(segs) != n:
+            return False
+        for x, (_, length) in zip(tensors, segs):
+            # (a member whose element count is not its segment's — a func that returned a wrong-shaped or broadcastable member —
+            # must not reach the kernel, which reads `length` elements from it: the framework-op pack raises, or broadcasts, as before)
+            if x.dtype != flat.dtype or x.device != flat.device or not x.is_contiguous() or x.numel() != int(length):
                 return False
         srcs = (C.c_void_p * n)(*[x.data_ptr() if x.numel() else None for x in tensors])
         starts = (C.c_int64 * n)(*[int(s) for s, _ in segs])

@@ -29,6 +29,20 @@ FLAGS = [
 ]
 
 
+def kernel_stamp(kernel="combine"):
+    """12 hex digits identifying the SOURCES of one kernel family (bench.py stamps recorded counter passes with it: a recorded HBM-traffic
+    figure is only reported for the kernel source it was measured on)."""
+    import hashlib
+
+    files = {"combine": ["xde_combine.hip", "xde_common.hpp"],
+             "errnorm": ["xde_norm.hip", "xde_errnorm_device.hpp", "xde_reduce.hpp", "xde_common.hpp"]}[kernel]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(HERE, f), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:12]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

@@ -131,16 +131,16 @@ __global__ __launch_bounds__(kSingleBlock) void xde_errnorm_control_single_kerne
   control_tail(tl.ctrl, tl.p, seg_val, seg_nf, tl.t_span, tl.step_t, tl.t_stage_out, tl.mirror, flags, &zs, &pfs);
 }
 
-__global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
-                                     int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
-                                     int64_t seq0, const double* first_step_dev) {
-  __shared__ xde_ctrl_t z;  // (LDS, not a private copy: no scratch)
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Construction of the control block before the first step (`_RungeKuttaState(y0, f0, t[0], t[0], first_step, ...)`,
+// base_adaptive_solver_rk.py:89-92, and the step_t bookkeeping :95-111); `z` is an LDS scratch copy (no private copy: no scratch memory).
+// One thread.
+__device__ __forceinline__ void ctrl_init_body(xde_ctrl_t* c, const xde_ctrl_params_t& p, double t_start, double first_step_signed,
+                                               int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
+                                               int64_t seq0, xde_ctrl_t& z) {
   for (int i = 0; i < int(sizeof(xde_ctrl_t) / 8); ++i) reinterpret_cast<uint64_t*>(&z)[i] = 0;
   z.t0 = t_start;
   z.t1 = t_start;
-  // device-resident first step (xde_initial_step): a magnitude, given the direction's sign here
-  z.dt = first_step_dev ? double(p.direction) * fabs(*first_step_dev) : first_step;
+  z.dt = first_step_signed;
   if (p.replay && p.n_replay > 0) z.dt = p.replay[0];  // prescribed step sequence: the first attempt's step
   z.n_out = n_out;
   z.ratio_prev = 1e-4;
@@ -166,6 +166,16 @@ __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double 
   else
     plan_next<double>(&z, p, step_t, t_stage_out);
   for (int i = 0; i < int(sizeof(xde_ctrl_t) / 8); ++i) reinterpret_cast<uint64_t*>(c)[i] = reinterpret_cast<const uint64_t*>(&z)[i];
+}
+
+__global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double t_start, double first_step,
+                                     int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
+                                     int64_t seq0, const double* first_step_dev) {
+  __shared__ xde_ctrl_t z;  // (LDS, not a private copy: no scratch)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // device-resident first step (xde_initial_step): a magnitude, given the direction's sign here
+  const double first = first_step_dev ? double(p.direction) * fabs(*first_step_dev) : first_step;
+  ctrl_init_body(c, p, t_start, first, n_out, t_span, step_t, t_stage_out, seq0, z);
 }
 
 // New output list for a running solve (AdaptiveRKSolver.step(next_t), base_adaptive_solver_rk.py:116-127): rows of the new
@@ -256,6 +266,105 @@ __global__ void xde_initial_step_kernel(int phase, const double* res, double* hs
     initial_step_phase<double>(phase, res, hs, p, t_start, t_probe_out, probe_dtype, c);
 }
 
+
+// The initial-step heuristic for SMALL states as one workgroup per phase (round 4): the adjoint's backward pass starts a solve per
+// output interval, and the heuristic's 3 norm passes + 3 finalize + 3 result + 2 scalar launches + ctrl_init were 12 of that solve's
+// launches on a 33 021-element state.  Phase 0: norm(y0/scale) and norm(f0/scale) in ONE pass (they share `scale`), then the phase-0
+// scalars (h0 -> ctrl->dt, t0 + h0).  Phase 1: norm((f1 - f0)/scale), the phase-1 scalars, and the control block's construction
+// (xde_ctrl_init's arithmetic).  The Euler probe between them stays an xde_stage_combine that reads dt from ctrl.
+struct InitArgs {
+  const void* a;   // phase 0: f0; phase 1: f1
+  const void* b;   // phase 1: f0
+  const void* y0;
+  SegMap map;
+  double rtol, atol;
+  double* hs;
+  double t_start;
+  void* t_probe_out;
+  int probe_dtype;
+  int phase;
+  int32_t n_out;
+  const double* t_span;
+  const double* step_t;
+  void* t_stage_out;
+  int64_t seq0;
+};
+
+template <typename T, int NORM, bool VEC>
+__global__ __launch_bounds__(kSingleBlock) void xde_initial_step_single_kernel(InitArgs g, xde_ctrl_params_t p, xde_ctrl_t* c) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  __shared__ double w_val[2][kSingleWaves][XDE_MAX_SEG];
+  __shared__ double seg_val[2][XDE_MAX_SEG];
+  __shared__ xde_ctrl_t z;
+  const T* __restrict__ a = static_cast<const T*>(g.a);
+  const T* __restrict__ b = static_cast<const T*>(g.b);
+  const T* __restrict__ y0 = static_cast<const T*>(g.y0);
+  const T rtol = T(g.rtol), atol = T(g.atol);
+  const bool diff = g.phase == 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int seg = 0; seg < g.map.n_seg; ++seg) {
+    const int64_t start = g.map.seg_start[seg], len = g.map.seg_len[seg];
+    const int64_t nvec = len / W, vbase = start / W;
+    T acc0 = T(0), acc1 = T(0);
+    auto one = [&](T av, T bv, T yv) {
+      const T scale = atol + abs_(yv) * rtol;
+      // phase 0: r0 = |y0 / scale|, r1 = |f0 / scale|;  phase 1: r0 = |(f1 - f0) / scale|
+      const T r0 = abs_((diff ? (av - bv) : yv) / scale);
+      const T r1 = diff ? T(0) : abs_(av / scale);
+      if (NORM == XDE_NORM_RMS) {
+        acc0 = acc0 + r0 * r0;
+        acc1 = acc1 + r1 * r1;
+      } else {
+        acc0 = (r0 != r0 || acc0 != acc0) ? (r0 != r0 ? r0 : acc0) : (r0 > acc0 ? r0 : acc0);
+        acc1 = (r1 != r1 || acc1 != acc1) ? (r1 != r1 ? r1 : acc1) : (r1 > acc1 ? r1 : acc1);
+      }
+    };
+    for (int64_t i = threadIdx.x; i < nvec; i += kSingleBlock) {  // (a state this kernel serves is <= 16 such iterations: no fp64 flush needed)
+      P av = P::load(a, vbase + i);
+      P yv = P::load(y0, vbase + i);
+      P bv = av;
+      if (diff) bv = P::load(b, vbase + i);
+#pragma unroll
+      for (int w = 0; w < W; ++w) one(av.v[w], bv.v[w], yv.v[w]);
+    }
+    if (VEC) {
+      const int64_t i = start + nvec * W + threadIdx.x;
+      if (i < start + len) one(a[i], diff ? b[i] : a[i], y0[i]);
+    }
+    double v0 = double(acc0), v1 = double(acc1);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      v0 = merge_<NORM>(v0, __shfl_down(v0, off, 64));
+      v1 = merge_<NORM>(v1, __shfl_down(v1, off, 64));
+    }
+    if (lane == 0) {
+      w_val[0][wave][seg] = v0;
+      w_val[1][wave][seg] = v1;
+    }
+  }
+  __syncthreads();
+  if (int(threadIdx.x) < 2 * g.map.n_seg) {
+    const int which = threadIdx.x / g.map.n_seg, seg = threadIdx.x % g.map.n_seg;
+    double v = w_val[which][0][seg];
+#pragma unroll
+    for (int w = 1; w < kSingleWaves; ++w) v = merge_<NORM>(v, w_val[which][w][seg]);
+    seg_val[which][seg] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double res[2];
+  res[0] = norm_from_sums(seg_val[0], p.seg_count, p.n_seg, NORM, p.state_dtype, nullptr);
+  res[1] = diff ? 0.0 : norm_from_sums(seg_val[1], p.seg_count, p.n_seg, NORM, p.state_dtype, nullptr);
+  if (p.state_dtype == XDE_F32)
+    initial_step_phase<float>(g.phase, res, g.hs, p, g.t_start, g.t_probe_out, g.probe_dtype, c);
+  else
+    initial_step_phase<double>(g.phase, res, g.hs, p, g.t_start, g.t_probe_out, g.probe_dtype, c);
+  if (diff) {
+    g.hs[4] = res[0];  // (the third norm, for the parity tests)
+    ctrl_init_body(c, p, g.t_start, double(p.direction) * fabs(g.hs[3]), g.n_out, g.t_span, g.step_t, g.t_stage_out, g.seq0, z);
+  }
+}
 
 }  // namespace
 
@@ -393,6 +502,70 @@ int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(xde_initial_step_kernel, dim3(1), dim3(64), 0, st, phase, res_dev, hs_dev, *params, t_start, t_probe_out,
                      probe_dtype, ctrl);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_initial_step_fused(int phase, const void* a, const void* b, const void* y0, const xde_segments_t* segs, int dtype, double* hs_dev,
+                           const xde_ctrl_params_t* params, double t_start, void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl,
+                           int32_t n_out, const double* t_span_dev, const double* step_t_dev, void* t_stage_out, int64_t seq0,
+                           void* stream) {
+  if (!a || !y0 || !hs_dev || !ctrl) return fail(XDE_EBADARG, "xde_initial_step_fused: null pointer");
+  if (phase != 0 && phase != 1) return fail(XDE_EBADARG, "xde_initial_step_fused: phase must be 0 or 1");
+  if (phase == 0 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step_fused: phase 0 needs t_probe_out");
+  if (phase == 1 && (!b || !t_span_dev || !t_stage_out)) return fail(XDE_EBADARG, "xde_initial_step_fused: phase 1 needs b, t_span_dev and t_stage_out");
+  if (phase == 1 && n_out < 1) return fail(XDE_EBADARG, "xde_initial_step_fused: n_out must be >= 1");
+  if (probe_dtype != XDE_F32 && probe_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step_fused: bad probe dtype");
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step_fused: bad dtype");
+  int rc = check_params(params, "xde_initial_step_fused");
+  if (rc != XDE_OK) return rc;
+  if (int rc0 = check_segments(segs)) return rc0;
+  if (segs->n_seg != params->n_seg) return fail(XDE_EBADARG, "xde_initial_step_fused: segments do not match params->n_seg");
+  if (dtype != params->state_dtype) return fail(XDE_EBADARG, "xde_initial_step_fused: dtype does not match params->state_dtype");
+  if (phase == 1 && params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_initial_step_fused: n_step_t > 0 without step_t_dev");
+  int64_t total = 0;
+  for (int s2 = 0; s2 < segs->n_seg; ++s2) total += segs->seg_len[s2];
+  if (total > (int64_t(1) << 20)) return fail(XDE_EBADARG, "xde_initial_step_fused: one workgroup serves small states only (<= 2^20 elements)");
+  InitArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = a;
+  g.b = b;
+  g.y0 = y0;
+  g.rtol = params->rtol;
+  g.atol = params->atol;
+  g.hs = hs_dev;
+  g.t_start = t_start;
+  g.t_probe_out = t_probe_out;
+  g.probe_dtype = probe_dtype;
+  g.phase = phase;
+  g.n_out = n_out;
+  g.t_span = t_span_dev;
+  g.step_t = step_t_dev;
+  g.t_stage_out = t_stage_out;
+  g.seq0 = seq0;
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const bool vec = aligned16(a) && aligned16(y0) && (!b || aligned16(b)) && segs_vec_ok(segs, width);
+  int nblocks = 0;
+  rc = build_segmap(segs, vec ? width : 1, vec, &g.map, &nblocks);
+  if (rc != XDE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_SCALEDNORM, (phase == 0 ? 2.0 : 3.0) * double(total) * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 g1(1), b1(kSingleBlock);
+#define LAUNCH_IS(T, NORM)                                                                              \
+  do {                                                                                                  \
+    if (vec)                                                                                            \
+      XDE_LAUNCH((xde_initial_step_single_kernel<T, NORM, true>), g1, b1, st, prof, g, *params, ctrl);   \
+    else                                                                                                \
+      XDE_LAUNCH((xde_initial_step_single_kernel<T, NORM, false>), g1, b1, st, prof, g, *params, ctrl);  \
+  } while (0)
+  if (dtype == XDE_F32) {
+    if (params->norm_kind == XDE_NORM_RMS) LAUNCH_IS(float, XDE_NORM_RMS);
+    else LAUNCH_IS(float, XDE_NORM_LINF);
+  } else {
+    if (params->norm_kind == XDE_NORM_RMS) LAUNCH_IS(double, XDE_NORM_RMS);
+    else LAUNCH_IS(double, XDE_NORM_LINF);
+  }
+#undef LAUNCH_IS
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

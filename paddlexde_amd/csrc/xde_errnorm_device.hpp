@@ -82,6 +82,108 @@ __device__ __forceinline__ void errnorm_body(const ErrArgs& a, const T* __restri
   nf_out = nf;
 }
 
+// non-finite test as ONE VALU instruction (v_cmp_class: sNaN | qNaN | -inf | +inf); the count is taken per WAVE on the scalar unit
+// (s_bcnt1 of the compare mask), so it costs the vector pipe nothing more — (x - x) == 0 was sub + compare + select + add per element
+__device__ __forceinline__ bool nonfinite_class(float x) { return __builtin_amdgcn_classf(x, 0x207); }
+__device__ __forceinline__ bool nonfinite_class(double x) { return __builtin_amdgcn_class(x, 0x207); }
+
+// The FSAL pair's error-norm pass (Dopri5 and friends: e = e_pre + k_S * (dt * c_S), vector path) as a kernel body of its own.
+//   * The operands whose address does not depend on the control block (y1, e_pre, k_S) are requested BEFORE the block's
+//     dt / accept words are waited for; only y0 (the speculative pipeline's select) follows them.
+//   * The loop is software-pipelined by hand: the loads of vector i + stride are issued before vector i is reduced, so a lane
+//     keeps 8 x 16 bytes in flight while it divides (at config 4's shard size a lane runs 8 iterations and the launch holds
+//     only 2 waves per SIMD: there is nobody else to hide the ~100 VALU instructions of an iteration behind).
+// Same per-lane summation order as errnorm_body (same indices, same fp32 accumulate, same 64-iteration fp64 flush): same bits.
+template <typename T, int NORM, bool NT>
+__device__ __forceinline__ void errnorm_pre_body(const ErrArgs& a, int seg, int lb, int nb, double& acc_out, double& nf_out) {
+  using P = Pack<T, true>;
+  constexpr int W = P::W;
+  const T* __restrict__ epre = static_cast<const T*>(a.e_pre);
+  const T* __restrict__ kl = static_cast<const T*>(a.k[0]);
+  const T* __restrict__ y1 = static_cast<const T*>(a.y1);
+  const int64_t start = a.map.seg_start[seg];
+  const int64_t len = a.map.seg_len[seg];
+  const int64_t nvec = len / W;
+  const int64_t vbase = start / W;
+  const int64_t stride = int64_t(nb) * kBlock;
+  const int64_t i0 = int64_t(lb) * kBlock + threadIdx.x;
+  // the control block's two words are REQUESTED here and waited for only where y0's address is formed, below the first loads
+  double dtd = a.dt_host;
+  int32_t accw = 0;
+  if (a.ctrl) {
+    dtd = __builtin_nontemporal_load(&a.ctrl->dt);
+    accw = __builtin_nontemporal_load(&a.ctrl->accept);
+  }
+  const T rtol = T(a.rtol), atol = T(a.atol);
+  T acc = T(0);
+  double acc64 = 0.0;
+  int it = 0;
+  int nfw = 0;  // per-wave count, complete in the wave's first lane (it has the smallest index: active whenever any lane is)
+  T c = T(0);
+  const T* __restrict__ y0 = static_cast<const T*>(a.y0[0]);
+  auto one = [&](T e, T y0e, T y1e) {
+    T tol = atol + rtol * fmax_(abs_(y0e), abs_(y1e));
+    T ar = abs_(e / tol);
+    if (NORM == XDE_NORM_RMS) {
+      acc = acc + ar * ar;
+    } else {
+      acc = (ar != ar || acc != acc) ? (ar != ar ? ar : acc) : (ar > acc ? ar : acc);
+    }
+    nfw += __popcll(__ballot(nonfinite_class(y0e)));
+  };
+  auto reduce_vec = [&](const P& epv, const P& kv, const P& y0v, const P& y1v) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) one(epv.v[w] + kv.v[w] * c, y0v.v[w], y1v.v[w]);
+    if (NORM == XDE_NORM_RMS && (++it & 63) == 0) {
+      acc64 += double(acc);
+      acc = T(0);
+    }
+  };
+  if (i0 < nvec) {
+    P y1v = P::load(y1, vbase + i0);
+    P ep = NT ? P::load_nt(epre, vbase + i0) : P::load(epre, vbase + i0);
+    P kk = P::load(kl, vbase + i0);
+    const int sel = (a.use_sel && accw) ? 1 : 0;
+    y0 = static_cast<const T*>(a.y0[sel]);
+    P y0v = NT ? P::load_nt(y0, vbase + i0) : P::load(y0, vbase + i0);
+    c = T(dtd) * T(a.coef[0]);  // `dt * tableau.c_error`
+    for (int64_t in = i0 + stride; in < nvec; in += stride) {
+      // (no condition inside the body: the next vector's four loads are in flight while the current one is reduced)
+      P y1n = P::load(y1, vbase + in);
+      P epn = NT ? P::load_nt(epre, vbase + in) : P::load(epre, vbase + in);
+      P kn = P::load(kl, vbase + in);
+      P y0n = NT ? P::load_nt(y0, vbase + in) : P::load(y0, vbase + in);
+      reduce_vec(ep, kk, y0v, y1v);
+      y1v = y1n;
+      ep = epn;
+      kk = kn;
+      y0v = y0n;
+    }
+    reduce_vec(ep, kk, y0v, y1v);
+  }
+  if (lb == 0) {  // the scalar tail of the segment (len % W elements)
+    y0 = static_cast<const T*>(a.y0[(a.use_sel && accw) ? 1 : 0]);
+    c = T(dtd) * T(a.coef[0]);
+    const int64_t j = start + nvec * W + threadIdx.x;
+    const bool t = j < start + len;
+    T e = T(0), y0e = T(0), y1e = T(1);
+    if (t) {
+      e = epre[j] + kl[j] * c;
+      y0e = y0[j];
+      y1e = y1[j];
+    }
+    if (t) {
+      T tol = atol + rtol * fmax_(abs_(y0e), abs_(y1e));
+      T ar = abs_(e / tol);
+      if (NORM == XDE_NORM_RMS) acc = acc + ar * ar;
+      else acc = (ar != ar || acc != acc) ? (ar != ar ? ar : acc) : (ar > acc ? ar : acc);
+    }
+    nfw += __popcll(__ballot(t && nonfinite_class(y0e)));
+  }
+  acc_out = NORM == XDE_NORM_RMS ? acc64 + double(acc) : double(acc);
+  nf_out = (threadIdx.x & 63) == 0 ? double(nfw) : 0.0;  // one lane per wave carries the wave's count into the reduction
+}
+
 // operand count > 8 (Dopri8): runtime loop over operands, same arithmetic order
 template <typename T, int NORM, bool VEC>
 __device__ void errnorm_generic(const ErrArgs& a, const T* __restrict__ y0, const T* __restrict__ k0, T dt, int seg,

@@ -45,6 +45,22 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_kernel(ErrArgs a) {
   block_reduce_store<NORM>(acc, double(nf), a.slot, seg);
 }
 
+// The FSAL pair's pass (e_pre + one derivative, vector path): errnorm_pre_body — loads ahead of the control-block read, hand-pipelined loop
+template <typename T, int NORM, bool NT>
+__global__ __launch_bounds__(kBlock) void xde_errnorm_pre_kernel(ErrArgs a) {
+  const int seg = find_segment(a.map, blockIdx.x);
+  const int lb = blockIdx.x - a.map.seg_blk[seg];
+  const int nb = a.map.seg_blk[seg + 1] - a.map.seg_blk[seg];
+  double acc = 0.0, nf = 0.0;
+  errnorm_pre_body<T, NORM, NT>(a, seg, lb, nb, acc, nf);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.slot->nblocks = gridDim.x;
+    a.slot->n_seg = a.map.n_seg;
+    a.slot->norm_kind = NORM;
+  }
+  block_reduce_store<NORM>(acc, nf, a.slot, seg);
+}
+
 template <typename T, int NORM, bool VEC>
 __global__ __launch_bounds__(kBlock) void xde_errnorm_wide_kernel(ErrArgs a) {
   int sel = 0;
@@ -237,9 +253,18 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_ERRNORM, bytes);
   dim3 g(nblocks), b(kBlock);
+  static const int pre_variant = [] {
+    const char* e = getenv("XDE_ERRNORM_PRE");
+    return (e && *e) ? atoi(e) : 1;
+  }();
+  const bool pre = vec && e_pre && nk == 1 && a.k0_alt == a.k[0] && pre_variant != 0;
 #define LAUNCH_ERR(T, NORM)                                                       \
   do {                                                                            \
-    if (vec && nk > 8 && !e_pre)                                                  \
+    if (pre && a.nt)                                                              \
+      XDE_LAUNCH((xde_errnorm_pre_kernel<T, NORM, true>), g, b, st, prof, a);     \
+    else if (pre)                                                                 \
+      XDE_LAUNCH((xde_errnorm_pre_kernel<T, NORM, false>), g, b, st, prof, a);    \
+    else if (vec && nk > 8 && !e_pre)                                             \
       XDE_LAUNCH((xde_errnorm_wide_kernel<T, NORM, true>), g, b, st, prof, a);    \
     else if (vec)                                                                 \
       XDE_LAUNCH((xde_errnorm_kernel<T, NORM, true>), g, b, st, prof, a);    \

@@ -24,6 +24,8 @@
 #include <cstddef>
 
 #include "xde_common.hpp"
+#include "xde_reduce.hpp"
+#include "xde_control_device.hpp"
 
 using namespace xde;
 
@@ -50,68 +52,65 @@ struct Peers {
   P2PMailbox* p[XDE_P2P_MAX_RANKS];
 };
 
-__global__ __launch_bounds__(64) void xde_p2p_exchange_kernel(double* sums, P2PMailbox* local, Peers peers, int world,
-                                                              int rank, int norm_kind, int64_t spin_limit) {
-  __shared__ int64_t s_seq;
-  __shared__ int s_timeout;  // this rank's own wait ran out
-  __shared__ int s_aborted;  // a peer said so, or an earlier exchange had already failed here
-  const int lane = threadIdx.x;
+// One exchange, executed by ONE wave (all 64 lanes active; wave-level control flow only, so that it can sit inside a larger
+// workgroup): `vec` — kVec doubles in LDS or global memory, readable and writable by this wave — is replaced by the rank-ordered
+// sum (XDE_NORM_LINF: max for its first XDE_MAX_SEG entries) over all ranks, or by the "stop" vector when the exchange failed.
+__device__ __forceinline__ bool p2p_exchange_wave(double* vec, P2PMailbox* local, const Peers& peers, int world, int rank, int norm_kind,
+                                                  int64_t spin_limit) {
+  const int lane = threadIdx.x & 63;
+  int64_t q = 0;
+  int dead = 0;
   if (lane == 0) {
-    const int64_t q = local->xseq + 1;
+    q = local->xseq + 1;
     local->xseq = q;
-    s_seq = q;
-    s_timeout = 0;
-    s_aborted = (local->error != 0 || __hip_atomic_load(&local->abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1 : 0;
+    dead = (local->error != 0 || __hip_atomic_load(&local->abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1 : 0;
   }
-  __syncthreads();
-  const int64_t q = s_seq;
+  q = __shfl(q, 0, 64);
+  dead = __shfl(dead, 0, 64);
   const int sl = int(q % kP2PSlots);
-  const bool dead_on_entry = s_aborted != 0;  // (uniform: read before anybody can set it below)
-  __syncthreads();
-  if (!dead_on_entry) {
-
-  // ---- post: 32 lanes x N peers write-through stores over xGMI (uncached destination) ----
-  if (lane < kVec) {
-    const uint64_t bits = uint64_t(__double_as_longlong(sums[lane]));
-    for (int p = 0; p < world; ++p)
-      __hip_atomic_store(reinterpret_cast<uint64_t*>(&peers.p[p]->slot[sl].data[rank][lane]), bits, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  __threadfence_system();  // wave-wide: every lane's data stores are acknowledged before any flag store is issued
-  if (lane < world)
-    __hip_atomic_store(&peers.p[lane]->slot[sl].flag[rank], q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-
-  // ---- wait: lane r polls the flag of rank r in the LOCAL mailbox; bounded ----
-  if (lane < world) {
-    int64_t spins = 0;
-    while (__hip_atomic_load(&local->slot[sl].flag[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != q) {
-      if (__hip_atomic_load(&local->abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
-        s_aborted = 1;
-        break;
+  int my_timeout = 0, my_abort = 0;
+  if (!dead) {  // (wave-uniform)
+    // ---- post: 32 lanes x N peers write-through stores over xGMI (uncached destination) ----
+    if (lane < kVec) {
+      const uint64_t bits = uint64_t(__double_as_longlong(vec[lane]));
+      for (int p = 0; p < world; ++p)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(&peers.p[p]->slot[sl].data[rank][lane]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();  // wave-wide: every lane's data stores are acknowledged before any flag store is issued
+    if (lane < world)
+      __hip_atomic_store(&peers.p[lane]->slot[sl].flag[rank], q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- wait: lane r polls the flag of rank r in the LOCAL mailbox; bounded ----
+    if (lane < world) {
+      int64_t spins = 0;
+      while (__hip_atomic_load(&local->slot[sl].flag[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != q) {
+        if (__hip_atomic_load(&local->abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+          my_abort = 1;
+          break;
+        }
+        if (++spins > spin_limit) {
+          my_timeout = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
       }
-      if (++spins > spin_limit) {
-        s_timeout = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
     }
   }
-  }  // !dead_on_entry
-  __syncthreads();
+  const bool timeout = __any(my_timeout) != 0;
+  const bool aborted = dead != 0 || __any(my_abort) != 0;
   __threadfence_system();
-  const bool failed = s_timeout != 0 || s_aborted != 0;
-  if (s_timeout != 0 && lane < world && lane != rank) {
+  const bool failed = timeout || aborted;
+  if (timeout && lane < world && lane != rank) {
     // tell the peers: they stop at once (inside their wait) or at their next exchange, instead of one timeout later
     __hip_atomic_store(&peers.p[lane]->abort_by, int64_t(rank) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&peers.p[lane]->abort, q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-
   // ---- sum in rank order ----
   if (lane < kVec) {
     double acc;
     if (failed) {
-      // a peer never arrived (or reported that one did not): make the controller stop the solve (non-finite count > 0 -> XDE_STATUS_NONFINITE); the host
-      // finds the mailbox's error flag and reports the exchange, not the state
+      // a peer never arrived (or reported that one did not): make the controller stop the solve (non-finite count > 0 ->
+      // XDE_STATUS_NONFINITE); the host finds the mailbox's error flag and reports the exchange, not the state
       acc = lane < XDE_MAX_SEG ? 0.0 : 1.0;
     } else {
       const bool is_max = norm_kind == XDE_NORM_LINF && lane < XDE_MAX_SEG;
@@ -123,9 +122,39 @@ __global__ __launch_bounds__(64) void xde_p2p_exchange_kernel(double* sums, P2PM
         acc = is_max ? nanmax_(acc, v) : acc + v;
       }
     }
-    sums[lane] = acc;
+    vec[lane] = acc;
   }
   if (lane == 0 && failed && local->error == 0) local->error = q;
+  return failed;
+}
+
+__global__ __launch_bounds__(64) void xde_p2p_exchange_kernel(double* sums, P2PMailbox* local, Peers peers, int world,
+                                                              int rank, int norm_kind, int64_t spin_limit) {
+  p2p_exchange_wave(sums, local, peers, world, rank, norm_kind, spin_limit);
+}
+
+// finalize -> exchange -> controller of a batch-sharded attempt as ONE launch (round 4; they were three dependent one-workgroup
+// launches, ~15-30 us of serial work per attempt that does not shrink with the shard): the workgroup fetches the control block and
+// the error-norm launch's partial records in one memory round trip and reduces them in the fixed order (xde_norm_finalize's
+// arithmetic), its first wave runs the mailbox exchange on the per-segment sums where they lie in LDS, lane 0 runs control_step on
+// the global sums, one wave publishes the block (xde_rk_control's arithmetic and publish).  Same bits as the three launches.
+__global__ __launch_bounds__(kBlock) void xde_p2p_control_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const NormSlot* slot,
+                                                                 P2PMailbox* local, Peers peers, int world, int rank,
+                                                                 int64_t spin_limit, const double* t_span, const double* step_t,
+                                                                 void* t_stage_out, xde_ctrl_t* mirror, int flags, int partial_cap) {
+  __shared__ double vec[kVec];  // [value(seg 0..15), nonfinite(seg 0..15)] — the layout of xde_norm_finalize's output
+  __shared__ xde_ctrl_t zs;
+  __shared__ TimePrefetch pfs;
+  control_prologue(c, p, t_span, step_t, mirror, flags, &zs, &pfs);
+  if (threadIdx.x < kVec) vec[threadIdx.x] = 0.0;
+  __syncthreads();
+  if (flags & kCtrlSpecPartials)
+    reduce_partials_speculative(slot, vec, vec + XDE_MAX_SEG, partial_cap);
+  else
+    reduce_partials<false>(slot, vec, vec + XDE_MAX_SEG);
+  if (threadIdx.x < 64) p2p_exchange_wave(vec, local, peers, world, rank, p.norm_kind, spin_limit);
+  __syncthreads();
+  control_tail(c, p, vec, vec + XDE_MAX_SEG, t_span, step_t, t_stage_out, mirror, flags, &zs, &pfs);
 }
 
 }  // namespace
@@ -202,12 +231,53 @@ int xde_p2p_exchange(double* sums_dev, void* local_mailbox, void* const* peer_ma
   return XDE_OK;
 }
 
+int xde_p2p_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void* ws, void* local_mailbox,
+                       void* const* peer_mailboxes, int world, int rank, int64_t spin_limit, const double* t_span_dev,
+                       const double* step_t_dev, void* t_stage_out, xde_ctrl_t* host_mirror, void* stream) {
+  if (!ctrl || !ws || !t_span_dev || !t_stage_out || !local_mailbox || !peer_mailboxes)
+    return fail(XDE_EBADARG, "xde_p2p_rk_control: null pointer");
+  int rc = check_params(params, "xde_p2p_rk_control");
+  if (rc != XDE_OK) return rc;
+  if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_p2p_rk_control: n_step_t > 0 without step_t_dev");
+  if (world < 1 || world > XDE_P2P_MAX_RANKS) return fail(XDE_EBADARG, "xde_p2p_rk_control: world out of range");
+  if (rank < 0 || rank >= world) return fail(XDE_EBADARG, "xde_p2p_rk_control: rank out of range");
+  if (spin_limit <= 0) return fail(XDE_EBADARG, "xde_p2p_rk_control: spin_limit must be positive (the wait is bounded)");
+  Peers peers;
+  memset(&peers, 0, sizeof(peers));
+  for (int q = 0; q < world; ++q) {
+    if (!peer_mailboxes[q]) return fail(XDE_EBADARG, "xde_p2p_rk_control: null peer mailbox");
+    peers.p[q] = static_cast<P2PMailbox*>(peer_mailboxes[q]);
+  }
+  if (peer_mailboxes[rank] != local_mailbox) return fail(XDE_EBADARG, "xde_p2p_rk_control: peer_mailboxes[rank] must be the local mailbox");
+  static const int flags = [] {
+    const char* e = getenv("XDE_CTRL_FLAGS");
+    return (e && *e) ? atoi(e) : 7;
+  }();
+  int cap = (norm_grid_cap() > fused_grid_cap() ? norm_grid_cap() : fused_grid_cap()) + XDE_MAX_SEG;
+  if (cap > XDE_MAX_PARTIALS) cap = XDE_MAX_PARTIALS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_CONTROL, 0.0);
+  XDE_LAUNCH(xde_p2p_control_kernel, dim3(1), dim3(kBlock), st, prof, ctrl, *params, slot_ptr(ws, 0), static_cast<P2PMailbox*>(local_mailbox),
+             peers, world, rank, spin_limit, t_span_dev, step_t_dev, t_stage_out, host_mirror, flags, cap);
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
 int xde_p2p_error(const void* local_mailbox, int64_t* error_out, void* stream) {
   if (!local_mailbox || !error_out) return fail(XDE_EBADARG, "xde_p2p_error: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(error_out, &static_cast<const P2PMailbox*>(local_mailbox)->error, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return XDE_OK;
+}
+
+int xde_p2p_error_info(const void* local_mailbox, int64_t* info_out, int n_out, void* stream) {
+  if (!local_mailbox || !info_out) return fail(XDE_EBADARG, "xde_p2p_error_info: null pointer");
+  if (n_out != 3) return fail(XDE_EBADARG, "xde_p2p_error_info: n_out must be 3 ({error, abort, abort_by})");
+  hipStream_t st = static_cast<hipStream_t>(stream);
   // {error, abort, abort_by} are adjacent words of the mailbox
   static_assert(offsetof(P2PMailbox, abort_by) == offsetof(P2PMailbox, error) + 2 * sizeof(int64_t), "mailbox header layout");
-  HIP_TRY(hipMemcpyAsync(error_out, &static_cast<const P2PMailbox*>(local_mailbox)->error, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(info_out, &static_cast<const P2PMailbox*>(local_mailbox)->error, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return XDE_OK;
 }

@@ -53,3 +53,10 @@ def upload(arr, device):
 def scalar(value, dtype, device):
     """0-dim device tensor holding ``value``: a fill kernel with the value as argument (no host-to-device copy)."""
     return torch.full((), float(value), dtype=dtype, device=device)
+
+
+def direction_of(t_host):
+    """+1 / -1: the direction of integration of an output grid, decided by its first two entries exactly as the oracle's time flip
+    decides it (`t_span[1] < t_span[0]`): a grid that repeats its start time counts as forward, so `[0, 0, -1]` is a forward grid
+    with an output time behind the start — refused like every other out-of-order time."""
+    return -1 if (len(t_host) > 1 and t_host[1] < t_host[0]) else 1

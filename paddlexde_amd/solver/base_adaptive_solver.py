@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import _hip
-from ._common import as_operand, np_dtype, t_span_to_host
+from ._common import as_operand, direction_of, np_dtype, t_span_to_host
 
 
 class AdaptiveSolver(metaclass=abc.ABCMeta):
@@ -61,15 +61,19 @@ class AdaptiveSolver(metaclass=abc.ABCMeta):
         # them; a time that lies BEHIND the previous one is outside that step and fails `interp_evaluate`'s assertion
         # (utils/ode_utils.py:65-67).  The device controller would extrapolate the last step's quartic instead — so the same
         # condition is checked here, before anything is launched (same exception type and message shape).
-        d0 = -1 if t_host[1] < t_host[0] else 1
+        # Stricter than the reference in one corner, deliberately: an out-of-order time that still lies inside the step the
+        # reference happens to be in passes its assertion; which times those are depends on the step sequence, so here EVERY
+        # out-of-order time is refused.  (Raised explicitly: an `assert` statement would vanish under `python -O`.)
+        d0 = direction_of(t_host)
         for i in range(2, len(t_host)):
-            assert d0 * t_host[i] >= d0 * t_host[i - 1], "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(
-                t_host[i - 1], t_host[i], t_host[i - 1])
+            if not d0 * t_host[i] >= d0 * t_host[i - 1]:
+                raise AssertionError("invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(
+                    t_host[i - 1], t_host[i], t_host[i - 1]))
         try:
             self._before_integrate(t_host)
             # rows whose time equals the start time need no step (`while next_t > rk_state.t1` is false at once,
             # base_adaptive_solver_rk.py:119); the device controller starts its row counter after them
-            d = -1 if t_host[1] < t_host[0] else 1
+            d = direction_of(t_host)
             e = 1
             while e < len(t_host) and d * t_host[e] <= d * t_host[0]:
                 solution[e] = y0

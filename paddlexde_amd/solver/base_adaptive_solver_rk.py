@@ -35,7 +35,7 @@ import torch
 
 from .. import _hip
 from ..utils.ode_utils import native_norm_spec
-from ._common import as_operand, np_dtype, scalar, storage_ptr, t_span_to_host, upload
+from ._common import as_operand, direction_of, np_dtype, scalar, storage_ptr, t_span_to_host, upload
 from .base_adaptive_solver import AdaptiveSolver
 
 _ButcherTableau = collections.namedtuple("_ButcherTableau", "alpha, beta, c_sol, c_error")
@@ -140,6 +140,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         _replay=None,
         _step_hook=None,
         reuse_f0=False,
+        stats_out=None,
         _xde_segments=None,
         _xde_segment_shapes=None,
         **kwargs,
@@ -191,6 +192,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # result to the heuristic instead (NFE is still counted as the reference counts it; func is called once less).  Off by
         # default; odeint_adjoint switches it on for its backward intervals, where that evaluation is one of nine per interval.
         self._reuse_f0 = bool(reuse_f0)
+        # options["stats_out"] = {}: a dict of the caller's that receives the solve's counters (attempts, accepted, rejected, func
+        # evaluations, final time and step) when it ends — `odeint()` returns the solution only, as the reference's does
+        self._stats_out = stats_out
         if self._replay is not None and step_t is not None:
             raise NotImplementedError("a prescribed step sequence and step_t clipping do not combine")
         if _step_hook is not None:
@@ -392,7 +396,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._kept = None  # step() API: operands of the last accepted step
         self._auto_state = None  # what pipeline='auto' resolved to
         self._graph_warmup = None
-        self._direction = -1 if t_span[1] < t_span[0] else 1
+        self._direction = direction_of(t_span)
         self._t_host = t_span
         self._t_span_dev = upload(t_span.astype(np.float64), dev)
         self._work = w = be.acquire_work(dev, y0.dtype)  # recycled by integrate() when the solve has ended
@@ -446,6 +450,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
         f0 = self._eval(self._scalar_t(t_span[0], self.dtype), y0)
         first_dev = None
+        self._ctrl_ready = False
         if self.first_step is None:
             # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
             f0_again = f0 if self._reuse_f0 else None
@@ -458,13 +463,20 @@ class AdaptiveRKSolver(AdaptiveSolver):
         else:
             first_step = self.first_step
         self.rk_state = _RungeKuttaState(y0, f0, t_span[0], t_span[0], first_step, None)
-        be.ctrl_init(self._ctrl, p, float(t_span[0]), 0.0 if first_step is None else float(d * abs(first_step)), len(t_span),
-                     self._t_span_dev, self._step_t_dev, self._t_stage, first_step_dev=first_dev)
+        if not self._ctrl_ready:  # (the fused initial step has constructed the control block already)
+            be.ctrl_init(self._ctrl, p, float(t_span[0]), 0.0 if first_step is None else float(d * abs(first_step)), len(t_span),
+                         self._t_span_dev, self._step_t_dev, self._t_stage, first_step_dev=first_dev)
 
     def _after_integrate(self):
         w, self._work = getattr(self, "_work", None), None
         if w is not None and self.pipeline != "graph" and self._auto_state != "graph":  # a captured graph keeps addressing its buffers
             self.backend.release_work(w)
+
+    def _fused_first_step(self):
+        """One-workgroup initial step (xde_initial_step_fused): small state, native norm in one launch's worth of segments, one GPU,
+        no prescribed step sequence.  XDE_FUSED_FIRST_STEP=0 keeps the separate launches (same results; measured side by side)."""
+        return (self._small_state and self._chunks is None and self.process_group is None and not self._replay
+                and hasattr(self.backend, "initial_step_fused") and os.environ.get("XDE_FUSED_FIRST_STEP", "1") != "0")
 
     def _select_initial_step_device(self, t0, y0, f0=None):
         """``select_initial_step`` (base_adaptive_solver.py:33-72) with its scalar arithmetic on the device: the three
@@ -476,6 +488,20 @@ class AdaptiveRKSolver(AdaptiveSolver):
         t0h = np_dtype(self.dtype)(t0)
         if f0 is None:
             f0 = self._eval(self._scalar_t(t0h, self.dtype), y0)
+        t_probe = torch.empty((), dtype=torch.promote_types(self.dtype, y0.dtype), device=dev)
+        if self._fused_first_step():
+            # small state: the three norms, the scalar arithmetic and the control block's construction in TWO one-workgroup launches
+            # (+ the Euler probe's combine); _before_integrate skips its ctrl_init
+            hs = torch.zeros(5, dtype=torch.float64, device=dev)
+            be.initial_step_fused(0, f0, None, y0, self._xsegs, hs, self._params, float(t0h), t_probe, self._ctrl)
+            y1 = torch.empty_like(y0)
+            be.stage_combine(y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
+            f1 = self._eval(t_probe, y1)
+            be.initial_step_fused(1, f1, f0, y0, self._xsegs, hs, self._params, float(t0h), None, self._ctrl, len(self._t_host),
+                                  self._t_span_dev, self._step_t_dev, self._t_stage)
+            self._first_step_dbg = (hs[4:5], hs)
+            self._ctrl_ready = True
+            return hs[3:4]
         res = torch.empty(2, dtype=torch.float64, device=dev)
         hs = torch.zeros(4, dtype=torch.float64, device=dev)
 
@@ -484,7 +510,6 @@ class AdaptiveRKSolver(AdaptiveSolver):
 
         norm_into(y0, None, res[0:1])
         norm_into(f0, None, res[1:2])
-        t_probe = torch.empty((), dtype=torch.promote_types(self.dtype, y0.dtype), device=dev)
         be.initial_step(0, res, hs, self._params, float(t0h), t_probe, self._ctrl)  # h0 -> ctrl.dt, t0 + h0 -> t_probe
         y1 = torch.empty_like(y0)
         be.stage_combine(y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
@@ -568,6 +593,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
                                   self._norm_kind, self._ws, ctrl=ctrl, y0_alt=y0_alt, k0_alt=k0_alt)
         if self.process_group is None:
             be.rk_control(ctrl, self._params, self._ws, None, self._t_span_dev, self._step_t_dev, self._t_stage)
+        elif getattr(self.norm_exchange, "fused_control", False) and y0.is_cuda:
+            # peer-to-peer exchange: partial records -> per-segment sums -> mailboxes -> controller, ONE launch
+            be.p2p_rk_control(ctrl, self._params, self._ws, self.norm_exchange, self._t_span_dev, self._step_t_dev, self._t_stage)
         else:
             be.norm_finalize(self._ws, 0, self._sums)
             self._allreduce_sums(self._sums)
@@ -608,12 +636,14 @@ class AdaptiveRKSolver(AdaptiveSolver):
             "t": float(c.t1),
             "dt_next": float(c.dt),
         }
+        if self._stats_out is not None:
+            self._stats_out.update(self.stats)
         self.rk_state = _RungeKuttaState(base[0], base[1], c.t0, c.t1, c.dt, None)
 
     def _run(self, solution):
         self._solution = solution
         self._base = (self.rk_state.y1, self.rk_state.f1)
-        self._pending = None  # lag pipeline: (y1, ks, read handle) of the newest, unresolved attempt
+        self._pending = None  # lag pipeline: (y1, [f1], read handle) of the newest, unresolved attempt
         self._n_attempts = 0
         self._last = None
         self._graph = None
@@ -729,6 +759,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
                     self._dense(self._solution, base, y1, ks)
                 self._base = (y1, ks[-1])
             self._raise_status(c)
+            del y1, ks  # (dead now: released before the next attempt allocates, so that it reuses these very blocks)
             if c.done and stop_on_done:
                 break
         self._last = c
@@ -840,7 +871,12 @@ class AdaptiveRKSolver(AdaptiveSolver):
                     self.nfe -= self._n_stage
                     self._last = c
                     return c
-            self._pending = (y1, ks, handle)
+            # Only the proposal (y1, f1 = ks[-1]) of the unresolved attempt is kept: its other stage derivatives are dead once its
+            # dense-output launch is enqueued, and released HERE they are the blocks the next attempt's func writes into — the step
+            # cycles through ~12 state-sized buffers instead of ~18 (config 4's shard: 192 MiB instead of 288, i.e. inside the
+            # 256 MiB Infinity Cache instead of spilling out of it).
+            self._pending = (y1, ks[-1:], handle)
+            del ks
         if self._pending is not None:  # drain: the caller gets a fully resolved state
             c = self._resolve_pending()
         self._last = c
@@ -874,11 +910,13 @@ class AdaptiveRKSolver(AdaptiveSolver):
         if c.out_end > c.out_begin:
             # already covered by the retained step: interpolate there                              :127
             # (ode_utils.py:65-67: the interpolant is valid on [t0, t1] of that step only)
-            assert d * tt(c.t0) <= d * nt, "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(c.t0, nt, c.t1)
+            if not d * tt(c.t0) <= d * nt:
+                raise AssertionError("invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(c.t0, nt, c.t1))
             self._dense(row, *self._kept)
         else:
             if not d * nt > d * tt(c.t1):
-                assert c.n_accept == 0, "invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(c.t0, nt, c.t1)
+                if c.n_accept != 0:
+                    raise AssertionError("invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}".format(c.t0, nt, c.t1))
                 # nothing stepped yet and next_t is the start time: the reference evaluates its initial interpolant
                 # ([y0]*5, base_adaptive_solver_rk.py:91) on the empty interval; the value there is y0
                 row[0] = y0

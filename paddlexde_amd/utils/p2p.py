@@ -16,40 +16,87 @@ from .. import _hip
 
 class PeerExchange:
     capturable = True  # the exchange is one kernel launch whose counter lives in device memory: valid inside a replayed hipGraph
+    # the solver takes finalize -> exchange -> controller of a sharded attempt as ONE launch (xde_p2p_rk_control) when this is set;
+    # False keeps the three launches (xde_norm_finalize, xde_p2p_exchange, xde_rk_control) — same bits, measured side by side
+    fused_control = True
     SPIN_LIMIT = 20_000_000  # polls of ~60 ns before an exchange gives up (about a second): a peer died or fell out of step
 
     def __init__(self, group=None, device=None):
         import torch.distributed as dist
 
-        self.lib = _hip.load_library()
+        from .exchange import raise_together
+
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        if self.world > _hip.XDE_P2P_MAX_RANKS:
-            raise _hip.XdeError("PeerExchange serves one node: at most {} ranks".format(_hip.XDE_P2P_MAX_RANKS))
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = None
         self._local = None
         self._opened = []
-        with torch.cuda.device(self.device):
-            p = C.c_void_p()
-            self._check(self.lib.xde_p2p_alloc(C.byref(p)), "xde_p2p_alloc")
-            self._local = p.value
-            handle = (C.c_ubyte * _hip.XDE_P2P_HANDLE_BYTES)()
-            self._check(self.lib.xde_p2p_export(self._local, handle), "xde_p2p_export")
-            handles = [None] * self.world
-            dist.all_gather_object(handles, bytes(handle), group=group)
-            ptrs = []
-            for r, h in enumerate(handles):
-                if r == self.rank:
-                    ptrs.append(self._local)
-                    continue
-                q = C.c_void_p()
-                buf = (C.c_ubyte * _hip.XDE_P2P_HANDLE_BYTES).from_buffer_copy(h)
-                self._check(self.lib.xde_p2p_import(buf, C.byref(q)), "xde_p2p_import")
-                self._opened.append(q.value)
-                ptrs.append(q.value)
-            self._peers = (C.c_void_p * self.world)(*ptrs)
-        dist.barrier(group=group)  # every mailbox is mapped everywhere before the first store into it
+        # -- rank-local: library, mailbox, IPC handle.  Nothing collective has been entered when one of these fails, and the
+        #    ranks agree on the outcome before the handles travel (a failure is an exception on EVERY rank).
+        err, handle = None, None
+        try:
+            if self.world > _hip.XDE_P2P_MAX_RANKS:
+                raise _hip.XdeError("PeerExchange serves one node: at most {} ranks".format(_hip.XDE_P2P_MAX_RANKS))
+            self.lib = _hip.load_library()
+            self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            with torch.cuda.device(self.device):
+                p = C.c_void_p()
+                self._check(self.lib.xde_p2p_alloc(C.byref(p)), "xde_p2p_alloc")
+                self._local = p.value
+                handle = (C.c_ubyte * _hip.XDE_P2P_HANDLE_BYTES)()
+                self._check(self.lib.xde_p2p_export(self._local, handle), "xde_p2p_export")
+        except Exception as e:  # noqa: BLE001
+            err = e
+        try:
+            raise_together(err, "PeerExchange: mailbox set-up", group)
+        except Exception:
+            self._release_local()
+            raise
+        # -- collective: every rank's (device index, handle)
+        infos = [None] * self.world
+        dist.all_gather_object(infos, (self.device.index, bytes(handle)), group=group)
+        self.peer_devices = [d for d, _ in infos]
+        # -- rank-local: peer access, mapping the peers' mailboxes
+        err = None
+        try:
+            with torch.cuda.device(self.device):
+                ptrs = []
+                for r, (d, h) in enumerate(infos):
+                    if r == self.rank:
+                        ptrs.append(self._local)
+                        continue
+                    if d != self.device.index and not torch.cuda.can_device_access_peer(self.device.index, d):
+                        raise _hip.XdeError("device {} cannot access its peer device {} (rank {})".format(self.device.index, d, r))
+                    q = C.c_void_p()
+                    buf = (C.c_ubyte * _hip.XDE_P2P_HANDLE_BYTES).from_buffer_copy(h)
+                    self._check(self.lib.xde_p2p_import(buf, C.byref(q)), "xde_p2p_import")
+                    self._opened.append(q.value)
+                    ptrs.append(q.value)
+                self._peers = (C.c_void_p * self.world)(*ptrs)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        try:
+            raise_together(err, "PeerExchange: mapping the peers' mailboxes", group)  # (also the barrier: every mailbox is mapped
+        except Exception:                                                             #  everywhere before the first store into it)
+            self._release_local()
+            raise
+
+    def abandon(self):
+        """Rank-local release, no collective: for a group that is being torn down after a failure."""
+        self._release_local()
+
+    def _release_local(self):
+        """Give back what THIS rank holds (no collective): the imported mappings, then the own mailbox."""
+        try:
+            for q in self._opened:
+                self.lib.xde_p2p_close(q)
+            self._opened = []
+            if self._local is not None:
+                self.lib.xde_p2p_free(self._local)
+                self._local = None
+        except Exception:  # noqa: BLE001
+            pass
 
     def __del__(self):  # best effort for a forgotten close(): release what is ours, touch nothing a peer may still use
         try:
@@ -78,7 +125,8 @@ class PeerExchange:
         """``(exchange, reported_by)``: the number of the first failed exchange on this rank (0: none) and the rank whose wait ran
         out first when this rank was told by a peer (None: this rank's own wait ran out).  One blocking 24-byte read."""
         e = (C.c_int64 * 3)()
-        self._check(self.lib.xde_p2p_error(self._local, e, _hip.HipBackend._stream(torch.empty(0, device=self.device))), "xde_p2p_error")
+        self._check(self.lib.xde_p2p_error_info(self._local, e, 3, _hip.HipBackend._stream(torch.empty(0, device=self.device))),
+                    "xde_p2p_error_info")
         return int(e[0]), (int(e[2]) - 1 if e[1] != 0 and e[2] > 0 else None)
 
     def error(self):

@@ -74,29 +74,58 @@ class RcclExchange:
     def __init__(self, group=None, device=None):
         import torch.distributed as dist
 
-        self.lib = _load_rccl()
+        from .exchange import raise_together
+
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = None
         self._comm = None
-        uid = _UniqueId()
-        if self.rank == 0:
-            self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        # -- rank-local: the library, and on rank 0 the communicator id.  The ranks agree before the id travels: a rank that cannot
+        #    load librccl (or rank 0 failing to make an id) is an exception on EVERY rank, with nobody left waiting in a broadcast.
+        err, uid = None, _UniqueId()
+        try:
+            self.lib = _load_rccl()
+            self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            if self.rank == 0:
+                self._check(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        except Exception as e:  # noqa: BLE001
+            err = e
+        raise_together(err, "RcclExchange: library / communicator id", group)
+        # -- collective: the 128-byte id, once
         box = [C.string_at(C.addressof(uid), _NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None]
         src = 0 if group is None else dist.get_global_rank(group, 0)
         dist.broadcast_object_list(box, src=src, group=group)
+        err = None
         if not isinstance(box[0], bytes) or len(box[0]) != _NCCL_UNIQUE_ID_BYTES:
-            raise _hip.XdeError("RcclExchange: the communicator id did not arrive intact")
+            err = _hip.XdeError("the communicator id did not arrive intact")
+        raise_together(err, "RcclExchange: communicator id broadcast", group)
         C.memmove(C.addressof(uid), box[0], _NCCL_UNIQUE_ID_BYTES)
+        # -- collective inside RCCL: every rank enters ncclCommInitRank together.  A rank that DIES or hangs in here cannot be
+        #    rescued by its peers (they wait inside the library): that case is fatal by design and ends in the caller's watchdog.  An
+        #    error RETURNED by the call is agreed on like every other step.
         comm = C.c_void_p()
-        with torch.cuda.device(self.device):
-            self._check(self.lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
-        self._comm = comm
-        # first use outside any timed / captured region: RCCL sets its channels up lazily
-        warm = torch.zeros(2 * _hip.XDE_MAX_SEG, dtype=torch.float64, device=self.device)
-        self.exchange(warm, _hip.NORM_RMS)
-        torch.cuda.synchronize(self.device)
+        err = None
+        try:
+            with torch.cuda.device(self.device):
+                self._check(self.lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
+            self._comm = comm
+        except Exception as e:  # noqa: BLE001
+            err = e
+        try:
+            raise_together(err, "RcclExchange: ncclCommInitRank", group)
+            # first use outside any timed / captured region: RCCL sets its channels up lazily
+            err = None
+            try:
+                warm = torch.zeros(2 * _hip.XDE_MAX_SEG, dtype=torch.float64, device=self.device)
+                self.exchange(warm, _hip.NORM_RMS)
+                torch.cuda.synchronize(self.device)
+            except Exception as e:  # noqa: BLE001
+                err = e
+            raise_together(err, "RcclExchange: first all-reduce", group)
+        except Exception:
+            self.close()
+            raise
 
     def _check(self, rc, who):
         if rc != 0:
@@ -127,9 +156,13 @@ class RcclExchange:
     def close(self):
         if self._comm is None:
             return
-        torch.cuda.synchronize(self.device)
-        self.lib.ncclCommDestroy(self._comm)
-        self._comm = None
+        comm, self._comm = self._comm, None
+        try:
+            torch.cuda.synchronize(self.device)
+        finally:
+            self.lib.ncclCommDestroy(comm)
+
+    abandon = close
 
     def __del__(self):
         try:

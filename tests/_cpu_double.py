@@ -266,6 +266,30 @@ class NumpyDoubleBackend:
                 first = np.fmin(Y(100.0) * h0, h1)
                 h[3] = float(np.float32(first)) if params.time_dtype == _hip.XDE_F32 else float(first)
 
+    def initial_step_fused(self, phase, a, b, y0, segs, hs, params, t_start, t_probe, ctrl, n_out=0, t_span_dev=None, step_t_dev=None,
+                           t_stage=None):
+        """Contract of xde_initial_step_fused: the separate calls, composed."""
+        import torch
+
+        ws, sums = self.new_workspace(None), self.new_sums(None)
+        counts = [params.seg_count[i] for i in range(params.n_seg)]
+        res = torch.zeros(2, dtype=torch.float64)
+
+        def norm(x, y, out):
+            self.scaled_norm_partial(x, y, y0, params.rtol, params.atol, segs, params.norm_kind, ws, 0)
+            self.norm_finalize(ws, 0, sums)
+            self.norm_result(sums, counts, params.norm_kind, params.state_dtype, out)
+
+        if phase == 0:
+            norm(y0, None, res[0:1])
+            norm(a, None, res[1:2])
+            self.initial_step(0, res, hs, params, t_start, t_probe, ctrl)
+        else:
+            norm(a, b, res[0:1])
+            self.initial_step(1, res, hs, params, t_start, None, ctrl)
+            hs[4] = res[0]
+            self.ctrl_init(ctrl, params, t_start, 0.0, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=hs[3:4])
+
     def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None):
         c = self._c(ctrl)
         C.memset(C.addressof(c), 0, C.sizeof(c))

@@ -289,3 +289,57 @@ def test_initial_step_vs_oracle_select_initial_step(dev, dtype, direction):
     be.initial_step(1, r2, h2, p, float(t0), None, ctrl2)
     ulp = 1.2e-7 if dtype == np.float32 else 2.3e-16
     assert h2.cpu().numpy()[3] == pytest.approx(float(first_ref), rel=2 * ulp), (h2.cpu().numpy(), first_ref)
+
+
+@pytest.mark.parametrize("direction", [1, -1])
+@pytest.mark.parametrize("norm_name", ["rms", "linf"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_initial_step_equals_the_separate_launches_and_the_oracle(dev, dtype, norm_name, direction, monkeypatch):
+    """Small states take select_initial_step (solver/base_adaptive_solver.py:33-72) as TWO one-workgroup launches + the Euler probe
+    (xde_initial_step_fused) instead of twelve launches.  Held to (a) the separate launches on the same inputs — d0, d1, h0, the
+    first step and the constructed control block (same stage times, same output bookkeeping) — and (b) the oracle's own
+    select_initial_step.  4099 x 2 elements: the scalar tail runs too."""
+    from paddlexde_amd import Dopri5 as Solver
+    from paddlexde_amd.utils import _linf_norm, _rms_norm
+    from paddlexde_amd.xde import BaseODE
+
+    be = _hip.get_backend()
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.RandomState(5)
+    y0 = rng.uniform(-2, 2, size=(4099, 2)).astype(dtype)
+    f_np, f_t = P.vdp_np(dtype(3.0)), P.vdp_torch(3.0)
+    rtol, atol = 1e-5, 1e-7
+    y0d = torch.from_numpy(y0).to(dev)
+    t_span = np.asarray([direction * 0.25, direction * 1.0, direction * 5.0])
+    tsp = t_span.astype(np.float32 if dtype == np.float32 else np.float64)
+
+    def run(fused):
+        monkeypatch.setenv("XDE_FUSED_FIRST_STEP", "1" if fused else "0")
+        s = Solver(xde=BaseODE(f_t, y0=y0d, t_span=torch.from_numpy(t_span)), y0=y0d, rtol=rtol, atol=atol,
+                   norm=_rms_norm if norm_name == "rms" else _linf_norm, dtype=tdt, step_t=torch.tensor([direction * 0.2500001, direction * 2.0]))
+        s.y0 = y0d
+        s._before_integrate(tsp)
+        assert s._fused_first_step() == fused and s._ctrl_ready == fused
+        res, hs = s._first_step_dbg
+        return s, float(res.cpu().numpy()[0]), hs.cpu().numpy()[:4].copy(), be.ctrl_read(s._ctrl), s._t_stage.cpu().numpy().copy()
+
+    sf, n3f, hf, cf, tf = run(True)
+    su, n3u, hu, cu, tu = run(False)
+    assert sf.nfe == su.nfe == 3  # f0, f0 again (as the reference counts it), f1
+    tight = 1e-6 if dtype == np.float32 else 1e-13  # one workgroup sums in another order than 512 (fp64 sums of state-dtype squares)
+    assert hf[0] == pytest.approx(hu[0], rel=tight) and hf[1] == pytest.approx(hu[1], rel=tight) and hf[2] == pytest.approx(hu[2], rel=tight)
+    assert n3f == pytest.approx(n3u, rel=1e-3 if dtype == np.float32 else 1e-9)  # (f1 - f0 at h0 ~ 1e-5: a cancellation)
+    assert hf[3] == pytest.approx(hu[3], rel=1e-4 if dtype == np.float32 else 1e-10)
+    for name in ("t0", "t1"):
+        assert getattr(cf, name) == getattr(cu, name)
+    for name in ("dt", "t_plan"):
+        assert getattr(cf, name) == pytest.approx(getattr(cu, name), rel=1e-4 if dtype == np.float32 else 1e-10)
+    for name in ("n_out", "next_out", "out_begin", "out_end", "done", "next_step_index", "on_step_t", "n_steps", "accept", "status"):
+        assert getattr(cf, name) == getattr(cu, name), name
+    assert cf.next_out == 1 and cf.dt * direction > 0, (cf.next_out, cf.dt, cf.on_step_t, cf.next_step_index)
+    assert np.allclose(tf[:6], tu[:6], rtol=1e-4 if dtype == np.float32 else 1e-10)
+    # (b) the oracle
+    f_or = f_np if direction > 0 else (lambda t, y: -f_np(-t, y))
+    so = O.AdaptiveRKSolver(f_or, y0, rtol, atol, method="dopri5", norm=O._rms_norm if norm_name == "rms" else O._linf_norm, dtype=dtype)
+    first_ref = so.select_initial_step(so.tt(0.25), y0, so.order - 1, so.rtol, so.atol)
+    assert hf[3] == pytest.approx(float(first_ref), rel=1e-4 if dtype == np.float32 else 1e-9)

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _hip.load_library()
     for sym in _declared():
         assert hasattr(lib, sym), sym
-    assert lib.xde_abi_version() == _hip.ABI_VERSION == 4
+    assert lib.xde_abi_version() == _hip.ABI_VERSION == 5
 
 
 def test_struct_layouts_match():
@@ -109,6 +109,8 @@ def test_every_entry_point_rejects_null_arguments():
         "xde_ctrl_init": lambda: lib.xde_ctrl_init(None, C.byref(P), 0.0, 0.1, 2, None, None, None, 0, None, None),
         "xde_ctrl_retarget": lambda: lib.xde_ctrl_retarget(None, C.byref(P), None, 1, None, None),
         "xde_initial_step": lambda: lib.xde_initial_step(0, None, None, C.byref(P), 0.0, None, 0, None, None),
+        "xde_initial_step_fused": lambda: lib.xde_initial_step_fused(0, None, None, None, C.byref(S), 0, None, C.byref(P), 0.0, None, 0, None, 2, None,
+                                                                    None, None, 0, None),
         "xde_ctrl_read": lambda: lib.xde_ctrl_read(None, None, None),
         "xde_host_alloc": lambda: lib.xde_host_alloc(0, None),
         "xde_ctrl_wait": lambda: lib.xde_ctrl_wait(None, 0, 1.0, None),
@@ -124,6 +126,8 @@ def test_every_entry_point_rejects_null_arguments():
         "xde_p2p_import": lambda: lib.xde_p2p_import(None, None),
         "xde_p2p_exchange": lambda: lib.xde_p2p_exchange(None, None, None, 2, 0, 0, 1000, None),
         "xde_p2p_error": lambda: lib.xde_p2p_error(None, None, None),
+        "xde_p2p_error_info": lambda: lib.xde_p2p_error_info(None, None, 3, None),
+        "xde_p2p_rk_control": lambda: lib.xde_p2p_rk_control(None, C.byref(P), None, None, None, 2, 0, 1000, None, None, None, None, None),
         "xde_prof_collect": lambda: lib.xde_prof_collect(None, None, None),
     }
     for name, call in calls.items():

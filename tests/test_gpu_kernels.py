@@ -584,6 +584,19 @@ def test_pack_segments_equals_the_framework_op_pack(dtype):
     odd[1] = members[1].to(torch.float64 if dtype == torch.float32 else torch.float32)
     assert not be.pack_segments(got, odd, segs)
     assert be.pack_segments(got, members[:1], segs[:1]) is True
+    # a member whose element count is not its segment's (a func that returned a wrong-shaped member) never reaches the kernel, which
+    # would read `length` elements from it: short -> out-of-bounds read, long -> silent truncation.  The framework-op pack raises.
+    short = list(members)
+    short[1] = members[1][:100].contiguous()
+    assert not be.pack_segments(got, short, segs)
+    with pytest.raises(RuntimeError), torch.no_grad():
+        _pack(short, segs, total, adt, dev)
+    long_ = list(members)
+    long_[4] = torch.randn(3, 50, generator=g, dtype=dtype).to(dev)
+    assert not be.pack_segments(got, long_, segs)
+    with pytest.raises(RuntimeError), torch.no_grad():
+        _pack(long_, segs, total, adt, dev)
+    assert not be.pack_segments(got, members[:2], segs[:3])  # member and segment lists of different lengths
     # bad layouts are refused before any launch
     lib = be.lib
     import ctypes as C

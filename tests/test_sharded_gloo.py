@@ -552,3 +552,52 @@ def test_rccl_backend_world_size_one_adjoint(tmp_path, norm):
     assert P.rel_err(r["sol"], sol.detach().cpu().numpy()) <= 1e-9
     for key, ref in (("gy", y0.grad), ("gW1", m.W1.grad), ("gW2", m.W2.grad), ("gt", t.grad)):
         assert P.rel_err(r[key], ref.cpu().numpy()) <= 1e-8, key
+
+
+# ----------------------------------------------------------------------------------------------
+# choosing the transport of the norm sums: group-safe set-up (utils/exchange.py)
+# ----------------------------------------------------------------------------------------------
+def _negotiate_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+
+        from paddlexde_amd import _hip
+        from paddlexde_amd.utils import exchange as X
+
+        rec = {}
+        # (1) a step that fails on ONE rank only is an exception on every rank, raised at the same point — nobody is left
+        #     waiting in the collective that would have followed
+        try:
+            X.raise_together(RuntimeError("no such library") if rank == 1 else None, "set-up", None)
+            rec["one_rank_fails"] = "no error"
+        except _hip.XdeError as e:
+            rec["one_rank_fails"] = str(e)
+        X.raise_together(None, "set-up", None)  # all fine: returns
+        rec["agree"] = [X.agree(True), X.agree(rank == 0)]
+        # (2) on a box without a GPU neither the mailboxes nor an RCCL communicator can be built: every rank falls back, together,
+        #     to the group's own all-reduce, and says why
+        ex, kind, report = X.negotiate(None, None, prefer=("p2p", "rccl", "allreduce"))
+        rec["kind"], rec["exchange_is_none"], rec["report"] = kind, ex is None, report
+        with open(os.path.join(out_dir, "neg{}.json".format(rank)), "w") as fh:
+            json.dump(rec, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_negotiation_is_group_safe_without_a_gpu(tmp_path):
+    """a rank failing before a constructor's collective must not leave its peers waiting in it."""
+    import json
+
+    if torch.cuda.is_available():
+        pytest.skip("the CPU statement of the fall-back; the GPU suite negotiates for real")
+    mp.spawn(_negotiate_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [json.load(open(tmp_path / "neg{}.json".format(r))) for r in range(2)]
+    assert "failed on another rank" in r0["one_rank_fails"] and "no such library" in r1["one_rank_fails"]
+    assert r0["agree"] == r1["agree"] == [True, False]
+    for r in (r0, r1):
+        assert r["kind"] == "allreduce" and r["exchange_is_none"]
+        assert [x["transport"] for x in r["report"]] == ["p2p", "rccl", "allreduce"]
+        assert [x["adopted"] for x in r["report"]] == [False, False, True] and all(x.get("why") for x in r["report"][:2])
