@@ -6,7 +6,9 @@
 N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts the N ranks itself (a child
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`), relays rank 0's
 line and exits non-zero if a rank fails, if the box has fewer than N GPUs (unless XDE_BENCH_REHEARSAL=1: all ranks on cuda:0 over
-gloo) or if the line does not say n_gpus == N.  Under a launcher (the driver's torch.distributed.run) it is one rank of the job.
+gloo), if the line does not say n_gpus == N, or — exit code 124, with the stage every rank was in — if the job outlives
+XDE_BENCH_TIMEOUT seconds.  Under a launcher (the driver's torch.distributed.run) it is one rank of the job.  Either way every rank
+runs each stage (rendezvous, transport probe, communicator, negotiation, timed region, extras, teardown) under a watchdog.
 
 A "step" is ONE attempted Dopri5 step over the whole batch: 6 stage combines (xde_stage_combine), 6 calls
 of the user's func (a framework call: torch matmul ``y @ A^T``), one fused error-norm launch and the device
@@ -16,9 +18,12 @@ Workload (N=1): BASELINE.json configs[1] — linear ODE dy/dt = A y, A = U - U^T
 128 fp32, y0 = randn (seed 0), rtol 1e-5 / atol 1e-7, inputs resident in HBM before the timed region.
 N>1: BASELINE.json configs[3] — the same ODE at GLOBAL batch 524288 x dim 64, rows split evenly over the N ranks
 (rank r owns rows [r*B/N, (r+1)*B/N): 65536 x 64 per GPU at N=8); the total work is the same for every N > 1
-("scaling": "strong"); the only collective is the all-reduce of the error norm's partial sums (32 doubles) per
-attempted step over RCCL (`rccl_ranks` = size of that nccl group).  Because the driver's `--gpus 1` line is config 2 — a different
-amount of work — the N > 1 line carries `n1_same_workload`: rank 0's own single-GPU run of the SAME global 524288 x 64 problem,
+("scaling": "strong"); the only exchange on the data path is that of the error norm's partial sums (32 doubles) per attempted
+step — by `--exchange auto`: one-shot stores into IPC-mapped peer mailboxes over xGMI fused with the controller launch if that
+transport's probe (child processes) succeeds, else ncclAllReduce on the solver's stream, else the nccl group's all_reduce; the
+line says which (`norm_exchange`, `norm_exchange_report`), times the others too (`exchange_ab`), and lists each rank's device and
+the peer-access matrix (`rccl_ranks` = size of the nccl group the job formed and checked).  Because the driver's `--gpus 1` line is
+config 2 — a different amount of work — the N > 1 line carries `n1_same_workload`: rank 0's own single-GPU run of the SAME global 524288 x 64 problem,
 taken after the timed region, so a strong-scaling efficiency can be computed from one line.  `--batch` (rows PER GPU) / `--dim` override either default (then "weak").
 `--workload rk4`: the bandwidth-bound fixed-step line (reference RK4 variant, 65536 x 128, 18 N 4 B per step).
 
@@ -455,12 +460,47 @@ def dde_workload(args):
     be.prof_enable(False)
     by = 5.0 * S * L * D * 4.0
     a = by * rec["launches"] / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] > 0 else 0.0
-    emit({"metric": "history-spline gathers per second (xde_hermite_gather, value + derivative)", "value": args.steps / el, "unit": "gathers/s",
-          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-          "config": {"workload": "D3STN-sized history: {} series x {} times x {} channels, {} lags".format(S, T, D, L)},
-          "roofline": {"bound": "hbm", "kernel": "xde_hermite_vec_kernel<float>", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": a / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e3 * rec["ms"] / max(rec["launches"], 1),
-                       "bytes_per_launch": by, "history_bytes": float(S) * T * D * 4.0}})
+    out = {"metric": "history-spline gathers per second (xde_hermite_gather, value + derivative)", "value": args.steps / el, "unit": "gathers/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "D3STN-sized history: {} series x {} times x {} channels, {} lags".format(S, T, D, L)},
+           "roofline": {"bound": "hbm", "kernel": "xde_hermite_vec_kernel<float>", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": a / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e3 * rec["ms"] / max(rec["launches"], 1),
+                        "bytes_per_launch": by, "history_bytes": float(S) * T * D * 4.0}}
+    # the other two history splines (interp_method "linear" / "bez": 2 / 4 rows in, value + derivative out) and HistoryIndex.backward
+    # (xde_lag_grad: grad_y and derivative in, L numbers out — one launch instead of a framework multiply + sum)
+    extra = {}
+    for method, rows in (("linear", 2), ("bez", 4)):
+        for _ in range(args.warmup):
+            be.history_gather(val, der, his, his_t, lags, method)
+        be.prof_enable(1)
+        for _ in range(args.steps):
+            be.history_gather(val, der, his, his_t, lags, method)
+        r2 = be.prof_collect()["dense"]
+        be.prof_enable(False)
+        b2 = float(rows + 2) * S * L * D * 4.0
+        a2 = b2 * r2["launches"] / (r2["ms"] * 1e-3) / 1e9 if r2["ms"] > 0 else 0.0
+        extra["gather_" + method] = {"avg_launch_us": 1e3 * r2["ms"] / max(r2["launches"], 1), "bytes_per_launch": b2, "achieved": a2,
+                                     "frac": a2 / HBM_PEAK_GBS}
+    gy = torch.randn(S, L, D, generator=g).to(dev)
+    for _ in range(args.warmup):
+        be.lag_grad(gy, der)
+    be.prof_enable(1)
+    for _ in range(args.steps):
+        be.lag_grad(gy, der)
+    r3 = be.prof_collect()["dense"]
+    be.prof_enable(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        (gy * der).sum(dim=(0, 2))
+    torch.cuda.synchronize()
+    fw = (time.perf_counter() - t0) / args.steps
+    b3 = 2.0 * S * L * D * 4.0
+    a3 = b3 * r3["launches"] / (r3["ms"] * 1e-3) / 1e9 if r3["ms"] > 0 else 0.0
+    extra["lag_grad"] = {"kernel": "xde_lag_grad_kernel<float, vec>", "avg_launch_us": 1e3 * r3["ms"] / max(r3["launches"], 1), "bytes_per_launch": b3,
+                         "achieved": a3, "frac": a3 / HBM_PEAK_GBS, "framework_multiply_plus_sum_us": 1e6 * fw}
+    out["history_index"] = extra
+    emit(out)
 
 
 def time_unsharded(B, D, dtype, pipeline, device, steps, warmup):
@@ -968,6 +1008,8 @@ def main():
     def timed_run(kind, ex, steps, warmup, events):
         """Build a solver on transport `kind`, let it settle, warm up, and time EXACTLY `steps` attempted steps between barriers:
         every rank's own clock stops after its stream has drained, the job's time is the MAX over the ranks."""
+        if os.environ.get("XDE_BENCH_TEST_HANG") == str(rank):  # test hook: this rank never joins the set-up's first collective
+            time.sleep(10 ** 6)
         solver = Solver(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=args.pipeline, process_group=group_for(kind),
                         norm_exchange=ex)
         solver.y0 = y0

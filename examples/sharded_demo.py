@@ -18,7 +18,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from paddlexde_amd import Dopri5, odeint  # noqa: E402
-from paddlexde_amd.utils import RcclExchange, _rms_norm  # noqa: E402
+from paddlexde_amd.utils import _rms_norm, negotiate_exchange  # noqa: E402
 
 
 def main():
@@ -40,9 +40,11 @@ def main():
     t = torch.linspace(0.0, 1.0, 5)
 
     options = {"norm": _rms_norm, "process_group": True}
-    exchange = None
-    if not rehearsal:
-        exchange = options["norm_exchange"] = RcclExchange()  # the all-reduce as ncclAllReduce on the solver's own stream
+    # how the 32 doubles travel: the fastest transport the whole group can set up and self-test — one-shot stores into IPC-mapped
+    # mailboxes over xGMI (fused with the controller launch), else ncclAllReduce on the solver's own stream, else the group's all_reduce
+    exchange, kind, _ = negotiate_exchange(None, dev, prefer=("p2p", "allreduce") if rehearsal else ("p2p", "rccl", "allreduce"))
+    if exchange is not None:
+        options["norm_exchange"] = exchange
     sol = odeint(lambda t_, y: y @ A.T, y0, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options=options)  # [T, B / world, D]
 
     # check: the rotation conserves every row's norm, and all ranks took the same steps (their last rows' norms gathered)
@@ -50,8 +52,8 @@ def main():
     worst = torch.tensor([drift], device="cpu" if rehearsal else dev)
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print("ranks {}  global batch {} x {}  rows per rank {}  worst relative norm drift over all ranks {:.2e}".format(
-            world, B, D, B // world, float(worst)))
+        print("ranks {}  global batch {} x {}  rows per rank {}  norm exchange '{}'  worst relative norm drift over all ranks {:.2e}".format(
+            world, B, D, B // world, kind, float(worst)))
     if exchange is not None:
         exchange.close()
     dist.destroy_process_group()

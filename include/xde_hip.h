@@ -375,6 +375,29 @@ int xde_hermite_gather(void* val_out, void* der_out, const void* his, const void
                        int64_t outer, int T, int D, int L, int dtype, void* stream);
 
 /*
+ * The same gather for every history spline HistoryIndex.forward offers (xde/base_dde.py:104-121; ABI 5): method XDE_HISTORY_CUBIC is
+ * xde_hermite_gather; XDE_HISTORY_LINEAR — LinearInterpolation (interpolation/interpolate.py:6-99): rows i, i+1 with weights
+ * [1-s, s] for the value and [-1, 1] for the derivative; XDE_HISTORY_BEZIER — BezierSpline (:207-298): rows i..i+3 (clamped at T-1)
+ * with the Bernstein weights of s = (t - t_i) / (t_{i+3} - t_i).  Conventions as written in the reference's `_make_series`: every row is
+ * divided by its own `scale{k+1}` (scale1 shifted right by k, first value repeated), the value is multiplied by scale1_i, the
+ * derivative is not.  Linear needs T >= 2, Bezier T >= 4; at most 128 lags per launch.
+ */
+#define XDE_HISTORY_CUBIC 0
+#define XDE_HISTORY_LINEAR 1
+#define XDE_HISTORY_BEZIER 2
+int xde_history_gather(void* val_out, void* der_out, const void* his, const void* his_t, const void* lags, int64_t outer, int T, int D,
+                       int L, int dtype, int method, void* stream);
+
+/*
+ * HistoryIndex.backward (xde/base_dde.py:123-127): grad_lags_out[l] = sum over o, d of grad_y[o, l, d] * der[o, l, d] (`grad_y *
+ * derivative_lags` summed over every axis but the lag axis; the history itself receives no gradient) — one launch, products formed
+ * in `dtype`, accumulated in fp64 in a fixed order (bit-reproducible), result rounded to `dtype`.
+ *   ws: xde_lag_grad_workspace_bytes(L) bytes of device memory, zero before the FIRST use (every launch leaves it re-armed).
+ */
+int64_t xde_lag_grad_workspace_bytes(int L);
+int xde_lag_grad(void* grad_lags_out, const void* grad_y, const void* der, int64_t outer, int D, int L, int dtype, void* ws, void* stream);
+
+/*
  * Predicated commit for the hipGraph pipeline (operand addresses are baked into a captured graph, so the
  * host cannot swap pointers): if ctrl->accept then y0_dst <- y1_src and f0_dst <- f1_src — the state update
  * `(t, y, f) <- (t1, y1, f1)` of AdaptiveRKSolver._adaptive_step (solver/base_adaptive_solver_rk.py:258-277).

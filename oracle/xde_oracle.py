@@ -898,10 +898,93 @@ class CubicHermiteSpline:
         return ((ts @ self._h) @ ps).squeeze(-2)
 
 
-def history_index(lags, his, his_span, dtype=np.float32):
+class _RowsSpline:
+    """What LinearInterpolation and BezierSpline share (interpolation/interpolate_base.py:7-107): `index = clip(bucketize(t) - 1, 0,
+    T - 1)`, `norm_t = (t - t[index]) / scale1[index]`, `evaluate = (ts @ H @ ps) * scale1[index]`, `derivative = ts' @ H @ ps`."""
+
+    M = 0
+    _H = None
+
+    def __init__(self, series, t=None, dtype=np.float32):
+        series = np.asarray(series).astype(dtype)
+        if t is None:
+            t = np.linspace(0, series.shape[-2], series.shape[-2] + 1)
+        t = np.asarray(t).astype(dtype)
+        self._t, self._series, self.dtype = t, series, dtype
+        self._series_arr, self._scale_t = self._make_series(series, t)
+        self._h = np.asarray(self._H).astype(dtype)
+
+    def _interpolate(self, t, der):
+        t = np.atleast_1d(np.asarray(t).astype(self.dtype))
+        maxlen = self._series.shape[-2] - 1
+        index = np.clip(np.searchsorted(self._t, t, side="left") - 1, 0, maxlen)
+        norm_t = (t - self._t[index]) / self._scale_t[index]
+        ts = self._ts(norm_t, der)[:, None, :]
+        ps = np.stack([np.take(self._series_arr[..., k, :], index, axis=-2) for k in range(self.M)], axis=-2)  # [..., L, M, D]
+        return ts.astype(self.dtype), ps.astype(self.dtype), index
+
+    def evaluate(self, t):
+        ts, ps, index = self._interpolate(t, der=False)
+        return ((ts @ self._h) @ ps).squeeze(-2) * self._scale_t[index][:, None]
+
+    def derivative(self, t):
+        ts, ps, index = self._interpolate(t, der=True)
+        return ((ts @ self._h) @ ps).squeeze(-2)
+
+
+class LinearInterpolation(_RowsSpline):
+    """interpolation/interpolate.py:6-99, as written: `ps = [p_i / scale1_i, p_{i+1} / scale2_i]`, H = [[-1, 1], [1, 0]],
+    `ts = [s, 1]`, `ts' = [1, 0]`."""
+
+    M = 2
+    _H = [[-1.0, 1.0], [1.0, 0.0]]  # sparse_coo(indices [[0,0,1],[0,1,0]], values [-1, 1, 1])  :36-41
+
+    def _make_series(self, series, t):  # :45-66
+        scale = t[1:] - t[:-1]
+        scale1 = np.concatenate([scale, scale[-1:]])
+        scale2 = np.concatenate([scale[:1], scale1[:-1]])
+        series2 = np.concatenate([series[..., 1:, :], series[..., -1:, :]], axis=-2)
+        return np.stack([series / scale1[:, None], series2 / scale2[:, None]], axis=-2), scale1
+
+    def _ts(self, s, der):  # :71-78
+        one, zero = np.ones_like(s), np.zeros_like(s)
+        return np.stack([s, one] if not der else [one, zero], axis=-1)
+
+
+class BezierSpline(_RowsSpline):
+    """interpolation/interpolate.py:207-298, as written: four rows i..i+3 (the last row repeated), each divided by its own scale{k}
+    (`scale = t[3:] - t[:-3]`, :249-253), H = the cubic Bernstein matrix (:237-243), `ts = [s^3, s^2, s, 1]`."""
+
+    M = 4
+    _H = [[-1.0, 3.0, -3.0, 1.0], [3.0, -6.0, 3.0, 0.0], [-3.0, 3.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]]
+
+    def _make_series(self, series, t):  # :245-274
+        scale = t[3:] - t[:-3]
+        scale1 = np.concatenate([scale, scale[-1:], scale[-1:], scale[-1:]])
+        scale2 = np.concatenate([scale[:1], scale1[:-1]])
+        scale3 = np.concatenate([scale[:1], scale2[:-1]])
+        scale4 = np.concatenate([scale[:1], scale3[:-1]])
+        s1 = series
+        s2 = np.concatenate([s1[..., 1:, :], series[..., -1:, :]], axis=-2)
+        s3 = np.concatenate([s2[..., 1:, :], series[..., -1:, :]], axis=-2)
+        s4 = np.concatenate([s3[..., 1:, :], series[..., -1:, :]], axis=-2)
+        arr = np.stack([s1 / scale1[:, None], s2 / scale2[:, None], s3 / scale3[:, None], s4 / scale4[:, None]], axis=-2)
+        return arr, scale1
+
+    def _ts(self, s, der):  # :279-286
+        one, zero = np.ones_like(s), np.zeros_like(s)
+        return np.stack([s**3, s**2, s, one] if not der else [3 * s**2, 2 * s, one, zero], axis=-1)
+
+
+HISTORY_SPLINES = {"cubic": CubicHermiteSpline, "linear": LinearInterpolation, "bez": BezierSpline}
+
+
+def history_index(lags, his, his_span, dtype=np.float32, interp_method="cubic"):
     """HistoryIndex.forward / backward (xde/base_dde.py:82-127): returns (y_lags, grad_fn) with
     ``grad_fn(grad_y) = sum over every axis but the lag axis of grad_y * derivative``."""
-    interp = CubicHermiteSpline(his, his_span, dtype=dtype)
+    if interp_method not in HISTORY_SPLINES:
+        raise NotImplementedError  # :110-111
+    interp = HISTORY_SPLINES[interp_method](his, his_span, dtype=dtype)
     y_lags = interp.evaluate(lags)
     der = interp.derivative(lags)
 

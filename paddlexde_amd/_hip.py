@@ -21,6 +21,7 @@ XDE_MAX_PACK = 64
 XDE_P2P_MAX_RANKS, XDE_P2P_HANDLE_BYTES = 16, 64
 COMBINE_RK, COMBINE_FUSE, COMBINE_WFUSE = 0, 1, 2
 NORM_RMS, NORM_LINF = 0, 1
+HISTORY_METHODS = {"cubic": 0, "linear": 1, "bez": 2}
 STATUS_OK, STATUS_DT_UNDERFLOW, STATUS_NONFINITE, STATUS_MAX_STEPS = 0, 1, 2, 3
 KID_NAMES = ("combine", "errnorm", "control", "dense", "scalednorm", "finalize", "commit", "combine_fuse", "combine_wfuse")
 
@@ -55,6 +56,9 @@ SYMBOLS = (
     "xde_pack_segments",
     "xde_dense_commit",
     "xde_hermite_gather",
+    "xde_history_gather",
+    "xde_lag_grad_workspace_bytes",
+    "xde_lag_grad",
     "xde_scale_fanout",
     "xde_graph_replace_memsets",
     "xde_p2p_mailbox_bytes",
@@ -237,6 +241,12 @@ def load_library():
         lib.xde_scale_fanout.argtypes = [vpp, vp, dp, i32, vp, i64, i32, vp]
         lib.xde_hermite_gather.restype = i32
         lib.xde_hermite_gather.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        lib.xde_history_gather.restype = i32
+        lib.xde_history_gather.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]
+        lib.xde_lag_grad_workspace_bytes.restype = i64
+        lib.xde_lag_grad_workspace_bytes.argtypes = [i32]
+        lib.xde_lag_grad.restype = i32
+        lib.xde_lag_grad.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         lib.xde_dense_commit.restype = i32
         lib.xde_dense_commit.argtypes = [vp, vpp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]
         lib.xde_commit.restype = i32
@@ -326,6 +336,7 @@ class HipBackend:
         self._mirror_pool = []  # pinned host mirror rings, reused across solver instances
         self._mirrors = {}  # device ctrl pointer -> _Mirror
         self._work_pool = {}  # (device, state dtype, stream) -> free _Work sets
+        self._lag_ws = {}  # (device, L) -> workspace of xde_lag_grad (zeroed once; every launch leaves it re-armed)
         self._tls = threading.local()  # .capturing: this THREAD is recording a hipGraph (its launches do not execute)
 
     # -- host mirror ring of the control block (see xde_rk_control / xde_ctrl_wait) -------------
@@ -597,6 +608,33 @@ class HipBackend:
         rc = self.lib.xde_hermite_gather(val.data_ptr(), der.data_ptr(), his.data_ptr(), his_t.data_ptr(), lags.data_ptr(), outer,
                                          T, D, lags.numel(), dtype_code(his.dtype), self._stream(his))
         self._check(rc, "xde_hermite_gather")
+
+    def history_gather(self, val, der, his, his_t, lags, method):
+        """his [..., T, D] (contiguous), his_t [T], lags [L]  ->  val, der [..., L, D] of the history spline `method`
+        ("cubic" | "linear" | "bez")."""
+        self._require_device(val, der, his, his_t, lags)
+        T, D = his.shape[-2], his.shape[-1]
+        outer = his.numel() // (T * D) if T * D else 0
+        rc = self.lib.xde_history_gather(val.data_ptr(), der.data_ptr(), his.data_ptr(), his_t.data_ptr(), lags.data_ptr(), outer, T, D,
+                                         lags.numel(), dtype_code(his.dtype), HISTORY_METHODS[method], self._stream(his))
+        self._check(rc, "xde_history_gather")
+
+    def lag_grad(self, grad_y, der):
+        """sum over every axis but the lag axis of grad_y * der ([..., L, D] both, contiguous) -> [L], one launch."""
+        self._require_device(grad_y, der)
+        L, D = der.shape[-2], der.shape[-1]
+        outer = der.numel() // (L * D) if L * D else 0
+        if L == 0 or outer == 0:
+            return torch.zeros(L, dtype=der.dtype, device=der.device)
+        out = torch.empty(L, dtype=der.dtype, device=der.device)
+        key = (der.device.index, L)
+        ws = self._lag_ws.get(key)
+        if ws is None:
+            ws = self._lag_ws[key] = torch.zeros(int(self.lib.xde_lag_grad_workspace_bytes(L)), dtype=torch.uint8, device=der.device)
+        rc = self.lib.xde_lag_grad(out.data_ptr(), grad_y.data_ptr(), der.data_ptr(), outer, D, L, dtype_code(der.dtype), ws.data_ptr(),
+                                   self._stream(der))
+        self._check(rc, "xde_lag_grad")
+        return out
 
     def pack_segments(self, flat, tensors, segs, scales=None):
         """``flat`` (16-byte-aligned segments, pads zero) <- the contiguous device tensors ``tensors`` at ``segs`` = [(start, len)], one

@@ -24,7 +24,24 @@ def odeint(
     atol=1e-9,
     options: object = {"norm": _rms_norm},
 ):
-    """Integrate ``dy/dt = func(t, y), y(t[0]) = y0`` and return y at every ``t_span`` point."""
+    """Integrate ``dy/dt = func(t, y), y(t[0]) = y0`` and return y at every ``t_span`` point.
+
+    ``y0`` / ``t_span`` may be tensors of another framework (anything with ``__dlpack__``): see utils/interop.py;
+    ``options["from_dlpack"]`` = that framework's importer makes ``func`` receive, and the call return, its own tensors."""
+    from ..utils import interop
+
+    importer = None
+    if isinstance(options, dict) and "from_dlpack" in options:
+        options = dict(options)
+        importer = options.pop("from_dlpack")
+    if importer is not None or interop.is_foreign(y0) or interop.is_foreign(t_span):
+        y0 = tuple(interop.to_torch(v) for v in y0) if isinstance(y0, (tuple, list)) else interop.to_torch(y0)
+        t_span = interop.to_torch(t_span) if interop.is_foreign(t_span) else t_span
+        if importer is not None:
+            inner = interop.adapt_func(func, importer)
+            with torch.no_grad():  # a foreign framework's func records no torch graph: forward only (use the C ABI binding to train)
+                sol = odeint(inner, y0, t_span, solver, rtol=rtol, atol=atol, options=options)
+            return tuple(importer(v) for v in sol) if isinstance(sol, tuple) else importer(sol)
     if not torch.is_tensor(t_span):
         t_span = torch.as_tensor(t_span)
     if _wants_autograd(func, y0, t_span, solver):

@@ -19,6 +19,7 @@ Deviations documented in SURVEY.md: D4 (tuple state flattened), D5 (reverse-time
 gradient w.r.t. ``y0`` is returned instead of ``None``)."""
 import threading
 import warnings
+import collections
 import weakref
 from typing import Any, NamedTuple, Optional
 
@@ -152,9 +153,13 @@ def _vjp_of(evaluate, t, y, wrt_params, cotangent, time_grad, retain):
 
 
 # (shape, dtype, device) -> a zero tensor that is only ever READ: the stand-in for a gradient autograd did not produce (the time
-# adjoint of an autonomous func, on every evaluation).  Entries are NEVER evicted: a captured HIP graph keeps the raw address of the
-# one it was recorded with.  One entry per distinct shape of t / of a parameter — a handful per model.
-_ZEROS = {}
+# adjoint of an autonomous func, on every evaluation).  A bounded, least-recently-used cache (a handful of shapes per model; a
+# process that walks through many models or batch shapes does not keep every zero it ever needed).  A captured HIP graph bakes in
+# the raw ADDRESS of the zero it was recorded with: while a capture records, every zero handed out is also appended to that
+# capture's own keep-alive list (_ZERO_SINKS), so an entry evicted from this cache lives exactly as long as a graph that reads it.
+_ZEROS = collections.OrderedDict()
+_ZEROS_MAX = 32
+_ZERO_SINKS = []  # stack of keep-alive lists of the dynamics currently being evaluated for capture
 
 
 def _zeros_like(x):
@@ -162,6 +167,12 @@ def _zeros_like(x):
     z = _ZEROS.get(key)
     if z is None:
         z = _ZEROS[key] = torch.zeros(key[0], dtype=x.dtype, device=x.device)
+        while len(_ZEROS) > _ZEROS_MAX:
+            _ZEROS.popitem(last=False)
+    else:
+        _ZEROS.move_to_end(key)
+    if _ZERO_SINKS and not any(z is k for k in _ZERO_SINKS[-1]):
+        _ZERO_SINKS[-1].append(z)
     return z
 
 
@@ -307,13 +318,20 @@ def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoin
         (s1, n1), (s2, n2) = segs[1], segs[2]
         yshape, dev = tuple(y0.shape), y0.device
 
+        keep = []  # the shared zeros this dynamics reads (their addresses end up inside the captured graph): alive as long as it is
+
         def flat_dynamics(t, yf):
             # unpack views -> func + vjp -> pack, all inside ONE captured graph
             v = yf[0] if fixed else yf
-            k = _pack(dyn(t, (None, v[s1 : s1 + n1].view(yshape), v[s2 : s2 + n2].view(yshape))), segs, total, adt, dev)
+            _ZERO_SINKS.append(keep)
+            try:
+                k = _pack(dyn(t, (None, v[s1 : s1 + n1].view(yshape), v[s2 : s2 + n2].view(yshape))), segs, total, adt, dev)
+            finally:
+                _ZERO_SINKS.pop()
             return k[None, :] if fixed else k
 
         graphed = GraphedFunc(flat_dynamics, clone_outputs=True)
+        graphed._keepalive = keep
         while len(cache) >= MAX_GRAPHS_PER_MODULE:  # a loop over many batch shapes must not pile up captures (oldest first)
             cache.pop(next(iter(cache)))
         cache[key] = graphed

@@ -141,6 +141,11 @@ class AdaptiveRKSolver(AdaptiveSolver):
         _step_hook=None,
         reuse_f0=False,
         stats_out=None,
+        callback_step=None,
+        callback_accept_step=None,
+        callback_reject_step=None,
+        callback_accept=None,
+        callback_reject=None,
         _xde_segments=None,
         _xde_segment_shapes=None,
         **kwargs,
@@ -189,14 +194,35 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._step_hook = _step_hook
         # The reference evaluates func(t0, y0) twice before the first attempt: once for the state (`_before_integrate`, :83) and
         # once more inside `select_initial_step` (f0=None, :84-87).  Same arguments, same value.  reuse_f0=True hands the first
-        # result to the heuristic instead (NFE is still counted as the reference counts it; func is called once less).  Off by
-        # default; odeint_adjoint switches it on for its backward intervals, where that evaluation is one of nine per interval.
+        # result to the heuristic instead: func is called once less.  `nfe` / stats["nfe"] stay the number of calls func really
+        # received (a func that counts its calls, or regularises on them, sees exactly that number); stats["nfe_reference"] is what
+        # the reference would report for the same solve (+1 here).  Off by default; odeint_adjoint switches it on for its
+        # backward intervals, where that evaluation is one of nine per interval.
         self._reuse_f0 = bool(reuse_f0)
         # options["stats_out"] = {}: a dict of the caller's that receives the solve's counters (attempts, accepted, rejected, func
         # evaluations, final time and step) when it ends — `odeint()` returns the solution only, as the reference's does
         self._stats_out = stats_out
         if self._replay is not None and step_t is not None:
             raise NotImplementedError("a prescribed step sequence and step_t clipping do not combine")
+        # Step callbacks.  The reference names them and leaves the calls commented out (`self.func.callback_step(t0, y0, dt)` at the top
+        # of every attempt, `callback_accept_step` / `callback_reject_step` on its verdict, base_adaptive_solver_rk.py:186,259,275).
+        # Here they are live: options["callback_step" | "callback_accept_step" | "callback_reject_step"] (short forms
+        # "callback_accept" / "callback_reject"), or methods of those names on the user's func, are called as `cb(t0, y0, dt)` —
+        # t0 and dt 0-dim HOST tensors of the time dtype, y0 the state the attempt starts from (a device tensor).  They need the
+        # host to know every attempt's verdict before the next one is enqueued, i.e. the "sync" pipeline: "auto" resolves to it,
+        # an explicit "lag" / "graph" refuses.
+        func = getattr(xde, "func", None)
+        pick = lambda opt, *names: opt if opt is not None else next(  # noqa: E731
+            (getattr(func, n) for n in names if callable(getattr(func, n, None))), None)
+        self._cb_step = pick(callback_step, "callback_step")
+        self._cb_accept = pick(callback_accept_step if callback_accept_step is not None else callback_accept, "callback_accept_step")
+        self._cb_reject = pick(callback_reject_step if callback_reject_step is not None else callback_reject, "callback_reject_step")
+        self._has_callbacks = any(cb is not None for cb in (self._cb_step, self._cb_accept, self._cb_reject))
+        if self._has_callbacks:
+            if pipeline not in ("auto", "sync"):
+                raise NotImplementedError("step callbacks are called by the host between attempts: pipeline='{}' enqueues attempts "
+                                          "ahead of their verdicts (use 'sync', or the default 'auto')".format(pipeline))
+            self.pipeline = pipeline = "sync"
         if _step_hook is not None:
             if pipeline not in ("auto", "sync"):
                 raise NotImplementedError("_step_hook observes attempts of pipeline='sync'")
@@ -214,7 +240,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._device_first_step = os.environ.get("XDE_HOST_FIRST_STEP", "0") != "1"
 
         self.backend = _hip.get_backend()
-        self.nfe = 0
+        self.nfe = 0  # calls func has received
+        self._nfe_skipped = 0  # calls the reference would have made on top (reuse_f0)
         self.stats = {}
 
         # -- operand plans (a function of the tableau only: built once per solver class) ---------------
@@ -455,7 +482,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
             # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
             f0_again = f0 if self._reuse_f0 else None
             if f0_again is not None:
-                self.nfe += 1  # (counted as the reference counts it)
+                self._nfe_skipped += 1  # (the call the reference makes here and this solve does not)
             if self._custom_norm or not self._device_first_step:
                 first_step = self.select_initial_step(t_span[0], y0, self.order - 1, self.rtol, self.atol, f0=f0_again)
             else:
@@ -633,6 +660,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
             "n_accept": int(c.n_accept),
             "n_reject": int(c.n_reject),
             "nfe": int(self.nfe),
+            "nfe_reference": int(self.nfe + self._nfe_skipped),
             "t": float(c.t1),
             "dt_next": float(c.dt),
         }
@@ -738,6 +766,22 @@ class AdaptiveRKSolver(AdaptiveSolver):
         self._finish(c, self._base)
         return c
 
+    def _callbacks_before(self, c, base):
+        """`callback_step(t0, y0, dt)` at the top of an attempt (base_adaptive_solver_rk.py:186); returns the arguments for the verdict's
+        callback.  `c`: the newest control block (None before the first attempt: the first step size was chosen on the device)."""
+        if c is None:
+            c = self.backend.ctrl_read(self._ctrl)
+        args = (torch.tensor(c.t1, dtype=self.dtype), base[0], torch.tensor(c.dt, dtype=self.dtype))
+        if self._cb_step is not None:
+            self._cb_step(*args)
+        return args
+
+    def _callbacks_after(self, c, args):
+        """`callback_accept_step` / `callback_reject_step` on the attempt's verdict (:259, :275)."""
+        cb = self._cb_accept if c.accept else self._cb_reject
+        if cb is not None:
+            cb(*args)
+
     def _advance_sync(self, max_attempts, stop_on_done=None):
         be = self.backend
         c = self._last
@@ -746,6 +790,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
             stop_on_done = max_attempts is None
         while max_attempts is None or done < max_attempts:
             base = self._base
+            cb_args = self._callbacks_before(c, base) if self._has_callbacks else None
             y1, ks = self._attempt(base)
             self._n_attempts += 1
             done += 1
@@ -754,6 +799,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
                 self.trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
             if self._step_hook is not None:
                 self._step_hook(self._n_attempts - 1, base[0], y1, ks, c)
+            if cb_args is not None:
+                self._callbacks_after(c, cb_args)
             if c.accept:
                 if c.out_end > c.out_begin and self._solution is not None:
                     self._dense(self._solution, base, y1, ks)
@@ -923,11 +970,14 @@ class AdaptiveRKSolver(AdaptiveSolver):
                 return row[0]
             while True:
                 base = self._base
+                cb_args = self._callbacks_before(c, base) if self._has_callbacks else None
                 y1, ks = self._attempt(base)
                 self._n_attempts += 1
                 c = be.ctrl_read(self._ctrl)
                 if self.record_trace:
                     self.trace.append((c.t0, c.dt_last, c.ratio, bool(c.accept)))
+                if cb_args is not None:
+                    self._callbacks_after(c, cb_args)
                 if c.accept:
                     self._kept = (base, y1, ks)
                     self._base = (y1, ks[-1])

@@ -19,6 +19,7 @@ import torch
 from .. import _hip
 from ..xde.base_dde import DDE_DAMPING, BaseDDE
 from ..xde.base_ode import BaseODE
+from ..xde.base_xde import BaseXDE
 from ._autograd import CombineFn
 from ._common import as_operand, np_dtype, storage_ptr, t_span_to_host, upload
 
@@ -65,6 +66,15 @@ class FixedSolver(metaclass=abc.ABCMeta):
         self.move = self.xde.move
         self.fuse = self.xde.fuse
         self.on_integrate_step_end = self.xde.on_integrate_step_end
+        # The reference binds this hook (base_fixed_solver.py:64) and never calls it; here it IS called, once per step of the eager
+        # loop, as `xde.on_integrate_step_end(y0, y1, t0, t1)` (state before / after the step, device tensors; t0 / t1 the shape-[1]
+        # device views the step itself received).  The base classes' hook does nothing, so only a wrapper that overrides it sees a
+        # difference — and such a wrapper keeps the solve on the eager loop: a captured step cannot call back into Python, so
+        # pipeline="graph" refuses it and "auto" does not capture.
+        self._step_end_hook = getattr(type(xde), "on_integrate_step_end", None) is not BaseXDE.on_integrate_step_end
+        if self._step_end_hook and pipeline == "graph":
+            raise NotImplementedError("pipeline='graph' replays a captured step and cannot call xde.on_integrate_step_end; "
+                                      "use pipeline='sync' (or the default 'auto', which then keeps the eager loop)")
         # the wrapper's fuse is what xde_stage_combine computes: BaseODE's `dy*dt + y0` or BaseDDE's damped form
         fuse_impl = getattr(type(xde), "fuse", None)
         if fuse_impl is BaseODE.fuse:
@@ -178,7 +188,7 @@ class FixedSolver(metaclass=abc.ABCMeta):
         # pipeline="graph": one captured step replayed over the grid (no autograd, data-independent step).  "auto" (default)
         # takes it for inference-style calls (grad mode off) on small states with enough steps to pay for the capture, behind
         # the capture guard, and falls back to the eager loop below if the capture is refused or fails.
-        can_graph = (self.graphable and not tracking and not torch.is_grad_enabled() and table is not None and y0.is_cuda
+        can_graph = (self.graphable and not self._step_end_hook and not tracking and not torch.is_grad_enabled() and table is not None and y0.is_cuda
                      and self.interp != "cubic" and pred_len - 1 >= self.GRAPH_MIN_STEPS
                      and threading.current_thread() is threading.main_thread() and not torch.cuda.is_current_stream_capturing())
         if self.pipeline == "graph" and can_graph:
@@ -212,6 +222,8 @@ class FixedSolver(metaclass=abc.ABCMeta):
                 # "linear": linear_interp returns y1 when t == t1 (interp_fn.py:7-8); any other value: raw y1
                 if y1.data_ptr() != dst.data_ptr():  # (differentiable copy when y1 carries an autograd graph)
                     dst.copy_(y1)
+                if self._step_end_hook:
+                    self.on_integrate_step_end(y0, y1, t0, t1)
                 y0 = y1
         finally:
             self._dt = None

@@ -1,11 +1,11 @@
 """Delay-equation problem wrapper (reference: paddlexde/xde/base_dde.py:14-127).
 
 ``BaseDDE`` evaluates the history at the learned lags ONCE, at construction (``HistoryIndex``: cubic-Hermite spline of
-``his`` sampled at ``his_span``), and then behaves like an ODE wrapper whose ``move`` calls ``func(y_lags, y0)`` and
+``his`` sampled at ``his_span`` by default; ``interp_method="linear"`` / ``"bez"`` as in the reference, :104-109), and then behaves like an ODE wrapper whose ``move`` calls ``func(y_lags, y0)`` and
 whose ``fuse`` is damped: ``y = dy*dt + y0; (dy - 0.001*y)*dt + y0`` (base_dde.py:47-58).  The fixed-step solvers map
-that ``fuse`` onto xde_stage_combine with ``damping=0.001``; the history gather is xde_hermite_gather (value and time
+that ``fuse`` onto xde_stage_combine with ``damping=0.001``; the history gather is xde_history_gather (value and time
 derivative in one pass), with the reference's backward: d loss / d lags = sum over every axis but the lag axis of
-``grad_y * derivative`` (base_dde.py:123-127); the history itself receives no gradient.
+``grad_y * derivative`` (base_dde.py:123-127) as ONE reduction launch (xde_lag_grad); the history itself receives no gradient.
 """
 import torch
 
@@ -18,9 +18,8 @@ DDE_DAMPING = 0.001  # `_lambda` of BaseDDE.fuse
 class HistoryIndex(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lags, his, his_span, interp_method="cubic"):
-        if interp_method != "cubic":
-            # ddeint never passes another method (base_dde.py:34); linear / Bezier history splines are out of scope
-            raise NotImplementedError("HistoryIndex: only the cubic-Hermite history spline (the reference default) is built")
+        if interp_method not in _hip.HISTORY_METHODS:
+            raise NotImplementedError  # (as the reference, base_dde.py:110-111)
         be = _hip.get_backend()
         be.require_device(his)
         dtype = his.dtype if his.dtype in (torch.float32, torch.float64) else torch.float32
@@ -30,7 +29,15 @@ class HistoryIndex(torch.autograd.Function):
         out_shape = tuple(his_c.shape[:-2]) + (lags_c.numel(), his_c.shape[-1])
         y_lags = torch.empty(out_shape, dtype=dtype, device=his.device)
         derivative_lags = torch.empty_like(y_lags)
-        be.hermite_gather(y_lags, derivative_lags, his_c, t_c, lags_c)
+        if interp_method == "cubic" or not hasattr(be, "history_gather"):
+            if interp_method != "cubic":
+                raise NotImplementedError("this backend serves the cubic history spline only")
+            be.hermite_gather(y_lags, derivative_lags, his_c, t_c, lags_c)
+        else:
+            need = 2 if interp_method == "linear" else 4
+            if his_c.shape[-2] < need:
+                raise ValueError("HistoryIndex(interp_method={!r}) needs at least {} history times".format(interp_method, need))
+            be.history_gather(y_lags, derivative_lags, his_c, t_c, lags_c, interp_method)
         ctx.save_for_backward(derivative_lags)
         ctx.lags_shape = tuple(lags.shape)
         ctx.lags_dtype = lags.dtype
@@ -39,9 +46,15 @@ class HistoryIndex(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_y):
         (derivative_lags,) = ctx.saved_tensors
-        grad = grad_y * derivative_lags
-        dims = [d for d in range(grad.dim()) if d != grad.dim() - 2]  # every axis but the lag axis (reference: [0, 1, 3])
-        grad = grad.sum(dim=dims).reshape(ctx.lags_shape).to(ctx.lags_dtype)
+        be = _hip.get_backend()
+        if (hasattr(be, "lag_grad") and grad_y.dtype == derivative_lags.dtype and grad_y.shape == derivative_lags.shape
+                and (derivative_lags.shape[-1] <= 256 or derivative_lags.shape[-1] % (4 if grad_y.dtype == torch.float32 else 2) == 0)):
+            grad = be.lag_grad(grad_y.contiguous(), derivative_lags)  # one launch: sum over every axis but the lag axis
+        else:
+            grad = grad_y * derivative_lags
+            dims = [d for d in range(grad.dim()) if d != grad.dim() - 2]  # every axis but the lag axis (reference: [0, 1, 3])
+            grad = grad.sum(dim=dims)
+        grad = grad.reshape(ctx.lags_shape).to(ctx.lags_dtype)
         return grad, None, None, None
 
 

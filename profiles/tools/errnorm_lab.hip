@@ -110,6 +110,28 @@ __global__ __launch_bounds__(256) void k_bare(const float* __restrict__ ep, cons
 __global__ void k_fill(float* p, size_t n, float v) {
   for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) p[i] = v + float(i % 97) * 1e-3f;
 }
+// in-situ conditions: the pass's operands have just been WRITTEN (y1 and e_pre by the last stage's combine, k by func's GEMM), and the chip
+// has been busy with matrix work (clocks under a power cap are not the clocks of a cold burst)
+__global__ __launch_bounds__(256) void k_write3(float* __restrict__ a, float* __restrict__ b, float* __restrict__ c, size_t nvec, float v) {
+  for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < nvec; i += size_t(gridDim.x) * 256) {
+    v4f x = {v, v * 0.5f, v * 0.25f, v * 2.f};
+    reinterpret_cast<v4f*>(a)[i] = x;
+    reinterpret_cast<v4f*>(b)[i] = x * 1e-6f;
+    reinterpret_cast<v4f*>(c)[i] = x * 1e-4f;
+  }
+}
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_heat(float* out, int iters) {  // MFMA-bound, touches no memory until the end
+  v16f acc = {0};
+  v8s a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
+  for (int i = 0; i < iters; ++i) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc, 0, 0, 0);
+  }
+  if (acc[0] == 123.456f) out[threadIdx.x] = acc[1];
+}
+
 // stands for the controller launch that precedes the pass in a real step: rewrites the control block (so its lines are not warm in this CU's caches)
 __global__ void k_touch(Ctrl* c) { c->dt = 0.01; c->accept = 1; }
 
@@ -147,6 +169,22 @@ int main(int argc, char** argv) {
   RUN((k_plain<false, false, true, false, 1>), grid, ep, k, y0a, y0b, y1, c, 0.01f, nvec, out); // nothing but loads + cheap math
   RUN((k_pipe<true>), grid, ep, k, y0a, y0b, y1, c, 0.01f, nvec, out);
   RUN((k_pipe<false>), grid, ep, k, y0a, y0b, y1, c, 0.01f, nvec, out);
+  // the same kernels under in-situ conditions (argv[3] = 1): operands freshly written, ~10 us of MFMA work in front, 600 rounds
+  if (argc > 3 && atoi(argv[3]) == 1) {
+    float* hb; CK(hipMalloc(&hb, 4096));
+#define RUN2(kern, ...)                                                                            \
+  for (int r = 0; r < 600; ++r) {                                                                  \
+    hipLaunchKernelGGL(k_write3, dim3(2048), dim3(256), 0, 0, y1, ep, k, nvec, 1.0f + r * 1e-3f);   \
+    hipLaunchKernelGGL(k_heat, dim3(1024), dim3(256), 0, 0, hb, 400);                               \
+    hipLaunchKernelGGL(k_touch, dim3(1), dim3(1), 0, 0, c);                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, __VA_ARGS__);                            \
+  }                                                                                                \
+  CK(hipDeviceSynchronize());
+    RUN2((k_plain<true, true, false, true, 1>), ep, k, y0a, y0b, y1, c, 0.01f, nvec, out);
+    RUN2((k_pipe<true>), ep, k, y0a, y0b, y1, c, 0.01f, nvec, out);
+    RUN2(k_bare, ep, k, y0a, y1, nvec, out);
+    RUN2((k_plain<true, true, true, true, 2>), ep, k, y0a, y0b, y1, c, 0.01f, nvec, out);
+  }
   printf("done %zu MiB grid %d\n", mib, grid);
   return 0;
 }

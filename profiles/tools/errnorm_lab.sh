@@ -5,11 +5,11 @@ cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/lab
 hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o gpurun_out/lab/errnorm_lab profiles/tools/errnorm_lab.hip
 export TMPDIR=/tmp
-for mib in 16 32; do
-  for grid in 512 1024 2048; do
+for mib in ${LAB_MIB:-16 32}; do
+  for grid in ${LAB_GRIDS:-512 1024 2048}; do
     d=gpurun_out/lab/m${mib}_g${grid}
     rm -rf $d
-    rocprofv3 --kernel-trace --stats --output-format csv -d $d -- gpurun_out/lab/errnorm_lab $mib $grid > $d.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $d -- gpurun_out/lab/errnorm_lab $mib $grid ${LAB_INSITU:-0} > $d.log 2>&1
     f=$(find $d -name '*kernel_stats.csv' | head -1)
     echo "## ${mib} MiB per stream, grid ${grid}"
     python3 - "$f" <<'PY'
@@ -19,6 +19,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     if n.startswith("k_") or "k_plain" in n or "k_pipe" in n or "k_bare" in n:
         if "k_fill" in n or "k_touch" in n: continue
         print("%-60s calls %4s avg %8.2f us  min %8.2f" % (n[:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+    elif "k_heat" in n or "k_write3" in n:
+        print("%-60s calls %4s avg %8.2f us" % (n[:60], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
   done
 done

@@ -512,6 +512,51 @@ class NumpyDoubleBackend:
             v[:, l, :] = (((c0 * p0 + c1 * p1) + c2 * d0) + c3 * d1) * h1
             dv[:, l, :] = ((g0 * p0 + g1 * p1) + g2 * d0) + g3 * d1
 
+    def history_gather(self, val, der, his, his_t, lags, method):
+        """Contract of xde_history_gather: "cubic" = hermite_gather; "linear" / "bez" = weighted rows, the kernel's op order."""
+        if method == "cubic":
+            return self.hermite_gather(val, der, his, his_t, lags)
+        self.launches.append("history_" + method)
+        T = _NP[his.dtype]
+        h, ts = _np(his), _np(his_t)
+        Tn, D = h.shape[-2], h.shape[-1]
+        hh = h.reshape(-1, Tn, D)
+        v, dv = _np(val).reshape(hh.shape[0], -1, D), _np(der).reshape(hh.shape[0], -1, D)
+        M, span = (2, 1) if method == "linear" else (4, 3)
+
+        def scale1(j):
+            jj = j if j < Tn - span else Tn - span - 1
+            return ts[jj + span] - ts[jj]
+
+        for l, tau in enumerate(_np(lags).reshape(-1)):
+            i = min(max(int(np.searchsorted(ts, tau, side="left")) - 1, 0), Tn - 1)
+            h1 = scale1(i)
+            s = T((tau - ts[i]) / h1)
+            if M == 2:
+                w, g = [-s + T(1), s], [T(-1), T(1)]
+            else:
+                s2 = s * s
+                s3 = s2 * s
+                a, b = T(3) * s2, T(2) * s
+                w = [((-s3 + T(3) * s2) - T(3) * s) + T(1), (T(3) * s3 - T(6) * s2) + T(3) * s, T(-3) * s3 + T(3) * s2, s3]
+                g = [(-a + T(3) * b) - T(3), (T(3) * a - T(6) * b) + T(3), T(-3) * a + T(3) * b, a]
+            av = ad = None
+            for k in range(M):
+                p = hh[:, min(i + k, Tn - 1), :] / scale1(max(i - k, 0))
+                av = w[k] * p if av is None else av + w[k] * p
+                ad = g[k] * p if ad is None else ad + g[k] * p
+            v[:, l, :] = av * h1
+            dv[:, l, :] = ad
+
+    def lag_grad(self, grad_y, der):
+        """Contract of xde_lag_grad: products in the state dtype, summed in fp64 over every axis but the lag axis."""
+        import torch
+
+        self.launches.append("lag_grad")
+        g = (_np(grad_y) * _np(der)).astype(np.float64)
+        axes = tuple(a for a in range(g.ndim) if a != g.ndim - 2)
+        return torch.from_numpy(g.sum(axis=axes).astype(_NP[der.dtype]))
+
     def dense_commit(self, out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype):
         self.dense_eval(out_base, ks, mid, y0, y1, f1, ctrl, t_span_dev, time_dtype)
         self.commit(ctrl, y0, y1, ks[0], f1)

@@ -31,26 +31,50 @@ def _history(shape, T, uniform, seed=0, dtype=np.float32):
 @pytest.mark.parametrize("uniform", [True, False])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("D", [7, 8])  # 7: scalar kernel; 8: the 16-byte-vector kernel with the per-lag table in LDS
-def test_history_gather_vs_oracle(dev, lead, uniform, dtype, D):
-    """xde_hermite_gather against the oracle's restatement of CubicHermiteSpline.evaluate / .derivative."""
+@pytest.mark.parametrize("method", ["cubic", "linear", "bez"])
+def test_history_gather_vs_oracle(dev, lead, uniform, dtype, D, method):
+    """HistoryIndex (xde/base_dde.py:82-127) for its three `interp_method`s against the oracle's restatements of
+    CubicHermiteSpline / LinearInterpolation / BezierSpline `.evaluate` and `.derivative` (interpolation/interpolate.py), and its
+    backward — one reduction launch — against `sum(grad_y * derivative)` over every axis but the lag axis."""
     T = 24
     his, t = _history(lead + (D,), T, uniform, dtype=dtype)
-    lags = np.array([t[0] - 0.4, t[0], 0.5 * (t[0] + t[1]), t[5], t[5] + 1e-3, t[11] + 0.77 * (t[12] - t[11]), t[-2], t[-1], t[-1] + 0.9],
-                    dtype=dtype)
-    y_ref, _ = O.history_index(lags, his, t, dtype=dtype)
-    d_ref = O.CubicHermiteSpline(his, t, dtype=dtype).derivative(lags)
+    lags = np.array([t[0] - 0.4, t[0], 0.5 * (t[0] + t[1]), t[5], t[5] + 1e-3, t[11] + 0.77 * (t[12] - t[11]), t[-4] + 0.1, t[-3], t[-2], t[-1],
+                     t[-1] + 0.9], dtype=dtype)
+    y_ref, _ = O.history_index(lags, his, t, dtype=dtype, interp_method=method)
+    d_ref = O.HISTORY_SPLINES[method](his, t, dtype=dtype).derivative(lags)
     lg = torch.from_numpy(lags).to(dev).requires_grad_(True)
-    y = HistoryIndex.apply(lg, torch.from_numpy(his).to(dev), torch.from_numpy(t).to(dev))
+    y = HistoryIndex.apply(lg, torch.from_numpy(his).to(dev), torch.from_numpy(t).to(dev), method)
     assert y.shape == lead + (len(lags), D)
     tol = 2e-5 if dtype == np.float32 else 1e-12
     assert P.rel_err(y.detach().cpu().numpy(), y_ref) <= tol
-    # nodes are interpolated (up to the spline's own rounding) and the gradient w.r.t. the lags is the derivative
+    # the gradient w.r.t. the lags is the derivative, reduced over every axis but the lag axis
     w = torch.randn(y.shape, generator=torch.Generator().manual_seed(1), dtype=y.dtype).to(dev)
     (y * w).sum().backward()
     axes = tuple(a for a in range(w.dim()) if a != w.dim() - 2)
-    g_ref = (w.cpu().numpy() * d_ref).sum(axis=axes)
-    assert lg.grad.shape == lg.shape
+    g_ref = (w.cpu().numpy().astype(np.float64) * d_ref.astype(np.float64)).sum(axis=axes)
+    assert lg.grad.shape == lg.shape and lg.grad.dtype == lg.dtype
     assert P.rel_err(lg.grad.cpu().numpy(), g_ref) <= (5e-5 if dtype == np.float32 else 1e-11)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lag_gradient_reduction_at_odd_sizes(dev, dtype):
+    """xde_lag_grad alone: [outer, L, D] products reduced to [L] in one launch, for row lengths that are / are not a multiple of
+    the vector width, a single row, many rows, an empty batch."""
+    from paddlexde_amd import _hip
+
+    be = _hip.get_backend()
+    if not hasattr(be, "lag_grad"):
+        pytest.skip("backend without lag_grad")
+    rng = np.random.RandomState(3)
+    for outer, L, D in [(1, 1, 1), (5, 3, 7), (64, 12, 64), (1000, 5, 16), (17, 128, 4), (3, 2, 250), (0, 4, 8)]:
+        gy, de = rng.randn(outer, L, D).astype(dtype), rng.randn(outer, L, D).astype(dtype)
+        got = be.lag_grad(torch.from_numpy(gy).to(dev), torch.from_numpy(de).to(dev)).cpu().numpy()
+        want = (gy * de).astype(np.float64).sum(axis=(0, 2))
+        assert got.shape == (L,) and got.dtype == dtype
+        assert np.allclose(got, want, rtol=3e-6 if dtype == np.float32 else 1e-13, atol=1e-6 if dtype == np.float32 else 1e-13), (outer, L, D)
+    # the same launch twice: the workspace is left re-armed
+    gy, de = torch.from_numpy(rng.randn(300, 12, 64).astype(dtype)).to(dev), torch.from_numpy(rng.randn(300, 12, 64).astype(dtype)).to(dev)
+    assert torch.equal(be.lag_grad(gy, de), be.lag_grad(gy, de))
 
 
 def test_history_spline_properties(dev):
@@ -176,8 +200,10 @@ def test_dde_api_conventions(dev):
                 his=torch.from_numpy(his).to(dev), his_span=torch.from_numpy(ht).to(dev), his_processed=True)
     dy, y0 = torch.ones(2, 3, device=dev), torch.full((2, 3), 2.0, device=dev)
     assert torch.allclose(x.fuse(dy, 0.5, y0), (dy - 0.001 * (dy * 0.5 + y0)) * 0.5 + y0)
-    with pytest.raises(NotImplementedError):
-        HistoryIndex.apply(torch.zeros(1, device=dev), torch.from_numpy(his).to(dev), torch.from_numpy(ht).to(dev), "linear")
+    with pytest.raises(NotImplementedError):  # (the reference's own refusal of an unknown method, base_dde.py:110-111)
+        HistoryIndex.apply(torch.zeros(1, device=dev), torch.from_numpy(his).to(dev), torch.from_numpy(ht).to(dev), "spline")
+    with pytest.raises(ValueError, match="at least 4"):
+        HistoryIndex.apply(torch.zeros(1, device=dev), torch.from_numpy(his[:, :3]).to(dev), torch.from_numpy(ht[:3]).to(dev), "bez")
 
 
 @pytest.mark.parametrize("block", range(_blocks(3)))

@@ -1664,8 +1664,8 @@ def test_output_times_behind_the_previous_one_are_refused_like_the_reference(dev
 def test_reuse_f0_calls_func_once_less_and_changes_nothing_else(dev):
     """The reference evaluates func(t0, y0) twice before the first attempt (base_adaptive_solver_rk.py:83 and, with f0=None, :84-87).
     `reuse_f0=True` hands the first value to the initial-step heuristic: one call less, the same solution bit for bit, the same step
-    trace, NFE reported as the reference counts it.  odeint_adjoint switches it on for its backward intervals (and lets the caller
-    switch it off); plain odeint leaves it off."""
+    trace; `nfe` is the number of calls func really received, `nfe_reference` what the reference would report.  odeint_adjoint
+    switches it on for its backward intervals (and lets the caller switch it off); plain odeint leaves it off."""
     from paddlexde_amd.xde import BaseODE
 
     A = P.skew_matrix(8).double().to(dev)
@@ -1683,10 +1683,11 @@ def test_reuse_f0_calls_func_once_less_and_changes_nothing_else(dev):
         s = Dopri5(xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-7, atol=1e-9, norm=_rms_norm, dtype=torch.float64, record_trace=True,
                    pipeline="sync", reuse_f0=reuse)
         sol = s.integrate(t)
-        out[reuse] = (sol.clone(), list(s.trace), s.stats["nfe"], calls[0])
+        out[reuse] = (sol.clone(), list(s.trace), s.stats["nfe"], calls[0], s.stats["nfe_reference"])
     assert torch.equal(out[False][0], out[True][0]) and out[False][1] == out[True][1]
-    assert out[False][2] == out[True][2] == out[False][3]  # NFE as the reference counts it = the calls it makes
+    assert out[False][2] == out[False][3] and out[True][2] == out[True][3]  # nfe = the calls func received, either way
     assert out[True][3] == out[False][3] - 1
+    assert out[False][4] == out[True][4] == out[False][3]  # nfe_reference = the calls the reference makes
 
     m = ODEFunc(torch.float64).to(dev)
     counted = [0]
@@ -1710,3 +1711,86 @@ def test_reuse_f0_calls_func_once_less_and_changes_nothing_else(dev):
     for a, b in zip(grads[None], grads[False]):
         assert torch.equal(a, b)
     assert n_calls[None] == n_calls[False] - (len(tt) - 1)  # one evaluation of the augmented dynamics less per output interval
+
+
+def test_step_callbacks_adaptive_and_fixed(dev):
+    """The reference names three callbacks in its adaptive stepper and leaves the calls commented out
+    (`self.func.callback_step(t0, y0, dt)` / `callback_accept_step` / `callback_reject_step`, base_adaptive_solver_rk.py:186,259,275), and
+    binds `xde.on_integrate_step_end` in the fixed-step loop without calling it (base_fixed_solver.py:64, xde/base_xde.py:102-103).
+    Here they are live: as options, or as methods of the user's func; every attempt announces itself with the (t0, dt) it runs
+    with — equal to the recorded trace — and exactly one of accept / reject follows; the results are those of a solve without
+    callbacks, bit for bit; pipelines that enqueue ahead of the verdicts refuse them."""
+    from paddlexde_amd import Dopri5, RK4
+    from paddlexde_amd.xde import BaseODE
+
+    mu = 30.0
+    f = P.vdp_torch(mu)
+    y0 = (torch.tensor([2.0, 0.0], dtype=torch.float64) + 0.01 * torch.randn(64, 2, generator=torch.Generator().manual_seed(0), dtype=torch.float64)).to(dev)
+    t = torch.tensor([0.0, 0.4, 1.1], dtype=torch.float64)
+    log = []
+    opts = {"norm": P_rms(), "dtype": torch.float64, "record_trace": True,
+            "callback_step": lambda t0, y, dt: log.append(("step", float(t0), float(dt), tuple(y.shape), t0.dtype, t0.device.type)),
+            "callback_accept_step": lambda t0, y, dt: log.append(("accept", float(t0), float(dt))),
+            "callback_reject": lambda t0, y, dt: log.append(("reject", float(t0), float(dt)))}
+    xde = BaseODE(f, y0=y0, t_span=t)
+    s = Dopri5(xde=xde, y0=y0, rtol=1e-6, atol=1e-8, **opts)
+    sol = s.integrate(t)
+    assert s.pipeline == "sync"  # "auto" resolved to the pipeline that can call back
+    steps = [e for e in log if e[0] == "step"]
+    verdicts = [e for e in log if e[0] != "step"]
+    assert len(steps) == len(verdicts) == len(s.trace) == s.stats["n_steps"] and s.stats["n_reject"] > 0
+    for st, vd, (t0, dt, _ratio, acc) in zip(steps, verdicts, s.trace):
+        assert st[1] == vd[1] == t0 and st[2] == vd[2] == dt and vd[0] == ("accept" if acc else "reject")
+        assert st[3] == (64, 2) and st[4] == torch.float64 and st[5] == "cpu"
+    assert [e[0] for e in log[:2]] == ["step", log[1][0]] and log[1][0] in ("accept", "reject")  # interleaved: step, verdict, step, ...
+    plain = Dopri5(xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-6, atol=1e-8, norm=P_rms(), dtype=torch.float64, pipeline="sync").integrate(t)
+    assert torch.equal(sol, plain)
+    # methods of the user's func, as the reference's comments spell them
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def forward(self, t_, y):
+            return f(t_, y)
+
+        def callback_step(self, t0, y, dt):
+            self.seen.append(float(t0))
+
+    fm = F()
+    s2 = Dopri5(xde=BaseODE(fm, y0=y0, t_span=t), y0=y0, rtol=1e-6, atol=1e-8, norm=P_rms(), dtype=torch.float64)
+    with torch.no_grad():
+        sol2 = s2.integrate(t)
+    assert torch.equal(sol2, plain) and len(fm.seen) == s2.stats["n_steps"]
+    for pipeline in ("lag", "graph"):
+        with pytest.raises(NotImplementedError, match="callbacks"):
+            Dopri5(xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-6, atol=1e-8, norm=P_rms(), pipeline=pipeline, callback_step=lambda *a: None)
+
+    # fixed-step: xde.on_integrate_step_end(y0, y1, t0, t1) after every step of the eager loop
+    class Watched(BaseODE):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.ends = []
+
+        def on_integrate_step_end(self, y0=None, y1=None, t0=None, t1=None):
+            self.ends.append((float(t0), float(t1), y0.clone(), y1.clone()))
+
+    A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], device=dev)
+    g = lambda t_, y: (y * y * y) @ A  # noqa: E731
+    ys = torch.tensor([[2.0, 0.0]], device=dev)
+    tf = torch.linspace(0.0, 1.0, 41)
+    xw = Watched(g, y0=ys, t_span=tf)
+    with torch.no_grad():
+        out = RK4(xde=xw, y0=ys, rtol=1e-7, atol=1e-9, norm=P_rms()).integrate(tf)  # 40 steps: "auto" would capture; the hook keeps it eager
+        ref = RK4(xde=BaseODE(g, y0=ys, t_span=tf), y0=ys, rtol=1e-7, atol=1e-9, norm=P_rms()).integrate(tf)
+    assert torch.equal(out, ref) and len(xw.ends) == 40
+    for i, (t0, t1, a, b) in enumerate(xw.ends):
+        assert t0 == float(tf[i]) and t1 == float(tf[i + 1]) and torch.equal(a, out[i : i + 1]) and torch.equal(b, out[i + 1 : i + 2])
+    with pytest.raises(NotImplementedError, match="on_integrate_step_end"):
+        RK4(xde=xw, y0=ys, rtol=1e-7, atol=1e-9, norm=P_rms(), pipeline="graph")
+
+
+def P_rms():
+    from paddlexde_amd.utils import _rms_norm
+
+    return _rms_norm

@@ -119,6 +119,8 @@ def test_every_entry_point_rejects_null_arguments():
         "xde_commit": lambda: lib.xde_commit(None, None, None, None, None, 8, 0, None),
         "xde_pack_segments": lambda: lib.xde_pack_segments(None, None, None, None, None, 1, 8, 0, None),
         "xde_hermite_gather": lambda: lib.xde_hermite_gather(None, None, None, None, None, 1, 4, 2, 1, 0, None),
+        "xde_history_gather": lambda: lib.xde_history_gather(None, None, None, None, None, 1, 4, 2, 1, 0, 1, None),
+        "xde_lag_grad": lambda: lib.xde_lag_grad(None, None, None, 1, 4, 2, 0, None, None),
         "xde_scale_fanout": lambda: lib.xde_scale_fanout(None, None, None, 1, None, 8, 0, None),
         "xde_graph_replace_memsets": lambda: lib.xde_graph_replace_memsets(None, C.byref(n)),
         "xde_p2p_alloc": lambda: lib.xde_p2p_alloc(None),
@@ -136,7 +138,7 @@ def test_every_entry_point_rejects_null_arguments():
         assert rc == _hip.XDE_EBADARG, (name, rc, msg)
         assert msg and (name in msg or "segments" in msg), (name, msg)
     covered = set(calls) | {"xde_last_error", "xde_abi_version", "xde_sizeof_ctrl", "xde_sizeof_ctrl_params", "xde_sizeof_segments", "xde_workspace_bytes", "xde_host_free", "xde_prof_enable",
-                                "xde_p2p_mailbox_bytes", "xde_p2p_free", "xde_p2p_close"}
+                                "xde_p2p_mailbox_bytes", "xde_p2p_free", "xde_p2p_close", "xde_lag_grad_workspace_bytes"}
     assert covered == set(_hip.SYMBOLS), set(_hip.SYMBOLS) ^ covered
     assert lib.xde_host_free(None) == _hip.XDE_OK  # freeing nothing is fine
 

@@ -33,3 +33,28 @@ def test_bench_refuses_more_ranks_than_gpus_without_touching_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3"], capture_output=True, text=True,
                        timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_stage_watchdog_ends_a_rank_that_outlives_its_stage(tmp_path):
+    """bench.py's per-rank stage clock (no GPU needed): a stage that outlives its limit ends the PROCESS with exit code 70, a line on stderr
+    naming rank and stage, and a status file the launching parent can read; `on_expire` hooks may choose another exit code (the extra
+    measurements of the N > 1 line print the main line and leave with 0)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, {root!r}); import bench\n"
+            "wd = bench.Watchdog(3)\nwd.stage('rendezvous', 100)\nwd.stage('communicator', 0.5{hook})\ntime.sleep(30)\n")
+    env = dict(os.environ, XDE_BENCH_STATUS_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code.format(root=root, hook="")], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 70 and "bench.py[rank 3]: stage 'communicator'" in r.stderr and "rendezvous" in r.stderr
+    st = json.load(open(tmp_path / "rank3.json"))
+    assert st["stage"] == "communicator" and st["note"] == "stage limit exceeded" and st["history"][0][0] == "rendezvous"
+    sys.path.insert(0, root)
+    import bench
+
+    assert "rank 3: in stage 'communicator'" in bench._stage_report(str(tmp_path), 4) and "rank 0: never reported" in bench._stage_report(str(tmp_path), 4)
+    r = subprocess.run([sys.executable, "-c", code.format(root=root, hook=", on_expire=lambda: 0")], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "over its limit" in r.stderr

@@ -363,20 +363,26 @@ def _p2p_worker(rank, world, port, out_dir, norm_name, pipeline):
                 want = torch.cat([torch.stack(parts).max(0).values[:16], torch.stack(parts).sum(0)[16:]])
                 assert torch.equal(sums.cpu(), want), (i, sums.cpu(), want)
             assert ex.error() == 0
+            assert ex.fused_control  # the default: finalize + exchange + controller of an attempt as ONE launch (xde_p2p_rk_control)
             sol, s = _solve(y0[rows].contiguous().to("cuda:0"), A.to("cuda:0"), True, norm_name, pipeline, exchange=ex)
+            # the same solve with the three launches the fused one replaces (xde_norm_finalize, xde_p2p_exchange, xde_rk_control)
+            ex.fused_control = False
+            sol3, s3 = _solve(y0[rows].contiguous().to("cuda:0"), A.to("cuda:0"), True, norm_name, pipeline, exchange=ex)
+            ex.fused_control = True
             # the all-reduce twin (gloo): a captured step cannot hold it, so the graph case is compared with the lag pipeline
             sol2, s2 = _solve(y0[rows].contiguous().to("cuda:0"), A.to("cuda:0"), True, norm_name, "lag" if pipeline == "graph" else pipeline)
         finally:
             ex.close()
         tr = lambda so: np.asarray([[a, b, c, float(d)] for a, b, c, d in so.trace])  # noqa: E731
         np.savez(os.path.join(out_dir, "p2p{}.npz".format(rank)), sol=sol.cpu().numpy(), trace=tr(s), sol_ar=sol2.cpu().numpy(),
-                 trace_ar=tr(s2))
+                 trace_ar=tr(s2), sol_3=sol3.cpu().numpy(), trace_3=tr(s3))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm_name,pipeline,world", [("rms", "sync", 2), ("rms", "lag", 2), ("linf", "lag", 2), ("rms", "graph", 2),
+                                                      ("rms", "sync", 3), ("rms", "lag", 3), ("rms", "graph", 3),
                                                       ("rms", "lag", 4), ("rms", "graph", 4)])
 def test_peer_exchange_two_ranks_on_one_gpu(tmp_path, norm_name, pipeline, world):
     """The IPC-mapped mailboxes carry the per-attempt norm sums instead of an all-reduce: both ranks stay in lock-step and the
@@ -388,10 +394,12 @@ def test_peer_exchange_two_ranks_on_one_gpu(tmp_path, norm_name, pipeline, world
     for r in rs[1:]:
         assert np.array_equal(rs[0]["trace"], r["trace"])  # lock-step, bit for bit, whatever the world size
     for r in rs:
+        # ONE launch (xde_p2p_rk_control) == the three launches it replaces, bit for bit, whatever the world size
+        assert np.array_equal(r["trace"], r["trace_3"]) and np.array_equal(r["sol"], r["sol_3"])
         if world == 2:
             assert np.array_equal(r["trace"], r["trace_ar"]) and np.array_equal(r["sol"], r["sol_ar"])
         else:
-            # four summands: the mailbox sums them in RANK order, the all-reduce in its own order — equal to fp64 rounding
+            # three / four summands: the mailbox sums them in RANK order, the all-reduce in its own order — equal to fp64 rounding
             assert r["trace"].shape == r["trace_ar"].shape and np.array_equal(r["trace"][:, 3], r["trace_ar"][:, 3])
             assert np.allclose(r["trace"][:, :3], r["trace_ar"][:, :3], rtol=1e-6, atol=1e-12)
             assert P.rel_err(r["sol"], r["sol_ar"]) <= 1e-6
