@@ -61,25 +61,31 @@ def selftest(exchange, group=None, rounds=3):
     dev = exchange.device
     base = torch.arange(2 * m, dtype=torch.float64)
     ok, why = True, None
+
+    def note(msg):
+        nonlocal ok, why
+        if ok:
+            ok, why = False, msg
+
     try:
+        # (every rank runs EVERY round whatever it has seen so far: a rank that left early would leave its peers waiting in the
+        #  next exchange until their bounded wait ran out)
         for i in range(rounds):
             sums = (base * (rank + 1) + i).to(dev)
             exchange.exchange(sums, _hip.NORM_RMS)
             want = sum(base * (r + 1) + i for r in range(world))
             if not torch.equal(sums.cpu(), want):
-                ok, why = False, "sum round {}: got {} want {}".format(i, sums.cpu()[:3].tolist(), want[:3].tolist())
-                break
+                note("sum round {}: got {} want {}".format(i, sums.cpu()[:4].tolist(), want[:4].tolist()))
             sums = (base * (rank + 1) - i).to(dev)
             exchange.exchange(sums, _hip.NORM_LINF)
             parts = torch.stack([base * (r + 1) - i for r in range(world)])
             want = torch.cat([parts.max(0).values[:m], parts.sum(0)[m:]])
             if not torch.equal(sums.cpu(), want):
-                ok, why = False, "max round {}: got {} want {}".format(i, sums.cpu()[:3].tolist(), want[:3].tolist())
-                break
+                note("max round {}: got {} want {}".format(i, sums.cpu()[:4].tolist(), want[:4].tolist()))
         if ok and exchange.error():
-            ok, why = False, "the exchange reports a failed round"
+            note("the exchange reports a failed round")
     except Exception as e:  # noqa: BLE001 - whatever went wrong, the group must hear about it
-        ok, why = False, "{}: {}".format(type(e).__name__, e)
+        note("{}: {}".format(type(e).__name__, e))
     return agree(ok, group), why
 
 

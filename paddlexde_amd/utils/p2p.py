@@ -19,7 +19,11 @@ class PeerExchange:
     # the solver takes finalize -> exchange -> controller of a sharded attempt as ONE launch (xde_p2p_rk_control) when this is set;
     # False keeps the three launches (xde_norm_finalize, xde_p2p_exchange, xde_rk_control) — same bits, measured side by side
     fused_control = True
-    SPIN_LIMIT = 20_000_000  # polls of ~60 ns before an exchange gives up (about a second): a peer died or fell out of step
+    # Polls (~60 ns each) before an exchange gives up: about 20 s.  The wait has to cover the honest skew between ranks — one rank
+    # still tuning its GEMMs or paging a library in while another has already enqueued its first exchange — and still end: a peer
+    # that died or fell out of lock-step must not leave a wave spinning for ever.  (Tests that exercise the failure path set it to
+    # milliseconds; bench.py's transport probe to a tenth of a second.)
+    SPIN_LIMIT = 400_000_000
 
     def __init__(self, group=None, device=None):
         import torch.distributed as dist

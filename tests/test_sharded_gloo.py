@@ -609,3 +609,74 @@ def test_exchange_negotiation_is_group_safe_without_a_gpu(tmp_path):
         assert r["kind"] == "allreduce" and r["exchange_is_none"]
         assert [x["transport"] for x in r["report"]] == ["p2p", "rccl", "allreduce"]
         assert [x["adopted"] for x in r["report"]] == [False, False, True] and all(x.get("why") for x in r["report"][:2])
+
+
+def _negotiate_gpu_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+
+        from paddlexde_amd.utils import exchange as X
+
+        rec = {}
+        dev = torch.device("cuda", 0)
+        # (1) the preferred transport works here (mailboxes are IPC-mapped between processes on one GPU): adopted after its self-test
+        ex, kind, report = X.negotiate(None, dev, prefer=("p2p", "rccl", "allreduce"))
+        rec["first"] = [kind, report]
+        ok, why = X.selftest(ex, None, rounds=5)
+        rec["selftest_again"] = [ok, why]
+        ex.close()
+        # (2) RCCL refuses two ranks on ONE device: the communicator cannot be built, on every rank; the group falls back TOGETHER
+        ex2, kind2, report2 = X.negotiate(None, dev, prefer=("rccl", "allreduce"))
+        rec["second"] = [kind2, ex2 is None, report2]
+        # (3) a transport whose self-test fails on ONE rank only is dropped by all of them
+        from paddlexde_amd.utils import PeerExchange
+
+        real = PeerExchange.exchange
+
+        def corrupt(self, sums, norm_kind):
+            real(self, sums, norm_kind)
+            if rank == 1:
+                sums[3] += 1.0  # this rank "receives" a wrong sum
+
+        PeerExchange.exchange = corrupt
+        try:
+            ex3, kind3, report3 = X.negotiate(None, dev, prefer=("p2p", "allreduce"))
+        finally:
+            PeerExchange.exchange = real
+        rec["third"] = [kind3, ex3 is None, report3]
+        with open(os.path.join(out_dir, "negg{}.json".format(rank)), "w") as fh:
+            json.dump(rec, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_exchange_negotiation_on_the_gpu_adopts_falls_back_and_never_splits(tmp_path):
+    """utils/exchange.py with the real transports, two ranks on one GPU: the peer-to-peer transport is adopted after its self-test;
+    RCCL — which cannot build a communicator for two ranks on one device — is dropped by both ranks with the library's own message
+    and the group lands on the all-reduce; a self-test that fails on ONE rank drops the transport on BOTH.  Run under a deadline: a
+    hang inside a communicator initialisation must fail this test, not the suite."""
+    import json
+    import time
+
+    ctx = mp.spawn(_negotiate_gpu_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=False)
+    deadline = time.time() + 240
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:  # (exactly the two processes this test started)
+                if p.is_alive():
+                    p.kill()
+            pytest.fail("the negotiation did not finish in 240 s")
+    r0, r1 = [json.load(open(tmp_path / "negg{}.json".format(r))) for r in range(2)]
+    for r in (r0, r1):
+        assert r["first"][0] == "p2p" and r["first"][1] == [{"transport": "p2p", "adopted": True}] and r["selftest_again"][0] is True
+        kind2, none2, rep2 = r["second"]
+        assert kind2 == "allreduce" and none2 and [x["transport"] for x in rep2] == ["rccl", "allreduce"] and rep2[0]["adopted"] is False
+        kind3, none3, rep3 = r["third"]
+        assert kind3 == "allreduce" and none3 and rep3[0] == {"transport": "p2p", "adopted": False, "why": rep3[0]["why"]}
+    assert "RcclExchange" in r0["second"][2][0]["why"] or "ncclCommInitRank" in r0["second"][2][0]["why"] or "another rank" in r0["second"][2][0]["why"]
+    assert "sum round" in r1["third"][2][0]["why"] and "another rank" in r0["third"][2][0]["why"]
