@@ -781,8 +781,10 @@ def p2p_probe_child():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if os.environ.get("XDE_BENCH_REHEARSAL", "0") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("XDE_BENCH_TEST_PROBE_FAIL") == str(rank):  # test hook: this rank's probe dies the hard way, before anything else
+        os.abort()
     wd = Watchdog(rank)
-    wd.stage("probe: rendezvous", 90)
+    wd.stage("probe: rendezvous", 45)
     dist.init_process_group("gloo")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -1005,7 +1007,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_run(kind, ex, steps, warmup, events):
+    def timed_run(kind, ex, steps, warmup, events, pipeline=None):
         """Build a solver on transport `kind`, let it settle, warm up, and time EXACTLY `steps` attempted steps between barriers:
         every rank's own clock stops after its stream has drained, the job's time is the MAX over the ranks."""
         if os.environ.get("XDE_BENCH_TEST_HANG") == str(rank):  # test hook: this rank never joins the set-up's first collective
@@ -1013,17 +1015,18 @@ def main():
         with torch.no_grad():
             func(None, y0)  # the framework picks (TunableOp: times) its GEMM here, on every rank, before anything is exchanged ...
         barrier()  # ... and the ranks start the solve together: the first norm exchange does not have to absorb seconds of skew
-        solver = Solver(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=args.pipeline, process_group=group_for(kind),
+        pipeline = args.pipeline if pipeline is None else pipeline
+        solver = Solver(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=pipeline, process_group=group_for(kind),
                         norm_exchange=ex)
         solver.y0 = y0
         solver._before_integrate(np.asarray([0.0, 1.0e9], dtype=np.float32))
         # pipeline="auto" on a small state starts eagerly and captures its hipGraph after AUTO_GRAPH_AFTER attempts: let it settle
         # (setup, like the GEMM tuning) before the W warm-up steps, so that no capture falls into the timed region
         settle = 0
-        while args.pipeline == "auto" and solver._auto_state in (None, "sync-then-graph") and settle < 64:
+        while pipeline == "auto" and solver._auto_state in (None, "sync-then-graph") and settle < 64:
             solver.advance(4)
             settle += 4
-        if solver._auto_state == "graph" or args.pipeline == "graph":
+        if solver._auto_state == "graph" or pipeline == "graph":
             solver.advance(solver.GRAPH_ATTEMPTS + 1)  # both graphs a budgeted advance replays (4 attempts, 1 attempt) now exist
             settle += solver.GRAPH_ATTEMPTS + 1
         solver.advance(warmup)
@@ -1157,8 +1160,19 @@ def main():
             _s, _c, el2, _p, _ = timed_run(kind, ex2, steps2, min(args.warmup, 10), False)
             ab[kind] = {"ms_per_step": 1e3 * el2 / steps2, "steps": steps2}
             del _s
+            if kind == "p2p" and args.pipeline in ("auto", "lag"):
+                # the one transport whose sharded attempt can be CAPTURED: the same ranks replaying hipGraphs of whole attempts
+                # (host floor 50 us per attempt against 129 us enqueued eagerly) — says whether the hosts of a full node keep up
+                _s, _c, el3, _p, _ = timed_run(kind, ex2, steps2, min(args.warmup, 10), False, pipeline="graph")
+                ab["p2p, pipeline=graph"] = {"ms_per_step": 1e3 * el3 / steps2, "steps": steps2}
+                del _s
             if ex2 is not None:
                 ex2.close()
+        if exchange_kind == "p2p" and args.pipeline in ("auto", "lag"):
+            steps2 = min(args.steps, 60)
+            _s, _c, el3, _p, _ = timed_run("p2p", exchange, steps2, min(args.warmup, 10), False, pipeline="graph")
+            ab["p2p, pipeline=graph"] = {"ms_per_step": 1e3 * el3 / steps2, "steps": steps2}
+            del _s
         out["exchange_ab"] = ab
 
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline and args.dtype == "f32":
