@@ -108,12 +108,9 @@ __device__ __forceinline__ void errnorm_pre_body(const ErrArgs& a, int seg, int 
   const int64_t stride = int64_t(nb) * kBlock;
   const int64_t i0 = int64_t(lb) * kBlock + threadIdx.x;
   // the control block's two words are REQUESTED here and waited for only where y0's address is formed, below the first loads
-  double dtd = a.dt_host;
-  int32_t accw = 0;
-  if (a.ctrl) {
-    dtd = __builtin_nontemporal_load(&a.ctrl->dt);
-    accw = __builtin_nontemporal_load(&a.ctrl->accept);
-  }
+  // (the host launches this kernel only with a control block: a branch on `a.ctrl` here would put the wait back in front)
+  const double dtd = __builtin_nontemporal_load(&a.ctrl->dt);
+  const int32_t accw = __builtin_nontemporal_load(&a.ctrl->accept);
   const T rtol = T(a.rtol), atol = T(a.atol);
   T acc = T(0);
   double acc64 = 0.0;
@@ -143,6 +140,9 @@ __device__ __forceinline__ void errnorm_pre_body(const ErrArgs& a, int seg, int 
     P y1v = P::load(y1, vbase + i0);
     P ep = NT ? P::load_nt(epre, vbase + i0) : P::load(epre, vbase + i0);
     P kk = P::load(kl, vbase + i0);
+    // (pinned: without this the scheduler hoists the select — and with it the wait for the control block's words — above the three
+    //  loads; 0.2 us per launch at 16 MiB operands, profiles/r04_errnorm_lab.txt k_pipe2)
+    __builtin_amdgcn_sched_barrier(0);
     const int sel = (a.use_sel && accw) ? 1 : 0;
     y0 = static_cast<const T*>(a.y0[sel]);
     P y0v = NT ? P::load_nt(y0, vbase + i0) : P::load(y0, vbase + i0);

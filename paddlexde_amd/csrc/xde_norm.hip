@@ -261,7 +261,7 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   //  locality — 82.4 vs 79.0 us at 128 MiB operands — so the general kernel keeps them; below, latency counts and the new body wins)
   int64_t tot_elems = 0;
   for (int s2 = 0; s2 < segs->n_seg; ++s2) tot_elems += segs->seg_len[s2];
-  const bool pre = vec && e_pre && nk == 1 && a.k0_alt == a.k[0] && pre_variant != 0 && !big_operand(tot_elems, dtype);
+  const bool pre = vec && e_pre && nk == 1 && ctrl && a.k0_alt == a.k[0] && pre_variant != 0 && !big_operand(tot_elems, dtype);
 #define LAUNCH_ERR(T, NORM)                                                       \
   do {                                                                            \
     if (pre && a.nt)                                                              \
