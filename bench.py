@@ -28,8 +28,9 @@ taken after the timed region, so a strong-scaling efficiency can be computed fro
 `--workload rk4`: the bandwidth-bound fixed-step line (reference RK4 variant, 65536 x 128, 18 N 4 B per step).
 
 value = states/sec = (global batch * dim) / (wall time per attempted step), whole job.
-roofline: algorithmic bytes of the stage-combine kernel (sum over the 6 stages of (operands + 2) *
-N * 4 B = 32 N * 4 B per step) / its launch durations measured with HIP events on the launch stream.
+roofline: bytes the stage-combine launches really move (SURVEY 8d counts (operands + 2) * N * 4 B per stage = 32 N * 4 B per Dopri5
+step; with stage 5 pre-summed — it reads y0, the partial sum stage 4's launch emitted, and k4 — the step moves 30 N, + 1 N for the
+partial error estimate) / their launch durations measured with HIP events on the launch stream.
 cpu_baseline: "B1", the oracle's torch-CPU twin (op-for-op restatement of the reference's eager op sequence — the reference's
 Paddle CPU path itself cannot run: Paddle is not installed and the reference never travels to the GPU box), timed on the host cores
 of this box on a bounded sample (~10 s of attempted steps at the SAME batch x dim); cpu_baseline_fused: "B2", the same step on fused

@@ -174,6 +174,19 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
                       const double* coef2, double damping, uint32_t nt_mask, void* stream);
 
 /*
+ * A stage whose EARLIER operands were already summed by the previous stage's launch (ABI 5): that launch passes
+ * `out2 = partial, coef2_j = beta_{i,j}` over the operands it holds anyway (xde_stage_combine's second output: `sum_j k_j (dt coef2_j)`,
+ * left to right), and stage i becomes
+ *     out = y0 + ((pre + k_0 (coef_0 dt)) + k_1 (coef_1 dt) ...)          k: the stage's 1..4 NEWEST derivatives only
+ * — the same left-to-right association as `yi = y0 + sum(k[..., :i+1] * (beta_i * dt), -1)` (base_adaptive_solver_rk.py:166-168), so the
+ * result is bit-identical, for 3 arrays read instead of (operands + 1): Dopri5's stage 5 reads y0, the partial sum and k_4 instead of
+ * y0, k_0..k_4, and the step moves 30 N instead of 32 N elements through its stage combines.  y0_alt: the speculative pipeline's select
+ * of y0 (the newest derivatives are never the select-able f0).
+ */
+int xde_stage_combine_pre(void* out, const void* y0, const void* y0_alt, const void* pre, const void* const* k, const double* coef,
+                          int nk, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, uint32_t nt_mask, void* stream);
+
+/*
  * Error-norm partials — replaces `y1_error = sum(k * (dt * c_error), -1)` (base_adaptive_solver_rk.py:180),
  * compute_error_ratio's element-wise chain and the reduction inside the norm (utils/ode_utils.py:80-82,
  * :4-9), and the `isfinite(y0).all()` pass (base_adaptive_solver_rk.py:201).

@@ -36,6 +36,7 @@ SYMBOLS = (
     "xde_sizeof_segments",
     "xde_workspace_bytes",
     "xde_stage_combine",
+    "xde_stage_combine_pre",
     "xde_error_norm_partial",
     "xde_error_norm_control",
     "xde_error_ratio",
@@ -203,6 +204,8 @@ def load_library():
         lib.xde_workspace_bytes.restype = i64
         lib.xde_stage_combine.restype = i32
         lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, C.c_uint32, vp]
+        lib.xde_stage_combine_pre.restype = i32
+        lib.xde_stage_combine_pre.argtypes = [vp, vp, vp, vp, vpp, dp, i32, dbl, vp, i64, i32, C.c_uint32, vp]
         lib.xde_error_norm_partial.restype = i32
         lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp, vp]
         lib.xde_error_norm_control.restype = i32
@@ -440,6 +443,17 @@ class HipBackend:
             _dbl_array(coef2) if coef2 is not None else None, float(damping), int(nt_mask) & 0xFFFFFFFF, self._stream(out),
         )
         self._check(rc, "xde_stage_combine")
+
+    def stage_combine_pre(self, out, y0, pre, ks, coef, *, dt_host=0.0, ctrl=None, y0_alt=None, nt_mask=0):
+        """out = y0 + ((pre + ks[0] coef[0] dt) + ...): a stage whose earlier operands the previous stage's launch has already summed
+        into ``pre`` (its second output)."""
+        self._require_device(out, y0, pre, y0_alt, *ks)
+        if out.numel() == 0:
+            return
+        rc = self.lib.xde_stage_combine_pre(out.data_ptr(), y0.data_ptr(), _ptr(y0_alt), pre.data_ptr(), _ptr_array(ks), _dbl_array(coef),
+                                            len(ks), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype),
+                                            int(nt_mask) & 0xFFFFFFFF, self._stream(out))
+        self._check(rc, "xde_stage_combine_pre")
 
     def error_norm_partial(self, ks, c_err, y0, y1, rtol, atol, segs, norm_kind, ws, *, dt_host=0.0, ctrl=None,
                            y0_alt=None, k0_alt=None, e_pre=None):

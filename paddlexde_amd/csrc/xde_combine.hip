@@ -29,9 +29,10 @@ __device__ __forceinline__ T fuse_(T dy, T dt, T y0, T lam) {
 // ------------------------------------------------------------------------------------------
 // K1: stage combine
 // ------------------------------------------------------------------------------------------
-template <typename T, int MODE, int NK, bool VEC, bool OUT2>
+template <typename T, int MODE, int NK, bool VEC, bool OUT2, bool PRE = false>
 __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __restrict__ y0,
                                              const T* __restrict__ k0, T dt) {
+  const T* __restrict__ pre = static_cast<const T*>(a.pre);
   const unsigned ntm = unsigned(a.nt);  // bit j: stream operand k_j; bit 31: stream y0
   using P = Pack<T, VEC>;
   constexpr int W = P::W;
@@ -61,6 +62,8 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
     // speculative pipeline y0 / k0 are picked by ctrl->accept, a scalar load that is still in flight when the wave starts;
     // k_1.. can be requested meanwhile, so the select's memory round trip hides behind them (it cost ~0.9 us per launch).
     P kk[NK];
+    P pr;
+    if (PRE) pr = P::load_nt(pre, i);  // (written by the previous stage's launch for this one alone: read once, streamed)
 #pragma unroll
     for (int j = NK - 1; j >= 1; --j) kk[j] = load_sel<P>(kp[j], i, (ntm >> j) & 1u);
     P y = load_sel<P>(y0, i, (ntm >> 31) & 1u);
@@ -70,7 +73,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
 #pragma unroll
     for (int w = 0; w < W; ++w) {
       if (MODE == XDE_COMBINE_RK) {
-        T acc = kk[0].v[w] * c[0];
+        T acc = PRE ? pr.v[w] + kk[0].v[w] * c[0] : kk[0].v[w] * c[0];
 #pragma unroll
         for (int j = 1; j < NK; ++j) acc = acc + kk[j].v[w] * c[j];
         o.v[w] = y.v[w] + acc;
@@ -112,7 +115,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
         for (int j = 1; j < NK; ++j) acc = acc + fuse_(kp[j][i], dt, yv, lam) * c[j];
         out[i] = acc * scale;
       } else {
-        acc = kp[0][i] * c[0];
+        acc = PRE ? pre[i] + kp[0][i] * c[0] : kp[0][i] * c[0];
         for (int j = 1; j < NK; ++j) acc = acc + kp[j][i] * c[j];
         out[i] = (MODE == XDE_COMBINE_RK) ? (yv + acc) : fuse_(acc, dt, yv, lam);
       }
@@ -203,6 +206,29 @@ __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
   }
 }
 
+// A stage whose earlier operands were already summed by the PREVIOUS stage's launch (which held them in registers anyway and emitted
+// `sum_j k_j (beta_ij dt)` over them as its second output): this launch reads y0, that partial sum and the newest derivative(s) —
+// Dopri5's stage 5: 3 arrays in, 1 out, instead of 6 in, 1 out; the emitting launch writes one array more.  Same left-to-right
+// association as the full sum (`((..) + k_3 c_3) + k_4 c_4`, then `y0 +`): bit-identical.  Its own instantiation (registers).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_combine_pre_kernel(CombineArgs a) {
+  int sel = 0;
+  T dt;
+  if (a.ctrl) {
+    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
+  } else {
+    dt = T(a.dt_host);
+  }
+  const T* y0 = static_cast<const T*>(a.y0[sel]);
+  const T* k0 = static_cast<const T*>(a.k[0]);  // (not the select-able f0: the operands here are the stage's NEWEST derivatives)
+  switch (a.nk) {
+    case 1: combine_body<T, XDE_COMBINE_RK, 1, VEC, false, true>(a, y0, k0, dt); break;
+    case 2: combine_body<T, XDE_COMBINE_RK, 2, VEC, false, true>(a, y0, k0, dt); break;
+    case 3: combine_body<T, XDE_COMBINE_RK, 3, VEC, false, true>(a, y0, k0, dt); break;
+    default: combine_body<T, XDE_COMBINE_RK, 4, VEC, false, true>(a, y0, k0, dt); break;
+  }
+}
+
 // (8..14 operands — Dopri8's later stages, the Adams predictor's long histories — take combine_generic's runtime loop.  A separate
 // kernel with compile-time counts was measured in round 3 and is NOT faster here: 63.9 vs 62.6 us per launch on Dopri8's four
 // long stages at config 2's size (0.80 of the HBM peak either way; the loop body is short enough for the compiler to keep several
@@ -278,15 +304,36 @@ __global__ __launch_bounds__(kBlock) void xde_commit_kernel(const xde_ctrl_t* c,
 
 extern "C" {
 
+static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
+                              const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
+                              int64_t n, int dtype, void* out2, const double* coef2, double damping, uint32_t nt_mask,
+                              const void* pre, void* stream);
+
 int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
                       const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
                       int64_t n, int dtype, void* out2, const double* coef2, double damping, uint32_t nt_mask, void* stream) {
+  return stage_combine_impl(out, y0, y0_alt, k, k0_alt, coef, nk, mode, scale, dt_host, ctrl, n, dtype, out2, coef2, damping, nt_mask,
+                            nullptr, stream);
+}
+
+int xde_stage_combine_pre(void* out, const void* y0, const void* y0_alt, const void* pre, const void* const* k, const double* coef,
+                          int nk, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, uint32_t nt_mask, void* stream) {
+  if (!pre) return fail(XDE_EBADARG, "xde_stage_combine_pre: null pointer");
+  if (nk < 1 || nk > 4) return fail(XDE_EBADARG, "xde_stage_combine_pre: 1..4 new operands");
+  return stage_combine_impl(out, y0, y0_alt, k, nullptr, coef, nk, XDE_COMBINE_RK, 1.0, dt_host, ctrl, n, dtype, nullptr, nullptr, 0.0,
+                            nt_mask, pre, stream);
+}
+
+static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
+                              const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
+                              int64_t n, int dtype, void* out2, const double* coef2, double damping, uint32_t nt_mask,
+                              const void* pre, void* stream) {
   if (!out || !y0 || !k || !coef) return fail(XDE_EBADARG, "xde_stage_combine: null pointer");
   if (nk < 1 || nk > XDE_MAX_K) return fail(XDE_EBADARG, "xde_stage_combine: nk out of range");
   if (n < 0) return fail(XDE_EBADARG, "xde_stage_combine: negative n");
   if (mode < 0 || mode > 2) return fail(XDE_EBADARG, "xde_stage_combine: bad mode");
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_stage_combine: bad dtype");
-  if ((y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: y0_alt/k0_alt must come together");
+  if (!pre && (y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: y0_alt/k0_alt must come together");
   if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_stage_combine: operand select needs ctrl");
   if ((out2 == nullptr) != (coef2 == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: out2/coef2 must come together");
   if (out2 && mode != XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: second output needs mode RK");
@@ -295,6 +342,7 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   memset(&a, 0, sizeof(a));
   a.out = out;
   a.out2 = out2;
+  a.pre = pre;
   a.y0[0] = y0;
   a.y0[1] = y0_alt ? y0_alt : y0;
   a.k0_alt = k0_alt ? k0_alt : k[0];
@@ -308,6 +356,7 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
     vec = vec && aligned16(k[j]);
   }
   if (out2) vec = vec && aligned16(out2);
+  if (pre) vec = vec && aligned16(pre);
   if (damping != 0.0 && mode == XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: damping applies to FUSE/WFUSE");
   a.damp = damping;
   // operands far larger than the Infinity Cache: stream everything; otherwise only what the caller marks as last use
@@ -325,7 +374,7 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double elt = dtype == XDE_F32 ? 4.0 : 8.0;
   const int kid = mode == XDE_COMBINE_RK ? XDE_KID_COMBINE : (mode == XDE_COMBINE_FUSE ? XDE_KID_COMBINE_FUSE : XDE_KID_COMBINE_WFUSE);
-  ProfScope prof(kid, double(nk + 2 + (out2 ? 1 : 0)) * double(n) * elt);
+  ProfScope prof(kid, double(nk + 2 + (out2 ? 1 : 0) + (pre ? 1 : 0)) * double(n) * elt);
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
 #define LAUNCH_COMBINE(T, MODE)                                                       \
   do {                                                                                \
@@ -341,7 +390,15 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
     else                                                                                     \
       XDE_LAUNCH((xde_combine_kernel<T, XDE_COMBINE_RK, false, true>), g, b, st, prof, a);   \
   } while (0)
-  if (out2) {
+  if (pre) {
+    if (dtype == XDE_F32) {
+      if (vec) XDE_LAUNCH((xde_combine_pre_kernel<float, true>), g, b, st, prof, a);
+      else XDE_LAUNCH((xde_combine_pre_kernel<float, false>), g, b, st, prof, a);
+    } else {
+      if (vec) XDE_LAUNCH((xde_combine_pre_kernel<double, true>), g, b, st, prof, a);
+      else XDE_LAUNCH((xde_combine_pre_kernel<double, false>), g, b, st, prof, a);
+    }
+  } else if (out2) {
     if (dtype == XDE_F32) LAUNCH_COMBINE2(float);
     else LAUNCH_COMBINE2(double);
   } else if (dtype == XDE_F32) {

@@ -181,7 +181,8 @@ __device__ inline double nanmax_(double a, double b) { return (a != a) ? a : ((b
 // ------------------------------------------------------------------------------------------
 struct CombineArgs {
   void* out;
-  void* out2;  // optional second output (RK mode): sum_j k_j * (dt * coef2_j), no y0 — the partial error estimate
+  void* out2;  // optional second output (RK mode): sum_j k_j * (dt * coef2_j), no y0 — the partial error estimate, or the NEXT stage's partial sum
+  const void* pre;  // optional pre-accumulated sum (RK mode): out = y0 + ((pre + k_0 c_0) + k_1 c_1 ...) — written by the previous stage's out2
   double coef2[XDE_MAX_K];
   const void* y0[2];
   const void* k[XDE_MAX_K];

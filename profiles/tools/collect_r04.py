@@ -79,10 +79,13 @@ def main():
         json.dump(pj, open(os.path.join(D, dst), "w"), indent=1)
         c, cl = (pj[k]["hbm_bytes_per_launch"] for k in ("combine", "combine_last_stage(+partial error)"))
         en = pj.get("errnorm", {}).get("hbm_bytes_per_launch")
-        by_size[key] = {"hbm_bytes_per_launch": (5 * c + cl) / 6, "errnorm_hbm_bytes_per_launch": en, "round": 4,
+        cp = pj.get("combine_pre(partial sum in)", {}).get("hbm_bytes_per_launch")
+        # a Dopri5 step: with pre-summed stages 3 plain launches (stages 1-3), 2 two-output launches (stage 4 emits stage 5's partial sum,
+        # stage 6 the partial error), 1 pre-summed launch (stage 5); without: 5 plain + the last stage
+        mean = (3 * c + 2 * cl + cp) / 6 if cp else (5 * c + cl) / 6
+        by_size[key] = {"hbm_bytes_per_launch": mean, "errnorm_hbm_bytes_per_launch": en, "round": 4,
                         "kernel_stamp": kernel_stamp("combine"), "errnorm_kernel_stamp": kernel_stamp("errnorm"),
-                        "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 5 plain stage launches + 1 last-stage "
-                                  "launch per step)" % dst}
+                        "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; mean over the step's six stage launches)" % dst}
     if by_size:
         json.dump({"by_size": by_size, "note": "written by profiles/tools/collect_r04.py; bench.py reports a figure only when kernel_stamp equals "
                    "csrc/build.py::kernel_stamp('combine') of the sources the library was built from"}, open(tpath, "w"), indent=1)

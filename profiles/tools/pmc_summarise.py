@@ -17,9 +17,11 @@ import sys
 
 
 def classify(name):
+    if "xde_combine_pre_kernel" in name:
+        return "combine_pre(partial sum in)"
     if "xde_combine_kernel" in name:
         if "Lb1ELb1E" in name or "true, true" in name:
-            return "combine_last_stage(+partial error)"
+            return "combine_last_stage(+partial error)"  # (since round 4 also the stage that emits the next stage's partial sum: both write two arrays)
         if "Li1E" in name or ", 1," in name:
             return "combine_fuse"
         if "Li2E" in name or ", 2," in name:

@@ -97,6 +97,25 @@ class NumpyDoubleBackend:
                     acc = acc + self._fuse(kk[j], dt, y, T(damping)) * cs[j]
                 o[...] = acc * T(scale)
 
+    def stage_combine_pre(self, out, y0, pre, ks, coef, *, dt_host=0.0, ctrl=None, y0_alt=None, nt_mask=0):
+        """Contract of xde_stage_combine_pre: out = y0 + ((pre + ks[0] c_0) + ks[1] c_1 ...), c_j = T(coef_j) * dt."""
+        self.launches.append("combine")
+        T = _NP[out.dtype]
+        sel = 0
+        if ctrl is not None:
+            c = self._c(ctrl)
+            dt = T(c.dt)
+            if y0_alt is not None and c.accept:
+                sel = 1
+        else:
+            dt = T(dt_host)
+        y = _np(y0_alt if sel else y0).reshape(-1)
+        with np.errstate(all="ignore"):
+            acc = _np(pre).reshape(-1)
+            for k, c_ in zip(ks, coef):
+                acc = acc + _np(k).reshape(-1) * (T(c_) * dt)
+            _np(out).reshape(-1)[...] = y + acc
+
     @staticmethod
     def _fuse(dy, dt, y0, lam):
         if lam == 0:

@@ -39,21 +39,29 @@ def test_one_attempt_taken_apart_vs_oracle(dev, name, dtype):
         y1_ref, f1_ref, err_ref, k = so._runge_kutta_step(y0, f0, t0, dt, t0 + dt, so.tableau)
     S = k.shape[-1] - 1
     cls = CASES[name]
-    n_stage, stage_plan, fsal, sol_plan, err_plan, mid_plan, fuse_err, err2_coef, _ = _build_plans(cls.tableau, cls.mid)
+    n_stage, stage_plan, fsal, sol_plan, err_plan, mid_plan, fuse_err, err2_coef, _, presum = _build_plans(cls.tableau, cls.mid)
     assert n_stage == S
+    if name == "dopri5" and presum:
+        assert sorted(presum) == [4]  # stage 5 (y0, k0..k4: six arrays in) reads y0, the partial sum stage 4's launch emitted, and k4
     mv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     ks = [mv(k[..., j]) for j in range(S + 1)]  # SoA: one tensor per stage derivative
     y0d = mv(y0)
 
     # ---- every stage input: y_i = y0 + sum_j k_j (beta_ij dt)                                        :166-168
     ebuf = torch.empty_like(y0d)
+    sbuf = torch.empty_like(y0d)
     y_last = None
     for i in range(S):
         idx, coef = stage_plan[i]
         out = torch.empty_like(y0d)
         last = i == S - 1
-        be.stage_combine(out, y0d, [ks[j] for j in idx], coef, _hip.COMBINE_RK, dt_host=float(dt),
-                         out2=ebuf if (last and fuse_err) else None, coef2=err2_coef if (last and fuse_err) else None)
+        if i in presum:  # the previous launch has summed this stage's earlier operands: same association, same bits
+            be.stage_combine_pre(out, y0d, sbuf, [ks[j] for j in presum[i][1]], presum[i][2], dt_host=float(dt))
+        elif i + 1 in presum:
+            be.stage_combine(out, y0d, [ks[j] for j in idx], coef, _hip.COMBINE_RK, dt_host=float(dt), out2=sbuf, coef2=presum[i + 1][0])
+        else:
+            be.stage_combine(out, y0d, [ks[j] for j in idx], coef, _hip.COMBINE_RK, dt_host=float(dt),
+                             out2=ebuf if (last and fuse_err) else None, coef2=err2_coef if (last and fuse_err) else None)
         want = y0 + O._sum_last(k[..., : i + 1] * (so.tableau.beta[i] * dt)).reshape(y0.shape)
         assert np.array_equal(out.cpu().numpy(), want), (name, "stage", i)
         y_last = out
@@ -174,7 +182,7 @@ def test_error_norm_kinds_vs_oracle(dev, dtype, kind, fused, direction):
         zip(np.cumsum([0] + lens[:-1]), lens)]
 
     S = k.shape[-1] - 1
-    n_stage, stage_plan, fsal, sol_plan, err_plan, mid_plan, fuse_err, err2_coef, _ = _build_plans(Dopri5.tableau, Dopri5.mid)
+    n_stage, stage_plan, fsal, sol_plan, err_plan, mid_plan, fuse_err, err2_coef, _, _presum = _build_plans(Dopri5.tableau, Dopri5.mid)
 
     def pad(compact_arr):  # the oracle's compact vector laid out with the device's pads
         out = np.zeros(total, dtype=dtype)

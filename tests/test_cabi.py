@@ -97,6 +97,7 @@ def test_every_entry_point_rejects_null_arguments():
     n = C.c_int(0)
     calls = {
         "xde_stage_combine": lambda: lib.xde_stage_combine(None, None, None, None, None, None, 1, 0, 1.0, 0.0, None, 8, 0, None, None, 0.0, 0, None),
+        "xde_stage_combine_pre": lambda: lib.xde_stage_combine_pre(None, None, None, None, None, None, 1, 0.0, None, 8, 0, 0, None),
         "xde_error_norm_partial": lambda: lib.xde_error_norm_partial(None, None, None, 1, None, None, None, 1e-3, 1e-6, 0.0, None, C.byref(S), 0, 0,
                                                                     None, None, None),
         "xde_error_norm_control": lambda: lib.xde_error_norm_control(None, None, None, 1, None, None, None, C.byref(S), 0, None, None, None,
