@@ -876,7 +876,7 @@ def main():
     global _REAL_STDOUT
     _REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
-    args.tunable_op = enable_tunable_op(not args.no_tunable_op)
+    args.tunable_op = not args.no_tunable_op  # (switched on below, after the transport probe: nothing may open the GPU before it)
 
     c4_label = None
     if args.workload in ("c4-shard", "c4-n1"):
@@ -886,6 +886,8 @@ def main():
         c4_label = ("BASELINE.json configs[3], one rank's shard at N=8 on one GPU" if args.workload == "c4-shard"
                     else "BASELINE.json configs[3], the whole problem on one GPU (N=1 point of the strong-scaling curve)")
         args.workload = "c2"
+    if args.workload != "c2":
+        args.tunable_op = enable_tunable_op(args.tunable_op)  # (single-process workloads: no probe to wait for)
     if args.workload == "rk4":
         return rk4_workload(args)
     if args.workload == "dense":
@@ -939,6 +941,9 @@ def main():
             if args.exchange == "p2p" and not p2p_probe["ok"]:
                 raise SystemExit("--exchange p2p, but the peer-to-peer probe failed: {}".format(p2p_probe["why"]))
         wd.stage("device + nccl group", 300)
+    # (from here on this process uses its GPU; the probe's children have come and gone — on a one-GPU rehearsal box that keeps the
+    #  number of processes holding the card at the number of ranks)
+    args.tunable_op = enable_tunable_op(args.tunable_op)
     torch.cuda.set_device(local_rank)
     if sharded and not rehearsal:
         try:

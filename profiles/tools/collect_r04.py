@@ -44,7 +44,7 @@ def xde_rows(stats_csv):
 def main():
     from paddlexde_amd.csrc.build import kernel_stamp
 
-    names = ["bench_default", "dense", "dde", "self_launch_n2", "self_launch_n3", "host_floor", "host_floor_graph", "host_floor_dist_p2p_graph",
+    names = ["bench_default", "dense", "dde", "self_launch_n2", "self_launch_n3", "self_launch_n4", "host_floor", "host_floor_graph", "host_floor_dist_p2p_graph",
              "c5_graph", "c5_auto", "c3_auto", "c1", "rk4", "bench_f64"]
     names += ["force_dist_c4shard_" + x for x in ("p2p", "rccl", "allreduce")] + ["host_floor_dist_" + x for x in ("p2p", "rccl", "allreduce")]
     for n in names:
