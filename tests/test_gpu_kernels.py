@@ -679,3 +679,56 @@ def P_skew(n):
     from . import problems as P
 
     return P.skew_matrix(n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n", [0, 1, 3, 257, 4096 + 5, 1 << 20])
+@pytest.mark.parametrize("nk_new", [1, 2, 4])
+def test_pre_summed_stage_equals_the_full_stage_bit_for_bit(be, dbl, dtype, n, nk_new):
+    """xde_stage_combine_pre: a stage whose earlier operands were summed by the previous stage's launch.  The emitting launch's second
+    output + the pre-summed launch must give EXACTLY what one full launch over all operands gives (same left-to-right association),
+    and each of the two must equal its numpy contract; with the device `dt`, with the speculative pipeline's select of y0, and on
+    unaligned views (scalar path)."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    n_old = 4
+    y0 = _rand(n, dt, 1, dev)
+    ks = [_rand(n, dt, 10 + j, dev) for j in range(n_old + nk_new)]
+    beta_next = list(np.linspace(-0.9, 1.7, n_old + nk_new))  # the NEXT stage's row
+    beta_this = list(np.linspace(0.4, -1.1, n_old))
+    h = 0.0371
+    # stage i-1: its own output, and the next stage's partial sum over the operands it holds
+    y_prev, part = torch.empty_like(y0), torch.empty_like(y0)
+    be.stage_combine(y_prev, y0, ks[:n_old], beta_this, _hip.COMBINE_RK, dt_host=h, out2=part, coef2=beta_next[:n_old])
+    out = torch.empty_like(y0)
+    be.stage_combine_pre(out, y0, part, ks[n_old:], beta_next[n_old:], dt_host=h)
+    full = torch.empty_like(y0)
+    be.stage_combine(full, y0, ks, beta_next, _hip.COMBINE_RK, dt_host=h)
+    assert torch.equal(out, full)
+    ref = torch.empty(n, dtype=dt)
+    dbl.stage_combine_pre(ref, y0.cpu(), part.cpu(), [k.cpu() for k in ks[n_old:]], beta_next[n_old:], dt_host=h)
+    assert torch.equal(out.cpu(), ref)
+    if n < 16:
+        return
+    # device dt + select of y0 (lag pipeline), and a misaligned partial sum / output (scalar path)
+    big = _rand(3 * (n + 8), dt, 7, dev)
+    part_u = big[1 : 1 + n]
+    part_u.copy_(part)
+    out_u = big[n + 9 : 2 * n + 9]
+    y0b = _rand(n, dt, 5, dev)
+    ctrl_h = _hip.XdeCtrl()
+    ctrl_h.dt = float(np.float32(0.0123))
+    for accept in (0, 1):
+        ctrl_h.accept = accept
+        ctrl = torch.frombuffer(bytearray(bytes(ctrl_h)), dtype=torch.uint8).to(dev)
+        be.stage_combine_pre(out_u, y0, part_u, ks[n_old:], beta_next[n_old:], ctrl=ctrl, y0_alt=y0b, nt_mask=1)
+        cc = torch.frombuffer(bytearray(bytes(ctrl_h)), dtype=torch.uint8)
+        dbl.stage_combine_pre(ref, y0.cpu(), part_u.cpu(), [k.cpu() for k in ks[n_old:]], beta_next[n_old:], ctrl=cc, y0_alt=y0b.cpu())
+        assert torch.equal(out_u.cpu(), ref)
+    # bad arguments are refused before any launch
+    lib = be.lib
+    assert lib.xde_stage_combine_pre(out.data_ptr(), y0.data_ptr(), None, None, None, None, 1, h, None, n, 0, 0, None) == _hip.XDE_EBADARG
+    five = (C.c_void_p * 5)(*[k.data_ptr() for k in ks[:5]])
+    cf = (C.c_double * 5)(*([1.0] * 5))
+    assert lib.xde_stage_combine_pre(out.data_ptr(), y0.data_ptr(), None, part.data_ptr(), five, cf, 5, h, None, n, 0, 0, None) == _hip.XDE_EBADARG
