@@ -946,13 +946,29 @@ def main():
     args.tunable_op = enable_tunable_op(args.tunable_op)
     torch.cuda.set_device(local_rank)
     if sharded and not rehearsal:
+        # the nccl (= RCCL) group of the same ranks: the transport of the fall-backs and of the A/B runs.  An ERROR while forming or
+        # checking it is agreed on and survived (the job then has the peer-to-peer transport, or the host-staged all-reduce, only);
+        # a rank that hangs in here ends in the watchdog.
+        from paddlexde_amd.utils import exchange as X0
+
+        err = None
         try:
-            nccl_pg = dist.new_group(backend="nccl", device_id=device)
-        except TypeError:  # (an older signature)
-            nccl_pg = dist.new_group(backend="nccl")
-        probe = torch.ones(1, device=device)
-        dist.all_reduce(probe, group=nccl_pg)  # the RCCL communicator exists and works before anything is timed
-        rccl_ranks = dist.get_world_size(nccl_pg) if float(probe.item()) == world else 0
+            try:
+                nccl_pg = dist.new_group(backend="nccl", device_id=device)
+            except TypeError:  # (an older signature)
+                nccl_pg = dist.new_group(backend="nccl")
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe, group=nccl_pg)  # the RCCL communicator exists and works before anything is timed
+            if float(probe.item()) != world:
+                err = "the nccl group's first all-reduce returned {} for {} ranks".format(float(probe.item()), world)
+        except Exception as e:  # noqa: BLE001
+            err = "{}: {}".format(type(e).__name__, e)
+        if X0.agree(err is None):
+            rccl_ranks = dist.get_world_size(nccl_pg)
+        else:
+            print("bench.py[rank {}]: no usable nccl group ({}); continuing without one".format(rank, err or "failed on another rank"),
+                  file=sys.stderr)
+            nccl_pg = None
 
     import paddlexde_amd
     from paddlexde_amd import _hip
@@ -991,7 +1007,7 @@ def main():
     if sharded:
         wd.stage("norm-exchange negotiation", 300)
         if args.exchange == "auto":
-            prefer = (["p2p"] if (p2p_probe and p2p_probe["ok"]) else []) + ([] if rehearsal else ["rccl"]) + ["allreduce"]
+            prefer = (["p2p"] if (p2p_probe and p2p_probe["ok"]) else []) + ([] if (rehearsal or nccl_pg is None) else ["rccl"]) + ["allreduce"]
         else:
             prefer = [args.exchange]
         exchange, exchange_kind, exchange_report = X.negotiate(None, device, prefer=tuple(prefer), log=(
@@ -1155,7 +1171,7 @@ def main():
         wd.stage("extra: the other norm-exchange transports", 420, on_expire=emit_main_line)
         ab = {exchange_kind: {"ms_per_step": ms_per_step, "steps": args.steps, "headline": True}}
         others = [k for k in ("p2p", "rccl", "allreduce") if k != exchange_kind and not (k == "p2p" and not (p2p_probe and p2p_probe["ok"]))
-                  and not (k == "rccl" and rehearsal)]
+                  and not (k == "rccl" and (rehearsal or nccl_pg is None))]
         for kind in others:
             try:
                 ex2, k2, _ = X.negotiate(None, device, prefer=(kind,))
