@@ -1794,3 +1794,38 @@ def P_rms():
     from paddlexde_amd.utils import _rms_norm
 
     return _rms_norm
+
+
+def test_lag_pipeline_does_not_speculate_past_the_end_of_a_solve(dev):
+    """The speculative pipeline enqueues attempt n+1 before it knows attempt n's verdict — except at the end: the predecessor's block
+    says where attempt n lands if accepted (`t_plan`), and when that is the last output time the host waits for the verdict first.
+    So a solve of several attempts calls func exactly as often under "lag" as under "sync" (no discarded attempt), with the same
+    rows bit for bit; only a solve that ends within its first attempts, whose step size the host never saw, pays for one."""
+    from paddlexde_amd.xde import BaseODE
+
+    A = P.skew_matrix(8).double().to(dev)
+    y0 = torch.randn(32, 8, generator=torch.Generator().manual_seed(3), dtype=torch.float64).to(dev)
+    calls = [0]
+
+    def f(t_, y):
+        calls[0] += 1
+        return y @ A.T
+
+    for t in (torch.linspace(0.0, 2.0, 5, dtype=torch.float64), torch.tensor([0.0, 3.0], dtype=torch.float64), torch.tensor([1.0, -1.5], dtype=torch.float64)):
+        got = {}
+        for pipeline in ("sync", "lag"):
+            calls[0] = 0
+            s = Dopri5(xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-8, atol=1e-10, norm=_rms_norm, dtype=torch.float64, pipeline=pipeline)
+            with torch.no_grad():
+                sol = s.integrate(t)
+            got[pipeline] = (sol.clone(), calls[0], s.stats["nfe"], s.stats["n_steps"])
+        assert got["sync"][3] >= 3  # (several attempts: the end is predictable)
+        assert torch.equal(got["sync"][0], got["lag"][0])
+        assert got["lag"][1] == got["sync"][1] == got["sync"][2] == got["lag"][2], got  # calls == nfe, identical under both pipelines
+    # a one-attempt solve: its only attempt's step size was chosen on the device, the host could not see the end coming
+    t = torch.tensor([0.0, 1e-6], dtype=torch.float64)
+    calls[0] = 0
+    s = Dopri5(xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-8, atol=1e-10, norm=_rms_norm, dtype=torch.float64, pipeline="lag")
+    with torch.no_grad():
+        s.integrate(t)
+    assert s.stats["n_steps"] == 1 and calls[0] == s.stats["nfe"] + 6  # one speculative attempt ran for nothing, and is not counted
