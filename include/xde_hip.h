@@ -319,6 +319,9 @@ int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde
  *            that norm), and the control block's construction exactly as xde_ctrl_init(first_step_dev = hs_dev + 3) does it.
  *   rtol / atol / norm kind / segment counts come from params; segs as in xde_scaled_norm_partial; hs_dev: 5 doubles.
  *   States above 2^20 elements are refused (one workgroup): use the separate calls.
+ *   Re-armable use (a launch recorded in a hipGraph and replayed for one output interval after another): t_start = NaN reads the
+ *   start time from t_span_dev[0] (then required in phase 0 too), and seq0 < 0 keeps the block's own controller-launch count
+ *   (ctrl->seq, what the host mirror's slots are numbered with) instead of resetting it; xde_ctrl_init takes seq0 < 0 the same way.
  */
 int xde_initial_step_fused(int phase, const void* a, const void* b, const void* y0, const xde_segments_t* segs, int dtype, double* hs_dev,
                            const xde_ctrl_params_t* params, double t_start, void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl,

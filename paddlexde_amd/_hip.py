@@ -535,12 +535,13 @@ class HipBackend:
         self._check(rc, "xde_initial_step")
 
     def initial_step_fused(self, phase, a, b, y0, segs, hs, params, t_start, t_probe, ctrl, n_out=0, t_span_dev=None, step_t_dev=None,
-                           t_stage=None):
+                           t_stage=None, keep_seq=False):
         """The initial-step heuristic of a small state, one workgroup per phase (phase 1 also constructs the control block, like
-        ctrl_init with the device-resident first step)."""
+        ctrl_init with the device-resident first step).  ``t_start = nan``: the start time is ``t_span_dev[0]``; ``keep_seq``: the
+        block goes on counting its controller launches (a launch recorded in a graph and replayed per output interval)."""
         self._require_device(a, b, y0, hs, ctrl, t_probe, t_span_dev, t_stage)
-        m = self._mirrors.get(ctrl.data_ptr()) if phase == 1 else None
-        seq0 = m.seq if m is not None else 0
+        m = self._mirrors.get(ctrl.data_ptr()) if (phase == 1 and not keep_seq) else None
+        seq0 = -1 if keep_seq else (m.seq if m is not None else 0)
         rc = self.lib.xde_initial_step_fused(int(phase), a.data_ptr(), _ptr(b), y0.data_ptr(), C.byref(segs), dtype_code(y0.dtype), hs.data_ptr(),
                                              C.byref(params), float(t_start), _ptr(t_probe),
                                              dtype_code(t_probe.dtype) if t_probe is not None else XDE_F32, ctrl.data_ptr(), int(n_out),

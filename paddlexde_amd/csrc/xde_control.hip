@@ -137,6 +137,8 @@ __global__ __launch_bounds__(kSingleBlock) void xde_errnorm_control_single_kerne
 __device__ __forceinline__ void ctrl_init_body(xde_ctrl_t* c, const xde_ctrl_params_t& p, double t_start, double first_step_signed,
                                                int32_t n_out, const double* t_span, const double* step_t, void* t_stage_out,
                                                int64_t seq0, xde_ctrl_t& z) {
+  // seq0 < 0: a block that is re-armed in place (a captured interval solve) keeps counting its controller launches where it was
+  const int64_t seq_start = seq0 < 0 ? c->seq : seq0;
   for (int i = 0; i < int(sizeof(xde_ctrl_t) / 8); ++i) reinterpret_cast<uint64_t*>(&z)[i] = 0;
   z.t0 = t_start;
   z.t1 = t_start;
@@ -160,7 +162,7 @@ __device__ __forceinline__ void ctrl_init_body(xde_ctrl_t* c, const xde_ctrl_par
     if (idx > p.n_step_t - 1) idx = p.n_step_t - 1;
   }
   z.next_step_index = idx;
-  z.seq = seq0;
+  z.seq = seq_start;
   if (p.time_dtype == XDE_F32)
     plan_next<float>(&z, p, step_t, t_stage_out);
   else
@@ -356,13 +358,15 @@ __global__ __launch_bounds__(kSingleBlock) void xde_initial_step_single_kernel(I
   double res[2];
   res[0] = norm_from_sums(seg_val[0], p.seg_count, p.n_seg, NORM, p.state_dtype, nullptr);
   res[1] = diff ? 0.0 : norm_from_sums(seg_val[1], p.seg_count, p.n_seg, NORM, p.state_dtype, nullptr);
+  // t_start = NaN: the start time is t_span_dev[0] (a launch recorded in a graph serves every interval it is replayed for)
+  const double t_start = (g.t_start != g.t_start && g.t_span) ? g.t_span[0] : g.t_start;
   if (p.state_dtype == XDE_F32)
-    initial_step_phase<float>(g.phase, res, g.hs, p, g.t_start, g.t_probe_out, g.probe_dtype, c);
+    initial_step_phase<float>(g.phase, res, g.hs, p, t_start, g.t_probe_out, g.probe_dtype, c);
   else
-    initial_step_phase<double>(g.phase, res, g.hs, p, g.t_start, g.t_probe_out, g.probe_dtype, c);
+    initial_step_phase<double>(g.phase, res, g.hs, p, t_start, g.t_probe_out, g.probe_dtype, c);
   if (diff) {
     g.hs[4] = res[0];  // (the third norm, for the parity tests)
-    ctrl_init_body(c, p, g.t_start, double(p.direction) * fabs(g.hs[3]), g.n_out, g.t_span, g.step_t, g.t_stage_out, g.seq0, z);
+    ctrl_init_body(c, p, t_start, double(p.direction) * fabs(g.hs[3]), g.n_out, g.t_span, g.step_t, g.t_stage_out, g.seq0, z);
   }
 }
 
@@ -515,6 +519,7 @@ int xde_initial_step_fused(int phase, const void* a, const void* b, const void* 
   if (phase == 0 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step_fused: phase 0 needs t_probe_out");
   if (phase == 1 && (!b || !t_span_dev || !t_stage_out)) return fail(XDE_EBADARG, "xde_initial_step_fused: phase 1 needs b, t_span_dev and t_stage_out");
   if (phase == 1 && n_out < 1) return fail(XDE_EBADARG, "xde_initial_step_fused: n_out must be >= 1");
+  if (t_start != t_start && !t_span_dev) return fail(XDE_EBADARG, "xde_initial_step_fused: t_start = NaN (read it from t_span_dev[0]) needs t_span_dev");
   if (probe_dtype != XDE_F32 && probe_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step_fused: bad probe dtype");
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step_fused: bad dtype");
   int rc = check_params(params, "xde_initial_step_fused");

@@ -17,6 +17,7 @@ How it is organised here (not the reference's layout):
     backward sums the row-summed adjoints over the process group where the step control looks at them.
 Deviations documented in SURVEY.md: D4 (tuple state flattened), D5 (reverse-time intervals run natively with a signed dt), D6 (the
 gradient w.r.t. ``y0`` is returned instead of ``None``)."""
+import os
 import threading
 import warnings
 import collections
@@ -280,7 +281,94 @@ def _graph_time_examples(adjoint_method, adjoint_options, t_span, y0):
     return [torch.zeros((), dtype=d, device=dev) for d in dtypes]
 
 
-def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoint_params):
+# captured interval solves: the whole 2-point solve of one output interval (initial-step heuristic + first attempted step) as one
+# hipGraph on a solver that is kept across intervals and backward passes (solver/base_adaptive_solver_rk.py: intervals_prepare)
+_INTERVAL_OPTION_KEYS = ("norm", "dtype", "safety", "ifactor", "dfactor", "min_step", "max_step", "max_num_steps", "controller",
+                         "pi_beta", "pipeline", "process_group", "reuse_f0")
+MAX_INTERVAL_SOLVERS = 4  # per captured dynamics (tolerances x solver x direction)
+
+
+class _NoIntervals:
+    """Cache entry: the interval solve could not be captured for this key; one ordinary solve per interval."""
+
+
+class _IntervalSolver:
+    def __init__(self, solver):
+        self.solver = solver
+        self.lock = threading.Lock()  # one sweep at a time owns the static buffers (a second, concurrent one solves per interval)
+
+
+def _interval_key(solver, rtol, atol, options, direction):
+    """Cache key of the captured interval solve for these solver options, or None when they rule it out."""
+    if _is_fixed(solver) or not isinstance(solver, type):
+        return None
+    if os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0":
+        return None
+    items = []
+    for k, v in options.items():
+        if k not in _INTERVAL_OPTION_KEYS:
+            return None
+        if k == "norm":
+            v = native_norm_spec(v)
+            if v is None:
+                return None
+        elif k == "process_group":
+            if v is not None:
+                return None
+        elif k == "pipeline":
+            if v not in ("auto", "sync"):  # (the interval solve resolves every attempt before the next: what "sync" asks for)
+                return None
+            continue
+        elif k == "reuse_f0":
+            if not v:
+                return None
+            continue
+        try:
+            hash(v)
+        except TypeError:
+            return None
+        items.append((k, v))
+    return (solver, float(rtol), float(atol), int(direction), tuple(sorted(items, key=lambda kv: kv[0])))
+
+
+def _prepare_intervals(graphed, flat_ex, segs, shapes, t_span, adjoint_solver, rtol, atol, adjoint_options):
+    """Build (once per key) the re-armable solver the backward sweep runs its intervals on.  Called where the dynamics is captured:
+    on the main thread, outside the autograd node."""
+    from ..solver._common import direction_of
+    from ..xde.base_ode import BaseODE
+
+    opts = {k: v for k, v in adjoint_options.items() if k not in ("_replay_intervals", "interval_graph")}
+    if adjoint_options.get("_replay_intervals") is not None or adjoint_options.get("interval_graph", True) is False:
+        return
+    if len(t_span) < 2 or _interval_key(adjoint_solver, rtol, atol, opts, 1) is None:
+        return
+    t_host = t_span.detach().to("cpu")
+    span = (t_host[-1].item(), t_host[-2].item())  # the sweep's first interval
+    if span[0] == span[1]:
+        return
+    key = _interval_key(adjoint_solver, rtol, atol, opts, direction_of(span))
+    cache = graphed.__dict__.setdefault("_intervals", {})
+    if key in cache:
+        return
+    try:
+        opts.pop("reuse_f0", None)
+        opts.pop("pipeline", None)
+        t_ex = torch.tensor(span, dtype=t_host.dtype)
+        s = adjoint_solver(xde=BaseODE(graphed.func, y0=flat_ex, t_span=t_ex), y0=flat_ex, rtol=rtol, atol=atol, reuse_f0=True,
+                           _xde_segments=segs, _xde_segment_shapes=shapes, **opts)
+        if not (hasattr(s, "intervals_supported") and s.intervals_supported()):
+            cache[key] = _NoIntervals()
+            return
+        s.intervals_prepare(span)
+        entry = _IntervalSolver(s)
+    except Exception:
+        entry = _NoIntervals()  # this solve cannot be captured: per-interval solves, and no second attempt for this key
+    while len(cache) >= MAX_INTERVAL_SOLVERS:
+        cache.pop(next(iter(cache)))
+    cache[key] = entry
+
+
+def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoint_params, rtol=None, atol=None):
     """Resolve ``adjoint_options["graph_func"]`` and return the captured FLAT augmented dynamics, or None for the eager one.
 
     The augmented dynamics (func forward + autograd vjp, ~30 eager launches) is captured into one HIP graph per time-argument
@@ -347,7 +435,12 @@ def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoin
         # for this module and signature
         cache[key] = _NoGraph()
         return None
-    return None if graphed.refused else graphed
+    if graphed.refused:
+        return None
+    if rtol is not None and not time_grad:
+        _prepare_intervals(graphed, flat_ex, segs, [tuple(x.shape) for x in example], t_span, adjoint_solver, rtol, atol,
+                           adjoint_options)
+    return graphed
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -405,6 +498,39 @@ def _check_sharded_backward(plan, pg, norm_spec, reduce_params):
             "gradients (the captured dynamics cannot hold the per-evaluation all-reduce)")
 
 
+def _interval_solver_for(plan, solve_options, t_host):
+    """The captured interval solve prepared for this sweep's options (its lock taken), or None."""
+    from ..solver._common import direction_of
+
+    if plan.graphed is None or plan.time_grad or plan.replay_intervals is not None:
+        return None
+    cache = getattr(plan.graphed, "_intervals", None)
+    if not cache:
+        return None
+    opts = {k: v for k, v in solve_options.items() if k != "_xde_flat_func"}
+    key = _interval_key(plan.solver, plan.rtol, plan.atol, opts, direction_of((t_host[-1].item(), t_host[-2].item())))
+    iv = cache.get(key) if key is not None else None
+    if not isinstance(iv, _IntervalSolver) or not iv.lock.acquire(blocking=False):
+        return None
+    return iv
+
+
+def _sweep_captured(solver, state, t_host, y_ans, grad_y, plan):
+    """`_sweep`'s loop on the re-armable solver: the augmented state lives in the solver's static buffer for the whole sweep; per
+    interval two output times go up, one graph (seldom two) is replayed, and the row comes back into the state."""
+    n_times = len(t_host)
+    flat = solver.interval_state
+    flat.copy_(state.flat)
+    state.flat = flat
+    times = t_host.tolist()
+    for i in range(n_times - 1, 0, -1):
+        row = solver.interval_solve((times[i], times[i - 1]))
+        flat.copy_(row)
+        state.restart_interval(y_ans[i - 1], grad_y[i - 1])
+    parts = [p.clone() for p in state.views()]  # (the static buffer serves the next sweep)
+    return parts[2].reshape(plan.y0_shape), None, list(parts[_N_LEADING:])
+
+
 def _sweep(plan, t_span, y_ans, grad_y, adjoint_params):
     """Integrate the augmented system from the last output time back to the first; returns ``(adj_y0, grad_t_span | None,
     [adj_theta ...])``."""
@@ -434,6 +560,12 @@ def _sweep(plan, t_span, y_ans, grad_y, adjoint_params):
 
     grad_t = torch.empty(n_times, dtype=t_span.dtype, device=t_span.device) if plan.time_grad else None
     t_host = t_span.detach().to("cpu")  # one device->host read of the output times for all intervals
+    iv = _interval_solver_for(plan, solve_options, t_host) if (pg is None and n_times > 1) else None
+    if iv is not None:
+        try:
+            return _sweep_captured(iv.solver, state, t_host, y_ans, grad_y, plan)
+        finally:
+            iv.lock.release()
     for i in range(n_times - 1, 0, -1):
         if plan.time_grad:
             # moving the output time t_i moves the loss by f(t_i, y_i) . dL/dy_i (:137-141)
@@ -523,7 +655,8 @@ def odeint_adjoint(
     if not torch.is_tensor(t_span):
         t_span = torch.as_tensor(t_span)
 
-    graphed = _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, wanted)
+    graphed = _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, wanted, adjoint_rtol, adjoint_atol)
+    adjoint_options.pop("interval_graph", None)
     plan = _BackwardPlan(
         func=func, solver=adjoint_solver, rtol=adjoint_rtol, atol=adjoint_atol,
         options={k: v for k, v in adjoint_options.items() if k != "_replay_intervals"},

@@ -433,6 +433,31 @@ class AdaptiveRKSolver(AdaptiveSolver):
     # base_adaptive_solver_rk.py:81-114
     # ------------------------------------------------------------------------------------------
     def _before_integrate(self, t_span):
+        t_span = self._setup(t_span)
+        be, p, d, y0 = self.backend, self._params, self._direction, self.y0
+
+        # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
+        f0 = self._eval(self._scalar_t(t_span[0], self.dtype), y0)
+        first_dev = None
+        self._ctrl_ready = False
+        if self.first_step is None:
+            # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
+            f0_again = f0 if self._reuse_f0 else None
+            if f0_again is not None:
+                self._nfe_skipped += 1  # (the call the reference makes here and this solve does not)
+            if self._custom_norm or not self._device_first_step:
+                first_step = self.select_initial_step(t_span[0], y0, self.order - 1, self.rtol, self.atol, f0=f0_again)
+            else:
+                first_step, first_dev = None, self._select_initial_step_device(t_span[0], y0, f0=f0_again)
+        else:
+            first_step = self.first_step
+        self.rk_state = _RungeKuttaState(y0, f0, t_span[0], t_span[0], first_step, None)
+        if not self._ctrl_ready:  # (the fused initial step has constructed the control block already)
+            be.ctrl_init(self._ctrl, p, float(t_span[0]), 0.0 if first_step is None else float(d * abs(first_step)), len(t_span),
+                         self._t_span_dev, self._step_t_dev, self._t_stage, first_step_dev=first_dev)
+
+    def _setup(self, t_span):
+        """Buffers, output times and controller parameters of a solve over ``t_span`` (everything before the first evaluation)."""
         be = self.backend
         tt = np_dtype(self.dtype)
         if not isinstance(t_span, np.ndarray) or t_span.dtype != tt:  # direct callers (the step() API) pass tensors
@@ -497,26 +522,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self._replay_dev = upload(tab, dev)  # kept alive by the solver: params hold its raw pointer
             p.replay, p.n_replay = self._replay_dev.data_ptr(), len(self._replay)
         self._params = p
-
-        # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
-        f0 = self._eval(self._scalar_t(t_span[0], self.dtype), y0)
-        first_dev = None
-        self._ctrl_ready = False
-        if self.first_step is None:
-            # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
-            f0_again = f0 if self._reuse_f0 else None
-            if f0_again is not None:
-                self._nfe_skipped += 1  # (the call the reference makes here and this solve does not)
-            if self._custom_norm or not self._device_first_step:
-                first_step = self.select_initial_step(t_span[0], y0, self.order - 1, self.rtol, self.atol, f0=f0_again)
-            else:
-                first_step, first_dev = None, self._select_initial_step_device(t_span[0], y0, f0=f0_again)
-        else:
-            first_step = self.first_step
-        self.rk_state = _RungeKuttaState(y0, f0, t_span[0], t_span[0], first_step, None)
-        if not self._ctrl_ready:  # (the fused initial step has constructed the control block already)
-            be.ctrl_init(self._ctrl, p, float(t_span[0]), 0.0 if first_step is None else float(d * abs(first_step)), len(t_span),
-                         self._t_span_dev, self._step_t_dev, self._t_stage, first_step_dev=first_dev)
+        return t_span
 
     def _after_integrate(self):
         w, self._work = getattr(self, "_work", None), None
@@ -978,6 +984,117 @@ class AdaptiveRKSolver(AdaptiveSolver):
             c = self._resolve_pending()
         self._last = c
         return c
+
+    # ------------------------------------------------------------------------------------------
+    # re-armable interval solves: one captured graph = the initial-step heuristic + the first attempted step of a 2-point solve
+    # ------------------------------------------------------------------------------------------
+    # odeint_adjoint's backward pass is one short solve per output interval (functional/odeint_adjoint.py:134-159): same state
+    # layout, same tolerances, same direction, 1-2 attempted steps each — and, for a small state, launch-bound.  Instead of one
+    # solver object, one control block and ~170 launches per interval, ONE solver is kept for the whole sweep (and the next
+    # backward pass): the state lives in a static buffer (`interval_state`), the two output times are uploaded into a static
+    # pair, and a replayed hipGraph re-arms the control block on the device (xde_initial_step_fused with t_start = NaN and
+    # seq0 < 0), runs the heuristic's two evaluations and the first attempt, writes the output row and hands the state over
+    # (xde_dense_commit).  A second graph holds one more attempt for the intervals that need it.  Same kernels, same operands,
+    # same order as the eager solve: bit-identical results (tests/test_gpu_adjoint.py).
+    def intervals_supported(self):
+        """Whether this solver's options allow the captured interval solve (else: one ordinary solve per interval)."""
+        return bool(self.y0.is_cuda and self._fused_first_step() and not self._custom_norm and self.first_step is None
+                    and self.step_t is None and not self._has_callbacks and self._step_hook is None and not self.record_trace
+                    and self._reuse_f0 and self._stats_out is None and self.pipeline == "auto" and self._device_first_step
+                    and self.y0.dim() == 1)
+
+    def intervals_prepare(self, t_span, capture=True):
+        """Static buffers for 2-point solves in the direction of ``t_span`` (two host times), one eager solve of that span from
+        the constructor's ``y0`` as warm-up and — ``capture`` — the two graphs.  Main thread, outside autograd nodes (see
+        utils/graphed.py); raises when the capture fails (the caller keeps the per-interval solves)."""
+        be = self.backend
+        t_span = self._setup(t_span)
+        if len(t_span) != 2 or not t_span[0] != t_span[1]:
+            raise ValueError("intervals_prepare needs two distinct output times")
+        y0, dev = self.y0, self.y0.device
+        self._iv_pinned = torch.empty(2, dtype=torch.float64).pin_memory()  # (self._t_span_dev is static from here on: every
+        # interval's two times are copied into it)
+        self._gbase = (y0.clone(), torch.empty_like(y0))
+        self._iv_y1 = torch.empty_like(y0)
+        self._iv_hs = torch.zeros(5, dtype=torch.float64, device=dev)
+        self._iv_tprobe = torch.empty((), dtype=torch.promote_types(self.dtype, y0.dtype), device=dev)
+        self._iv_t0 = None if self.dtype == torch.float64 else torch.empty((), dtype=self.dtype, device=dev)
+        self._solution = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=dev)
+        self._iv_first_graph = self._iv_next_graph = None
+        self._ctrl_ready = True
+        # (a control block whose launch count the host mirror agrees with, before the in-graph re-arming keeps counting from it)
+        be.ctrl_init(self._ctrl, self._params, float(t_span[0]), 0.0, 2, self._t_span_dev, self._step_t_dev, self._t_stage)
+        with torch.no_grad(), torch.autograd.set_multithreading_enabled(False):
+            nfe0 = self.nfe
+            self.interval_solve(t_span)  # eager: func's lazy initialisations, the allocator's blocks
+            if capture:
+                torch.cuda.synchronize(dev)
+                self._iv_first_graph = be.capture(self._iv_first, self._ctrl, launches=1)
+                self._iv_next_graph = be.capture(self._iv_attempt, self._ctrl, launches=1)
+            self.nfe = nfe0
+        return self
+
+    @property
+    def interval_state(self):
+        """The static state buffer an interval solve starts from (write the state into it, do not replace it)."""
+        return self._gbase[0]
+
+    def _iv_first(self):
+        be = self.backend
+        y0, f0 = self._gbase
+        nan = float("nan")
+        if self._iv_t0 is None:
+            t0 = self._t_span_dev[0]
+        else:
+            t0 = self._iv_t0.copy_(self._t_span_dev[0])  # (the output times are values of the time dtype: an exact conversion)
+        f0.copy_(self._eval(t0, y0))
+        be.initial_step_fused(0, f0, None, y0, self._xsegs, self._iv_hs, self._params, nan, self._iv_tprobe, self._ctrl,
+                              t_span_dev=self._t_span_dev, keep_seq=True)
+        be.stage_combine(self._iv_y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
+        f1 = self._eval(self._iv_tprobe, self._iv_y1)
+        be.initial_step_fused(1, f1, f0, y0, self._xsegs, self._iv_hs, self._params, nan, None, self._ctrl, 2, self._t_span_dev,
+                              self._step_t_dev, self._t_stage, keep_seq=True)
+        self._iv_attempt()
+
+    def _iv_attempt(self):
+        base = self._gbase
+        y1, ks = self._attempt(base)
+        idx, coef = self._mid_plan
+        self.backend.dense_commit(self._solution, [ks[j] for j in idx], coef, base[0], y1, ks[-1], self._ctrl, self._t_span_dev,
+                                  _hip.dtype_code(self.dtype))
+
+    def interval_solve(self, t_span):
+        """Integrate ``interval_state`` from ``t_span[0]`` to ``t_span[1]`` (host times, the prepared direction); returns the
+        state at ``t_span[1]`` — a view of a static row, valid until the next call.  ``interval_state`` is overwritten."""
+        be = self.backend
+        tt = np_dtype(self.dtype)
+        t = np.asarray([t_span[0], t_span[1]], dtype=tt)
+        d = self._direction
+        if not d * t[1] > d * t[0]:
+            if t[1] == t[0]:  # (an output time repeated: the state itself, as integrate() fills such rows)
+                self._solution[1].copy_(self._gbase[0])
+                return self._solution[1]
+            raise AssertionError("interval_solve: the interval runs against the prepared direction")
+        self._iv_pinned.numpy()[:] = t.astype(np.float64)
+        self._t_span_dev.copy_(self._iv_pinned, non_blocking=True)
+        graphs = self._iv_first_graph is not None
+        with torch.no_grad():
+            first = True
+            while True:
+                if graphs:
+                    (handle,) = (self._iv_first_graph if first else self._iv_next_graph).replay()
+                    c = be.ctrl_wait(handle)
+                else:
+                    (self._iv_first if first else self._iv_attempt)()
+                    c = be.ctrl_read(self._ctrl)
+                if graphs:
+                    self.nfe += self._n_stage + (2 if first else 0)
+                first = False
+                self._raise_status(c)
+                if c.done:
+                    break
+        self._last = c
+        return self._solution[1]
 
     # base_adaptive_solver_rk.py:116-127
     def step(self, next_t):

@@ -286,9 +286,12 @@ class NumpyDoubleBackend:
                 h[3] = float(np.float32(first)) if params.time_dtype == _hip.XDE_F32 else float(first)
 
     def initial_step_fused(self, phase, a, b, y0, segs, hs, params, t_start, t_probe, ctrl, n_out=0, t_span_dev=None, step_t_dev=None,
-                           t_stage=None):
+                           t_stage=None, keep_seq=False):
         """Contract of xde_initial_step_fused: the separate calls, composed."""
         import torch
+
+        if t_start != t_start:  # NaN: the start time is the first output time
+            t_start = float(t_span_dev.numpy()[0])
 
         ws, sums = self.new_workspace(None), self.new_sums(None)
         counts = [params.seg_count[i] for i in range(params.n_seg)]
