@@ -1012,13 +1012,17 @@ class AdaptiveRKSolver(AdaptiveSolver):
         if len(t_span) != 2 or not t_span[0] != t_span[1]:
             raise ValueError("intervals_prepare needs two distinct output times")
         y0, dev = self.y0, self.y0.device
-        self._iv_pinned = torch.empty(2, dtype=torch.float64).pin_memory()  # (self._t_span_dev is static from here on: every
-        # interval's two times are copied into it)
-        self._gbase = (y0.clone(), torch.empty_like(y0))
+        # the interval's two output times (double, what the kernels read) and its start time in the time dtype (what func is handed):
+        # 32 static bytes on the device, written by ONE host-to-device copy per interval from a pinned mirror
+        self._iv_pinned = torch.zeros(32, dtype=torch.uint8).pin_memory()
+        self._iv_times = torch.zeros(32, dtype=torch.uint8, device=dev)
+        self._t_span_dev = self._iv_times[:16].view(torch.float64)
+        self._iv_t0 = self._iv_times[16:24].view(self.dtype)[0]
+        self._iv_upload(t_span)
+        self._gbase = (y0.clone(), None)
         self._iv_y1 = torch.empty_like(y0)
         self._iv_hs = torch.zeros(5, dtype=torch.float64, device=dev)
         self._iv_tprobe = torch.empty((), dtype=torch.promote_types(self.dtype, y0.dtype), device=dev)
-        self._iv_t0 = None if self.dtype == torch.float64 else torch.empty((), dtype=self.dtype, device=dev)
         self._solution = torch.empty((2,) + tuple(y0.shape), dtype=y0.dtype, device=dev)
         self._iv_first_graph = self._iv_next_graph = None
         self._ctrl_ready = True
@@ -1034,6 +1038,12 @@ class AdaptiveRKSolver(AdaptiveSolver):
             self.nfe = nfe0
         return self
 
+    def _iv_upload(self, t):
+        host = self._iv_pinned.numpy()
+        host[:16].view(np.float64)[:] = np.asarray(t, dtype=np.float64)
+        host[16:24].view(np_dtype(self.dtype))[0] = t[0]
+        self._iv_times.copy_(self._iv_pinned, non_blocking=True)
+
     @property
     def interval_state(self):
         """The static state buffer an interval solve starts from (write the state into it, do not replace it)."""
@@ -1041,13 +1051,12 @@ class AdaptiveRKSolver(AdaptiveSolver):
 
     def _iv_first(self):
         be = self.backend
-        y0, f0 = self._gbase
+        y0 = self._gbase[0]
         nan = float("nan")
-        if self._iv_t0 is None:
-            t0 = self._t_span_dev[0]
-        else:
-            t0 = self._iv_t0.copy_(self._t_span_dev[0])  # (the output times are values of the time dtype: an exact conversion)
-        f0.copy_(self._eval(t0, y0))
+        # (f0 stays where func wrote it — recorded: a block of this graph's private pool, kept allocated by this reference, which the
+        # second graph addresses too)
+        f0 = self._eval(self._iv_t0, y0)
+        self._gbase = (y0, f0)
         be.initial_step_fused(0, f0, None, y0, self._xsegs, self._iv_hs, self._params, nan, self._iv_tprobe, self._ctrl,
                               t_span_dev=self._t_span_dev, keep_seq=True)
         be.stage_combine(self._iv_y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
@@ -1075,8 +1084,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
                 self._solution[1].copy_(self._gbase[0])
                 return self._solution[1]
             raise AssertionError("interval_solve: the interval runs against the prepared direction")
-        self._iv_pinned.numpy()[:] = t.astype(np.float64)
-        self._t_span_dev.copy_(self._iv_pinned, non_blocking=True)
+        self._iv_upload(t)
         graphs = self._iv_first_graph is not None
         with torch.no_grad():
             first = True
