@@ -13,8 +13,10 @@ How it is organised here (not the reference's layout):
     the reference rebuilds a tuple per interval, here the reset and the jump are two in-place copies into the flat buffer;
   * the adjoint norm is an object (``SegmentMaxNorm``) that states what it is — "max over the first n segments of the per-segment
     state norm" — so that the solver maps it onto ONE segmented reduction kernel without inspecting closures;
-  * the augmented dynamics can be replayed from a captured HIP graph (``adjoint_options["graph_func"]``), and a batch-sharded
-    backward sums the row-summed adjoints over the process group where the step control looks at them.
+  * the augmented dynamics can be replayed from a captured HIP graph (``adjoint_options["graph_func"]``) — and with it the sweep's
+    2-point solves themselves: ONE re-armable solver serves every interval (and the next backward pass), the initial-step heuristic
+    and the first attempted step of an interval are one graph replay (``_sweep_captured``; ``adjoint_options["interval_graph"]``);
+  * a batch-sharded backward sums the row-summed adjoints over the process group where the step control looks at them.
 Deviations documented in SURVEY.md: D4 (tuple state flattened), D5 (reverse-time intervals run natively with a signed dt), D6 (the
 gradient w.r.t. ``y0`` is returned instead of ``None``)."""
 import os
