@@ -394,6 +394,59 @@ def test_initial_step_scalars(be, dbl, dtype, tdtype):
                 assert np.sign(fg) == direction
 
 
+@pytest.mark.parametrize("norm", ["rms", "linf"])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_initial_step_fused_over_many_segments(be, dbl, dtype, norm):
+    """xde_initial_step_fused on tuple states: up to 16 segments of every size class (one element, shorter than a vector, with and
+    without a scalar tail, thousands of elements; segment starts 16-byte aligned as the tuple layout makes them, and unaligned), whose
+    16-byte units the one workgroup's waves share out among themselves.  d0, d1, the third norm and the first step against the
+    separate launches' contract (the CPU double composes them), NaN propagation included."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    w = 4 if dtype == "f32" else 2
+    rng = np.random.RandomState(11)
+    layouts = [[1, 16384, 16384, 100, 50, 100, 2], [3], [1, 1, 1], [5, 7, 9, 4099, 2, 1, 64, 63, 65, 1024, 3, 8191, 6, 2, 1, 40000],
+               [65536], [17, 2049]]
+    for li, lens in enumerate(layouts):
+        for aligned in (True, False):
+            segs, pos = [], 0
+            for n in lens:
+                segs.append((pos, n))
+                pos += ((n + w - 1) // w * w) if aligned else n
+            total = pos
+            y0 = torch.from_numpy(rng.uniform(-2, 2, total)).to(dt)
+            f0 = torch.from_numpy(rng.uniform(-3, 3, total)).to(dt)
+            f1 = f0 + torch.from_numpy(rng.uniform(-1e-3, 1e-3, total)).to(dt)
+            if li == 3 and aligned:
+                f0[segs[4][0]] = float("nan")  # one poisoned element in a 2-element segment
+            p = _hip.XdeCtrlParams()
+            p.rtol, p.atol, p.min_step, p.max_step = 1e-3, 1e-5, 0.0, float("inf")
+            p.safety, p.ifactor, p.dfactor, p.order = 0.9, 10.0, 0.2, 5.0
+            p.max_num_steps = 2**31 - 1
+            p.time_dtype = p.state_dtype = _hip.dtype_code(dt)
+            p.norm_kind = _hip.NORM_RMS if norm == "rms" else _hip.NORM_LINF
+            p.n_stage, p.n_seg, p.direction = 6, len(segs), 1
+            for i, (_, n) in enumerate(segs):
+                p.seg_count[i] = float(n)
+            xs = _hip.make_segments(segs)
+            t_span = torch.tensor([0.25, 1.0], dtype=torch.float64)
+            out = []
+            for backend, device in ((be, dev), (dbl, torch.device("cpu"))):
+                ctrl = backend.new_ctrl(device)
+                ts = torch.zeros(_hip.XDE_MAX_STAGE, dtype=dt, device=device)
+                hs = torch.zeros(5, dtype=torch.float64, device=device)
+                t_probe = torch.zeros((), dtype=dt, device=device)
+                a, b, y = f0.to(device), f1.to(device), y0.to(device)
+                backend.initial_step_fused(0, a, None, y, xs, hs, p, 0.25, t_probe, ctrl)
+                backend.initial_step_fused(1, b, a, y, xs, hs, p, 0.25, None, ctrl, 2, t_span.to(device), None, ts)
+                out.append((hs.cpu().numpy().copy(), backend.ctrl_read(ctrl).dt))
+            (hg, fg), (hr, fr) = out
+            tol = 1e-5 if dtype == "f32" else 1e-12
+            np.testing.assert_allclose(hg[[0, 1, 4]], hr[[0, 1, 4]], rtol=tol, atol=0, equal_nan=True, err_msg=str((li, aligned)))
+            np.testing.assert_allclose(hg[3], hr[3], rtol=10 * tol, atol=0, equal_nan=True, err_msg=str((li, aligned)))
+            np.testing.assert_allclose(fg, fr, rtol=10 * tol, atol=0, equal_nan=True)
+
+
 def test_stage_combine_and_error_norm_beyond_2_31_elements(be):
     """Maximum sizes: N = 2^31 + 5 fp32 elements (8 GiB per operand) — 64-bit indexing in the combine and in the norm
     partials.  Checked against torch on slices at both ends and around the 2^31 boundary, and through the norm of a
