@@ -287,6 +287,7 @@ def _graph_time_examples(adjoint_method, adjoint_options, t_span, y0):
 # hipGraph on a solver that is kept across intervals and backward passes (solver/base_adaptive_solver_rk.py: intervals_prepare)
 _INTERVAL_OPTION_KEYS = ("norm", "dtype", "safety", "ifactor", "dfactor", "min_step", "max_step", "max_num_steps", "controller",
                          "pi_beta", "pipeline", "process_group", "reuse_f0")
+_FIXED_INTERVAL_OPTION_KEYS = ("norm", "interp", "pipeline", "variant", "process_group")  # (a fixed grid: one STEP per interval)
 MAX_INTERVAL_SOLVERS = 4  # per captured dynamics (tolerances x solver x direction)
 
 
@@ -300,17 +301,20 @@ class _IntervalSolver:
         self.lock = threading.Lock()  # one sweep at a time owns the static buffers (a second, concurrent one solves per interval)
 
 
-def _interval_key(solver, rtol, atol, options, direction):
+def _interval_key(solver, rtol, atol, options, direction, t_dtype=None):
     """Cache key of the captured interval solve for these solver options, or None when they rule it out."""
-    if _is_fixed(solver) or not isinstance(solver, type):
+    if not isinstance(solver, type):
         return None
     if os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0":
         return None
+    fixed = _is_fixed(solver)
     items = []
     for k, v in options.items():
-        if k not in _INTERVAL_OPTION_KEYS:
+        if k not in (_FIXED_INTERVAL_OPTION_KEYS if fixed else _INTERVAL_OPTION_KEYS):
             return None
         if k == "norm":
+            if fixed:
+                continue  # (a fixed grid has no step control: the norm is never called)
             v = native_norm_spec(v)
             if v is None:
                 return None
@@ -318,7 +322,11 @@ def _interval_key(solver, rtol, atol, options, direction):
             if v is not None:
                 return None
         elif k == "pipeline":
-            if v not in ("auto", "sync"):  # (the interval solve resolves every attempt before the next: what "sync" asks for)
+            if v not in ("auto", "sync") and not (fixed and v == "graph"):  # (every attempt is resolved before the next: "sync")
+                return None
+            continue
+        elif k == "interp":
+            if v != "linear":
                 return None
             continue
         elif k == "reuse_f0":
@@ -330,6 +338,10 @@ def _interval_key(solver, rtol, atol, options, direction):
         except TypeError:
             return None
         items.append((k, v))
+    if fixed and t_dtype not in (torch.float32, torch.float64):
+        return None
+    if fixed:  # (one step per interval: its direction is in the data; its times are handed to func in the output times' dtype)
+        return (solver, "fixed", str(t_dtype), tuple(sorted(items, key=lambda kv: kv[0])))
     return (solver, float(rtol), float(atol), int(direction), tuple(sorted(items, key=lambda kv: kv[0])))
 
 
@@ -342,13 +354,13 @@ def _prepare_intervals(graphed, flat_ex, segs, shapes, t_span, adjoint_solver, r
     opts = {k: v for k, v in adjoint_options.items() if k not in ("_replay_intervals", "interval_graph")}
     if adjoint_options.get("_replay_intervals") is not None or adjoint_options.get("interval_graph", True) is False:
         return
-    if len(t_span) < 2 or _interval_key(adjoint_solver, rtol, atol, opts, 1) is None:
+    if len(t_span) < 2 or _interval_key(adjoint_solver, rtol, atol, opts, 1, t_span.dtype) is None:
         return
     t_host = t_span.detach().to("cpu")
     span = (t_host[-1].item(), t_host[-2].item())  # the sweep's first interval
     if span[0] == span[1]:
         return
-    key = _interval_key(adjoint_solver, rtol, atol, opts, direction_of(span))
+    key = _interval_key(adjoint_solver, rtol, atol, opts, direction_of(span), t_host.dtype)
     cache = graphed.__dict__.setdefault("_intervals", {})
     if key in cache:
         return
@@ -356,12 +368,18 @@ def _prepare_intervals(graphed, flat_ex, segs, shapes, t_span, adjoint_solver, r
         opts.pop("reuse_f0", None)
         opts.pop("pipeline", None)
         t_ex = torch.tensor(span, dtype=t_host.dtype)
-        s = adjoint_solver(xde=BaseODE(graphed.func, y0=flat_ex, t_span=t_ex), y0=flat_ex, rtol=rtol, atol=atol, reuse_f0=True,
-                           _xde_segments=segs, _xde_segment_shapes=shapes, **opts)
+        if _is_fixed(adjoint_solver):
+            s = adjoint_solver(xde=BaseODE(graphed.func, y0=flat_ex, t_span=t_ex), y0=flat_ex, rtol=rtol, atol=atol, **opts)
+        else:
+            s = adjoint_solver(xde=BaseODE(graphed.func, y0=flat_ex, t_span=t_ex), y0=flat_ex, rtol=rtol, atol=atol, reuse_f0=True,
+                               _xde_segments=segs, _xde_segment_shapes=shapes, **opts)
         if not (hasattr(s, "intervals_supported") and s.intervals_supported()):
             cache[key] = _NoIntervals()
             return
-        s.intervals_prepare(span)
+        if _is_fixed(adjoint_solver):
+            s.intervals_prepare(span, t_host.dtype if t_host.dtype in (torch.float32, torch.float64) else torch.float32)
+        else:
+            s.intervals_prepare(span)
         entry = _IntervalSolver(s)
     except Exception:
         entry = _NoIntervals()  # this solve cannot be captured: per-interval solves, and no second attempt for this key
@@ -510,7 +528,7 @@ def _interval_solver_for(plan, solve_options, t_host):
     if not cache:
         return None
     opts = {k: v for k, v in solve_options.items() if k != "_xde_flat_func"}
-    key = _interval_key(plan.solver, plan.rtol, plan.atol, opts, direction_of((t_host[-1].item(), t_host[-2].item())))
+    key = _interval_key(plan.solver, plan.rtol, plan.atol, opts, direction_of((t_host[-1].item(), t_host[-2].item())), t_host.dtype)
     iv = cache.get(key) if key is not None else None
     if not isinstance(iv, _IntervalSolver) or not iv.lock.acquire(blocking=False):
         return None
@@ -521,13 +539,15 @@ def _sweep_captured(solver, state, t_host, y_ans, grad_y, plan):
     """`_sweep`'s loop on the re-armable solver: the augmented state lives in the solver's static buffer for the whole sweep; per
     interval two output times go up, one graph (seldom two) is replayed, and the row comes back into the state."""
     n_times = len(t_host)
-    flat = solver.interval_state
+    fixed = _is_fixed(plan.solver)
+    flat = solver.interval_state[0] if fixed else solver.interval_state  # (fixed solvers carry the state as [1, total])
     flat.copy_(state.flat)
     state.flat = flat
     times = t_host.tolist()
     for i in range(n_times - 1, 0, -1):
         row = solver.interval_solve((times[i], times[i - 1]))
-        flat.copy_(row)
+        if not fixed:  # (the one-step solve leaves its result in the state buffer; the adaptive one in an output row)
+            flat.copy_(row)
         state.restart_interval(y_ans[i - 1], grad_y[i - 1])
     parts = [p.clone() for p in state.views()]  # (the static buffer serves the next sweep)
     return parts[2].reshape(plan.y0_shape), None, list(parts[_N_LEADING:])

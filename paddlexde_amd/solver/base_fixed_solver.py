@@ -307,6 +307,101 @@ class FixedSolver(metaclass=abc.ABCMeta):
             self.nfe += per_step
         return out
 
+    # -- re-armable one-step solves: odeint_adjoint's backward over a fixed grid -----------------------------------------
+    # The backward sweep of a fixed-grid solve is one STEP per output interval, each from a fresh solver: with the captured
+    # dynamics that was 2 input copies + 1 clone around every evaluation.  Here ONE solver is kept for the sweep (and the next
+    # backward pass): the state lives in a static buffer, the step's times and step sizes go up in one host-to-device copy, and
+    # the whole step — func's framework ops, the combines, the hand-over — is one graph replay.  Same kernels, same operands as
+    # the eager step: bit-identical.
+    _IV_SLOTS = 8
+
+    def intervals_supported(self):
+        return bool(self.graphable and not self._step_end_hook and self.interp != "cubic" and self.y0.is_cuda and self.y0.dim() >= 2
+                    and self.pipeline in ("auto", "sync", "graph"))
+
+    def _iv_host_rows(self, t_host):
+        """(times row in the time dtype: t0, t1, the step's time values; the dt of every combine of the step, fp64) for one step."""
+        dts = t_host[1:] - t_host[:-1]
+        cols = [np.broadcast_to(t_host[:-1] + v if is_time else v, dts.shape) for v, is_time in self._time_values_tagged(dts)]
+        row = np.concatenate([t_host[:1], t_host[1:]] + [np.asarray(c) for c in cols]).astype(t_host.dtype)
+        return row, np.asarray([v[0] for v in self._record_combine_dts(dts)], dtype=np.float64)
+
+    def intervals_prepare(self, t_span, t_dtype, capture=True):
+        """Static buffers for one-step solves, one eager step over ``t_span`` (two host times) from the constructor's ``y0`` as
+        warm-up, and — ``capture`` — the step's graph.  Main thread, outside autograd nodes (utils/graphed.py)."""
+        from ..utils.graphed import CapturedGraph
+
+        dev = self.y0.device
+        self.backend.require_device(self.y0)
+        y0 = as_operand(self.y0.detach())
+        self._iv_tt = tt = np_dtype(t_dtype)
+        row, dtrow = self._iv_host_rows(np.asarray([t_span[0], t_span[1]], dtype=tt))
+        K, nb, item = len(dtrow), C.sizeof(_hip.XdeCtrl), np.dtype(tt).itemsize
+        # one static device block: K control blocks (the combines read their `dt` field), then the step's times; its pinned mirror
+        size = K * nb + len(row) * 8
+        # (the host never waits for a step here, so the mirror is a ring: a slot is rewritten only after the copy that read it ran)
+        self._iv_pinned = torch.zeros(self._IV_SLOTS, size, dtype=torch.uint8).pin_memory()
+        self._iv_events = [None] * self._IV_SLOTS
+        self._iv_slot = 0
+        self._iv_block = torch.zeros(size, dtype=torch.uint8, device=dev)
+        self._iv_ctrl_list = [self._iv_block[k * nb : (k + 1) * nb] for k in range(K)]
+        self._iv_row = self._iv_block[K * nb : K * nb + len(row) * item].view(t_dtype)
+        host = self._iv_pinned.numpy()
+        self._iv_host_dt = [h[: K * nb].view(np.float64).reshape(K, nb // 8)[:, 2] for h in host]  # (the `dt` field of each control block)
+        self._iv_host_row = [h[K * nb : K * nb + len(row) * item].view(tt) for h in host]
+        self._iv_y = (y0.clone(), torch.empty_like(y0))
+        self._iv_graph = None
+        with torch.no_grad(), torch.autograd.set_multithreading_enabled(False):
+            nfe0 = self.nfe
+            self.interval_solve(t_span)  # eager: func's lazy initialisations, the allocator's blocks
+            self._iv_per_step = self.nfe - nfe0
+            if capture:
+                torch.cuda.synchronize(dev)
+                g = CapturedGraph()
+                with g.capture(capture_error_mode="thread_local"):
+                    self._iv_body()
+                g.finish()
+                self._iv_graph = g
+            self.nfe = nfe0
+        return self
+
+    @property
+    def interval_state(self):
+        """The static state buffer a one-step solve starts from and leaves its result in."""
+        return self._iv_y[0]
+
+    def _iv_body(self):
+        y_cur, y_next = self._iv_y
+        row = self._iv_row
+        self._row, self._y1_out, self._g_ctrls, self._g_slot = row[2:], y_next, self._iv_ctrl_list, 0
+        self._dt, self._t0_host = self._iv_tt(1.0), self._iv_tt(0.0)  # placeholders: every dt the kernels use comes from the block
+        try:
+            y1, _ = self.step(row[0:1], row[1:2], y_cur)
+        finally:
+            self._row = self._y1_out = self._g_ctrls = self._dt = self._t0_host = None
+        y_cur.copy_(y1)
+
+    def interval_solve(self, t_span):
+        """One step from ``t_span[0]`` to ``t_span[1]`` (host times) on ``interval_state``, in place; returns it."""
+        row, dtrow = self._iv_host_rows(np.asarray([t_span[0], t_span[1]], dtype=self._iv_tt))
+        i = self._iv_slot
+        self._iv_slot = (i + 1) % self._IV_SLOTS
+        if self._iv_events[i] is not None:
+            self._iv_events[i].synchronize()
+        self._iv_host_row[i][:] = row
+        self._iv_host_dt[i][:] = dtrow
+        self._iv_block.copy_(self._iv_pinned[i], non_blocking=True)
+        if self._iv_events[i] is None:
+            self._iv_events[i] = torch.cuda.Event()
+        self._iv_events[i].record()
+        with torch.no_grad():
+            if self._iv_graph is not None:
+                self._iv_graph.replay()
+                self.nfe += self._iv_per_step
+            else:
+                self._iv_body()
+        return self._iv_y[0]
+
     def _time_values_tagged(self, dt):
         """[(value, is_offset_from_t0)] matching ``_time_values``; default: every value is a plain dt-like."""
         return [(v, False) for v in self._time_values(dt)]

@@ -1914,3 +1914,40 @@ def test_adjoint_captured_interval_solves_report_errors(dev):
             grads(**adj)
         msgs.append(str(e.value))
     assert msgs[0] == msgs[1] and "max_num_steps" in msgs[0], msgs
+
+
+@pytest.mark.parametrize("solver_name,dtype", [("rk4", torch.float32), ("rk4", torch.float64), ("euler", torch.float32), ("midpoint", torch.float32)])
+def test_adjoint_captured_fixed_step_intervals(dev, solver_name, dtype):
+    """A fixed-grid backward sweep — one STEP per output interval — replayed from ONE re-armable captured step (solver/base_fixed_solver.py:
+    intervals_prepare; the step's times and step sizes go up in one copy per interval, the host never waits): bit for bit the
+    gradients of the per-interval solves, on the per-evaluation captured dynamics and on the eager one, call after call, in both
+    directions of time, on uneven grids."""
+    import importlib
+    import os
+
+    OA = importlib.import_module("paddlexde_amd.functional.odeint_adjoint")
+    cls = {"rk4": RK4, "euler": Euler, "midpoint": Midpoint}[solver_name]
+    y0 = (torch.rand(96, 2, generator=torch.Generator().manual_seed(4), dtype=dtype) * 4 - 2).to(dev)
+    m = ODEFunc(dtype).to(dev)
+
+    def grads(t, **adj):
+        for p_ in m.parameters():
+            p_.grad = None
+        y = y0.clone().requires_grad_(True)
+        sol = odeint_adjoint(m, y, t, solver=cls, options={"norm": _rms_norm}, adjoint_options=adj)
+        (sol * sol).mean().backward()
+        return [y.grad.clone()] + [p_.grad.clone() for p_ in m.parameters()]
+
+    grid = torch.tensor([0.0, 0.02, 0.05, 0.06, 0.1, 0.17, 0.2, 0.21, 0.3, 0.34, 0.4, 0.5, 0.55], dtype=dtype)  # 12 uneven intervals
+    for t in (grid.to(dev), grid.flip(0).to(dev)):
+        eager = grads(t, graph_func=False)
+        per_eval = grads(t, graph_func=True, interval_graph=False)
+        for call in range(3):
+            got = grads(t, graph_func=True)
+            for a, b, c in zip(got, eager, per_eval):
+                assert torch.equal(a, b) and torch.equal(a, c), (call, float((a - b).abs().max()))
+    if str(dev).startswith("cuda") and os.environ.get("XDE_INTERVAL_GRAPH", "1") != "0":
+        ivs = [iv for g in OA._GRAPH_CACHE.get(m, {}).values() if not isinstance(g, OA._NoGraph) for iv in getattr(g, "_intervals", {}).values()]
+        used = [iv for iv in ivs if isinstance(iv, OA._IntervalSolver)]
+        assert len(used) == 1, ivs  # (a step's direction is data: one captured step serves both)
+        assert used[0].solver._iv_graph is not None and used[0].solver.nfe >= 6 * 12
