@@ -995,7 +995,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
     # pair, and a replayed hipGraph re-arms the control block on the device (xde_initial_step_fused with t_start = NaN and
     # seq0 < 0), runs the heuristic's two evaluations and the first attempt, writes the output row and hands the state over
     # (xde_dense_commit).  A second graph holds one more attempt for the intervals that need it.  Same kernels, same operands,
-    # same order as the eager solve: bit-identical results (tests/test_gpu_adjoint.py).
+    # same order as the eager solve: bit-identical results (tests/_e2e_cases.py::test_adjoint_captured_interval_solves).
     def intervals_supported(self):
         """Whether this solver's options allow the captured interval solve (else: one ordinary solve per interval)."""
         return bool(self.y0.is_cuda and self._fused_first_step() and not self._custom_norm and self.first_step is None
