@@ -292,7 +292,10 @@ MAX_INTERVAL_SOLVERS = 4  # per captured dynamics (tolerances x solver x directi
 
 
 class _NoIntervals:
-    """Cache entry: the interval solve could not be captured for this key; one ordinary solve per interval."""
+    """Cache entry: the interval solve could not be captured for this key (``reason`` says why); one ordinary solve per interval."""
+
+    def __init__(self, reason=""):
+        self.reason = reason
 
 
 class _IntervalSolver:
@@ -374,15 +377,15 @@ def _prepare_intervals(graphed, flat_ex, segs, shapes, t_span, adjoint_solver, r
             s = adjoint_solver(xde=BaseODE(graphed.func, y0=flat_ex, t_span=t_ex), y0=flat_ex, rtol=rtol, atol=atol, reuse_f0=True,
                                _xde_segments=segs, _xde_segment_shapes=shapes, **opts)
         if not (hasattr(s, "intervals_supported") and s.intervals_supported()):
-            cache[key] = _NoIntervals()
+            cache[key] = _NoIntervals("the solver's options rule it out (intervals_supported)")
             return
         if _is_fixed(adjoint_solver):
             s.intervals_prepare(span, t_host.dtype if t_host.dtype in (torch.float32, torch.float64) else torch.float32)
         else:
             s.intervals_prepare(span)
         entry = _IntervalSolver(s)
-    except Exception:
-        entry = _NoIntervals()  # this solve cannot be captured: per-interval solves, and no second attempt for this key
+    except Exception as e:  # this solve cannot be captured: per-interval solves, and no second attempt for this key
+        entry = _NoIntervals("{}: {}".format(type(e).__name__, e))
     while len(cache) >= MAX_INTERVAL_SOLVERS:
         cache.pop(next(iter(cache)))
     cache[key] = entry
