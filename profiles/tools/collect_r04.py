@@ -109,8 +109,12 @@ def main():
     p = os.path.join(S, "c3_timeline.txt")
     if os.path.exists(p):
         open(os.path.join(D, "r04_c3_timeline.txt"), "w").write(
-            "# profiles/tools/c3_timeline.py on a rocprofv3 --kernel-trace of `python3 bench.py --workload c3` (round 4: one-workgroup initial step):\n"
-            "# the second, tuned Dopri5 repetition (durations and the span are inflated by the tracer, the MIX is what counts)\n" + open(p).read())
+            "# profiles/tools/c3_timeline.py on a rocprofv3 --kernel-trace of `python3 bench.py --workload c3` (round 4, final: one-workgroup initial\n"
+            "# step + captured interval solves): the second, tuned Dopri5 repetition (durations and the span are inflated by the tracer, the MIX is\n"
+            "# what counts).  Before the captured interval solves: 5853 kernels of which 917 copies (2 input copies + 1 clone around each replay of\n"
+            "# the captured dynamics); now the whole 2-point solve is one graph and those copies are gone.\n" + open(p).read()
+            + "# alternating with XDE_INTERVAL_GRAPH=0 on one box (`python3 bench.py --workload c3`): dopri5 backward 19.8 / 19.2 ms vs 26.4 / 25.7 ms;\n"
+              "# rk4 backward (fixed grid: one re-armable captured step per interval) 9.07 / 9.13 ms vs 10.91 / 10.86 ms\n")
     p = os.path.join(S, "watchdog.err")
     if os.path.exists(p):
         keep = [ln for ln in open(p).read().splitlines() if "bench.py" in ln or ln.startswith("  rank") or ln.startswith("rc=")]
