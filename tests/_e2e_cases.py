@@ -1951,3 +1951,42 @@ def test_adjoint_captured_fixed_step_intervals(dev, solver_name, dtype):
         used = [iv for iv in ivs if isinstance(iv, OA._IntervalSolver)]
         assert len(used) == 1, ivs  # (a step's direction is data: one captured step serves both)
         assert used[0].solver._iv_graph is not None and used[0].solver.nfe >= 6 * 12
+
+
+def test_rearmable_interval_solver_equals_integrate(dev):
+    """`intervals_prepare` / `interval_solve` on the solver itself: a chain of 2-point solves on ONE re-armed solver — replayed from its
+    graphs, and run eagerly on the same static buffers — gives bit for bit the rows a fresh solver's `integrate` gives for every
+    interval; a repeated output time returns the state itself."""
+    if not str(dev).startswith("cuda"):
+        pytest.skip("the re-armable solver is a device path (static buffers + hipGraph)")
+    from paddlexde_amd.xde import BaseODE
+
+    dtype = torch.float32
+    m = ODEFunc(dtype).to(dev)
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    func = lambda t, y: m(t, y.view(-1, 2)).reshape(-1)  # noqa: E731
+    y_start = (torch.rand(4099 * 2, generator=torch.Generator().manual_seed(9)) * 4 - 2).to(dev)
+    times = [0.0, 0.3, 0.35, 1.5, 1.5, 4.0]  # one-attempt intervals, a several-attempt one, a repeated time
+
+    def make():
+        return Dopri5(xde=BaseODE(func, y0=y_start, t_span=torch.tensor(times[:2])), y0=y_start, rtol=1e-5, atol=1e-7, norm=_rms_norm, reuse_f0=True)
+
+    want, y = [], y_start
+    for a, b in zip(times[:-1], times[1:]):
+        s = Dopri5(xde=BaseODE(func, y0=y, t_span=torch.tensor([a, b])), y0=y, rtol=1e-5, atol=1e-7, norm=_rms_norm, reuse_f0=True)
+        y = s.integrate(torch.tensor([a, b]))[1].clone()
+        want.append(y)
+    for capture in (True, False):
+        s = make()
+        if not s.intervals_supported():
+            pytest.skip("the one-workgroup initial step is switched off by the environment")
+        s.intervals_prepare((times[0], times[1]), capture=capture)
+        assert (s._iv_first_graph is not None) == capture
+        s.interval_state.copy_(y_start)
+        for (a, b), ref in zip(zip(times[:-1], times[1:]), want):
+            row = s.interval_solve((a, b))
+            assert torch.equal(row, ref), (capture, a, b, float((row - ref).abs().max()))
+            s.interval_state.copy_(row)
+        with pytest.raises(AssertionError):
+            s.interval_solve((1.0, 0.5))  # against the prepared direction
