@@ -304,6 +304,9 @@ int xde_ctrl_retarget(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const d
  *   phase 1: res_dev = {norm((f1 - f0)/scale)} -> d2 = |./h0| -> h1 -> hs_dev[3] = min(100 h0, h1) in the time dtype;
  *            pass hs_dev + 3 to xde_ctrl_init as first_step_dev.  (first_step_dev != NULL overrides first_step; the
  *            direction's sign is applied there.)
+ *   phase 2: phase 0 with the start time read from res_dev[2] instead of t_start — for a launch recorded in a hipGraph and replayed
+ *            for one output interval after another (res_dev then holds three doubles).  xde_ctrl_init takes t_start = NaN as
+ *            "the start time is t_span_dev[0]" and seq0 < 0 as "keep the block's controller-launch count" for the same use.
  */
 int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde_ctrl_params_t* params,
                      double t_start, void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl, void* stream);
@@ -320,7 +323,7 @@ int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde
  *   rtol / atol / norm kind / segment counts come from params; segs as in xde_scaled_norm_partial; hs_dev: 5 doubles.
  *   States above 2^20 elements are refused (one workgroup): use the separate calls.
  *   Re-armable use (a launch recorded in a hipGraph and replayed for one output interval after another): t_start = NaN reads the
- *   start time from t_span_dev[0] (then required in phase 0 too), and seq0 < 0 keeps the block's own controller-launch count
+ *   start time from t_span_dev[0] (pass it in phase 0 too), and seq0 < 0 keeps the block's own controller-launch count
  *   (ctrl->seq, what the host mirror's slots are numbered with) instead of resetting it; xde_ctrl_init takes seq0 < 0 the same way.
  */
 int xde_initial_step_fused(int phase, const void* a, const void* b, const void* y0, const xde_segments_t* segs, int dtype, double* hs_dev,

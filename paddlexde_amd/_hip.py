@@ -528,7 +528,8 @@ class HipBackend:
             m.seq += 1
 
     def initial_step(self, phase, res, hs, params, t_start, t_probe, ctrl):
-        """Scalar part of select_initial_step on the device (phase 0: h0; phase 1: the first step)."""
+        """Scalar part of select_initial_step on the device (phase 0: h0; phase 1: the first step; phase 2: phase 0 with the start
+        time in ``res[2]``)."""
         self._require_device(res, hs, ctrl, t_probe)
         rc = self.lib.xde_initial_step(int(phase), res.data_ptr(), hs.data_ptr(), C.byref(params), float(t_start), _ptr(t_probe),
                                        dtype_code(t_probe.dtype) if t_probe is not None else XDE_F32, ctrl.data_ptr(), self._stream(ctrl))
@@ -550,10 +551,12 @@ class HipBackend:
         if m is not None:
             m.seq0 = seq0
 
-    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None):
+    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None, keep_seq=False):
+        """``t_start = nan``: the start time is ``t_span_dev[0]``; ``keep_seq``: the block goes on counting its controller launches
+        (both for a launch recorded in a graph and replayed per output interval)."""
         self._require_device(ctrl, t_span_dev, t_stage)
-        m = self._mirrors.get(ctrl.data_ptr())
-        seq0 = m.seq if m is not None else 0
+        m = None if keep_seq else self._mirrors.get(ctrl.data_ptr())
+        seq0 = -1 if keep_seq else (m.seq if m is not None else 0)
         rc = self.lib.xde_ctrl_init(ctrl.data_ptr(), C.byref(params), float(t_start), float(first_step), int(n_out),
                                     t_span_dev.data_ptr(), _ptr(step_t_dev), t_stage.data_ptr(), seq0, _ptr(first_step_dev),
                                     self._stream(ctrl))

@@ -177,6 +177,7 @@ __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double 
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   // device-resident first step (xde_initial_step): a magnitude, given the direction's sign here
   const double first = first_step_dev ? double(p.direction) * fabs(*first_step_dev) : first_step;
+  if (t_start != t_start) t_start = t_span[0];  // (a launch recorded in a graph: the start time is the first output time)
   ctrl_init_body(c, p, t_start, first, n_out, t_span, step_t, t_stage_out, seq0, z);
 }
 
@@ -262,6 +263,10 @@ __device__ void initial_step_phase(int phase, const double* res, double* hs, con
 __global__ void xde_initial_step_kernel(int phase, const double* res, double* hs, xde_ctrl_params_t p, double t_start,
                                         void* t_probe_out, int probe_dtype, xde_ctrl_t* c) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (phase == 2) {  // phase 0 of a launch recorded in a graph: the start time is device data (res[2])
+    phase = 0;
+    t_start = res[2];
+  }
   if (p.state_dtype == XDE_F32)
     initial_step_phase<float>(phase, res, hs, p, t_start, t_probe_out, probe_dtype, c);
   else
@@ -498,8 +503,8 @@ int xde_ctrl_retarget(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const d
 int xde_initial_step(int phase, const double* res_dev, double* hs_dev, const xde_ctrl_params_t* params, double t_start,
                      void* t_probe_out, int probe_dtype, xde_ctrl_t* ctrl, void* stream) {
   if (!res_dev || !hs_dev || !ctrl) return fail(XDE_EBADARG, "xde_initial_step: null pointer");
-  if (phase != 0 && phase != 1) return fail(XDE_EBADARG, "xde_initial_step: phase must be 0 or 1");
-  if (phase == 0 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step: phase 0 needs t_probe_out");
+  if (phase != 0 && phase != 1 && phase != 2) return fail(XDE_EBADARG, "xde_initial_step: phase must be 0, 1 or 2");
+  if (phase != 1 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step: phase 0 needs t_probe_out");
   if (probe_dtype != XDE_F32 && probe_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step: bad probe dtype");
   int rc = check_params(params, "xde_initial_step");
   if (rc != XDE_OK) return rc;
@@ -519,7 +524,6 @@ int xde_initial_step_fused(int phase, const void* a, const void* b, const void* 
   if (phase == 0 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step_fused: phase 0 needs t_probe_out");
   if (phase == 1 && (!b || !t_span_dev || !t_stage_out)) return fail(XDE_EBADARG, "xde_initial_step_fused: phase 1 needs b, t_span_dev and t_stage_out");
   if (phase == 1 && n_out < 1) return fail(XDE_EBADARG, "xde_initial_step_fused: n_out must be >= 1");
-  if (t_start != t_start && !t_span_dev) return fail(XDE_EBADARG, "xde_initial_step_fused: t_start = NaN (read it from t_span_dev[0]) needs t_span_dev");
   if (probe_dtype != XDE_F32 && probe_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step_fused: bad probe dtype");
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step_fused: bad dtype");
   int rc = check_params(params, "xde_initial_step_fused");

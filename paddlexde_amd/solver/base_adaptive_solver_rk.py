@@ -998,10 +998,10 @@ class AdaptiveRKSolver(AdaptiveSolver):
     # same order as the eager solve: bit-identical results (tests/_e2e_cases.py::test_adjoint_captured_interval_solves).
     def intervals_supported(self):
         """Whether this solver's options allow the captured interval solve (else: one ordinary solve per interval)."""
-        return bool(self.y0.is_cuda and self._fused_first_step() and not self._custom_norm and self.first_step is None
-                    and self.step_t is None and not self._has_callbacks and self._step_hook is None and not self.record_trace
-                    and self._reuse_f0 and self._stats_out is None and self.pipeline == "auto" and self._device_first_step
-                    and self.y0.dim() == 1)
+        return bool(self.y0.is_cuda and not self._custom_norm and self._chunks is None and self.process_group is None
+                    and not self._replay and self.first_step is None and self.step_t is None and not self._has_callbacks
+                    and self._step_hook is None and not self.record_trace and self._reuse_f0 and self._stats_out is None
+                    and self.pipeline == "auto" and self._device_first_step and self.y0.dim() == 1)
 
     def intervals_prepare(self, t_span, capture=True):
         """Static buffers for 2-point solves in the direction of ``t_span`` (two host times), one eager solve of that span from
@@ -1012,12 +1012,15 @@ class AdaptiveRKSolver(AdaptiveSolver):
         if len(t_span) != 2 or not t_span[0] != t_span[1]:
             raise ValueError("intervals_prepare needs two distinct output times")
         y0, dev = self.y0, self.y0.device
-        # the interval's two output times (double, what the kernels read) and its start time in the time dtype (what func is handed):
-        # 32 static bytes on the device, written by ONE host-to-device copy per interval from a pinned mirror
-        self._iv_pinned = torch.zeros(32, dtype=torch.uint8).pin_memory()
-        self._iv_times = torch.zeros(32, dtype=torch.uint8, device=dev)
-        self._t_span_dev = self._iv_times[:16].view(torch.float64)
-        self._iv_t0 = self._iv_times[16:24].view(self.dtype)[0]
+        # One static device block of five doubles: [d0, d1 | t0, t1 | t0 in the time dtype].  The last three — the interval's two output
+        # times as the kernels read them and its start time as func is handed it — are written by ONE host-to-device copy per interval
+        # from a pinned mirror; the first two are the heuristic's norms (separate launches of a larger state), so that the scalar
+        # kernel finds (d0, d1, start time) side by side (xde_initial_step, phase 2).
+        self._iv_pinned = torch.zeros(24, dtype=torch.uint8).pin_memory()
+        self._iv_block = torch.zeros(40, dtype=torch.uint8, device=dev)
+        self._iv_res = self._iv_block[:24].view(torch.float64)
+        self._t_span_dev = self._iv_block[16:32].view(torch.float64)
+        self._iv_t0 = self._iv_block[32:40].view(self.dtype)[0]
         self._iv_upload(t_span)
         self._gbase = (y0.clone(), None)
         self._iv_y1 = torch.empty_like(y0)
@@ -1042,7 +1045,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         host = self._iv_pinned.numpy()
         host[:16].view(np.float64)[:] = np.asarray(t, dtype=np.float64)
         host[16:24].view(np_dtype(self.dtype))[0] = t[0]
-        self._iv_times.copy_(self._iv_pinned, non_blocking=True)
+        self._iv_block[16:].copy_(self._iv_pinned, non_blocking=True)
 
     @property
     def interval_state(self):
@@ -1057,12 +1060,24 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # second graph addresses too)
         f0 = self._eval(self._iv_t0, y0)
         self._gbase = (y0, f0)
-        be.initial_step_fused(0, f0, None, y0, self._xsegs, self._iv_hs, self._params, nan, self._iv_tprobe, self._ctrl,
-                              t_span_dev=self._t_span_dev, keep_seq=True)
-        be.stage_combine(self._iv_y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
-        f1 = self._eval(self._iv_tprobe, self._iv_y1)
-        be.initial_step_fused(1, f1, f0, y0, self._xsegs, self._iv_hs, self._params, nan, None, self._ctrl, 2, self._t_span_dev,
-                              self._step_t_dev, self._t_stage, keep_seq=True)
+        if self._fused_first_step():  # small state: two one-workgroup launches around the Euler probe
+            be.initial_step_fused(0, f0, None, y0, self._xsegs, self._iv_hs, self._params, nan, self._iv_tprobe, self._ctrl,
+                                  t_span_dev=self._t_span_dev, keep_seq=True)
+            be.stage_combine(self._iv_y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
+            f1 = self._eval(self._iv_tprobe, self._iv_y1)
+            be.initial_step_fused(1, f1, f0, y0, self._xsegs, self._iv_hs, self._params, nan, None, self._ctrl, 2, self._t_span_dev,
+                                  self._step_t_dev, self._t_stage, keep_seq=True)
+        else:  # the separate launches of _select_initial_step_device, the start time read on the device
+            res, hs = self._iv_res, self._iv_hs
+            self._scaled_norm_into(y0, None, y0, self.rtol, self.atol, res[0:1])
+            self._scaled_norm_into(f0, None, y0, self.rtol, self.atol, res[1:2])
+            be.initial_step(2, res, hs, self._params, nan, self._iv_tprobe, self._ctrl)  # h0 -> ctrl.dt, t0 + h0 -> t_probe
+            be.stage_combine(self._iv_y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
+            f1 = self._eval(self._iv_tprobe, self._iv_y1)
+            self._scaled_norm_into(f1, f0, y0, self.rtol, self.atol, res[0:1])
+            be.initial_step(1, res, hs, self._params, nan, None, self._ctrl)
+            be.ctrl_init(self._ctrl, self._params, nan, 0.0, 2, self._t_span_dev, self._step_t_dev, self._t_stage,
+                         first_step_dev=hs[3:4], keep_seq=True)
         self._iv_attempt()
 
     def _iv_attempt(self):

@@ -263,6 +263,8 @@ class NumpyDoubleBackend:
     def initial_step(self, phase, res, hs, params, t_start, t_probe, ctrl):
         Y = np.float32 if params.state_dtype == _hip.XDE_F32 else np.float64
         r, h = res.numpy(), hs.numpy()
+        if phase == 2:  # phase 0 with the start time in res[2]
+            phase, t_start = 0, float(r[2])
         with np.errstate(all="ignore"):
             if phase == 0:
                 d0, d1 = Y(abs(r[0])), Y(abs(r[1]))
@@ -312,9 +314,14 @@ class NumpyDoubleBackend:
             hs[4] = res[0]
             self.ctrl_init(ctrl, params, t_start, 0.0, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=hs[3:4])
 
-    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None):
+    def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None, keep_seq=False):
         c = self._c(ctrl)
+        seq = c.seq
+        if t_start != t_start:  # NaN: the start time is the first output time
+            t_start = float(t_span_dev.numpy()[0])
         C.memset(C.addressof(c), 0, C.sizeof(c))
+        if keep_seq:
+            c.seq = seq
         c.t0 = c.t1 = float(t_start)
         if first_step_dev is not None:
             first_step = float(params.direction) * abs(float(first_step_dev.numpy()[0]))

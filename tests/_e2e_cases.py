@@ -1866,9 +1866,8 @@ def test_adjoint_captured_interval_solves(dev, solver_name, dtype, n_out, t_end)
                 assert torch.equal(a, b) and torch.equal(a, c), (call, float((a - b).abs().max()))
     import os
 
-    switched_off = (os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0" or os.environ.get("XDE_FUSED_FIRST_STEP", "1") == "0"
-                    or os.environ.get("XDE_SINGLE_ELEMS", "1") == "0" or os.environ.get("XDE_HOST_FIRST_STEP", "0") == "1")
-    if str(dev).startswith("cuda") and not switched_off:  # (kernel-policy runs without the one-workgroup initial step solve per interval)
+    switched_off = os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0" or os.environ.get("XDE_HOST_FIRST_STEP", "0") == "1"
+    if str(dev).startswith("cuda") and not switched_off:  # (a kernel-policy run with the heuristic's scalars on the host solves per interval)
         ivs = [iv for g in OA._GRAPH_CACHE.get(m, {}).values() if not isinstance(g, OA._NoGraph) for iv in getattr(g, "_intervals", {}).values()]
         used = [iv for iv in ivs if isinstance(iv, OA._IntervalSolver)]
         assert len(used) == 2, ivs  # one per direction
@@ -1990,3 +1989,37 @@ def test_rearmable_interval_solver_equals_integrate(dev):
             s.interval_state.copy_(row)
         with pytest.raises(AssertionError):
             s.interval_solve((1.0, 0.5))  # against the prepared direction
+
+
+def test_adjoint_captured_interval_solves_larger_state(dev):
+    """A state above the one-workgroup kernels' reach (> 65536 elements: multi-workgroup norms, separate launches of the initial-step
+    heuristic with the start time read on the device, error norm and controller as two launches) takes the captured interval solve
+    too: bit for bit the gradients of the per-interval solves."""
+    import importlib
+    import os
+
+    OA = importlib.import_module("paddlexde_amd.functional.odeint_adjoint")
+    dtype = torch.float32
+    y0 = (torch.rand(40000, 2, generator=torch.Generator().manual_seed(6)) * 4 - 2).to(dev)
+    t = torch.linspace(0.0, 1.0, 6).to(dev)
+    m = ODEFunc(dtype).to(dev)
+
+    def grads(**adj):
+        for p_ in m.parameters():
+            p_.grad = None
+        y = y0.clone().requires_grad_(True)
+        sol = odeint_adjoint(m, y, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm}, adjoint_options=adj)
+        (sol * sol).mean().backward()
+        return [y.grad.clone()] + [p_.grad.clone() for p_ in m.parameters()]
+
+    eager = grads(graph_func=False)
+    per_eval = grads(graph_func=True, interval_graph=False)
+    for call in range(2):
+        got = grads(graph_func=True)
+        for a, b, c in zip(got, eager, per_eval):
+            assert torch.equal(a, b) and torch.equal(a, c), (call, float((a - b).abs().max()))
+    switched_off = os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0" or os.environ.get("XDE_HOST_FIRST_STEP", "0") == "1"
+    if str(dev).startswith("cuda") and not switched_off:
+        ivs = [iv for g in OA._GRAPH_CACHE.get(m, {}).values() if not isinstance(g, OA._NoGraph) for iv in getattr(g, "_intervals", {}).values()]
+        used = [iv for iv in ivs if isinstance(iv, OA._IntervalSolver)]
+        assert len(used) == 1 and used[0].solver.nfe > 0 and not used[0].solver._small_state, ivs
