@@ -530,7 +530,7 @@ def _interval_solver_for(plan, solve_options, t_host):
     cache = getattr(plan.graphed, "_intervals", None)
     if not cache:
         return None
-    opts = {k: v for k, v in solve_options.items() if k != "_xde_flat_func"}
+    opts = {k: v for k, v in solve_options.items() if k not in ("_xde_flat_func", "_short_solves")}
     key = _interval_key(plan.solver, plan.rtol, plan.atol, opts, direction_of((t_host[-1].item(), t_host[-2].item())), t_host.dtype)
     iv = cache.get(key) if key is not None else None
     if not isinstance(iv, _IntervalSolver) or not iv.lock.acquire(blocking=False):
@@ -578,6 +578,9 @@ def _sweep(plan, t_span, y_ans, grad_y, adjoint_params):
     if not _is_fixed(plan.solver):
         # one evaluation of the augmented dynamics (func forward + vjp) less per interval: the heuristic's f0 is the state's f0
         solve_options.setdefault("reuse_f0", True)
+        # ... and intervals are mostly ONE attempted step long: where the speculative pipeline runs (large states, process groups) it
+        # waits for the first attempt's verdict instead of discarding a second attempt per interval
+        solve_options["_short_solves"] = True
     if plan.graphed is not None:
         # the captured FLAT dynamics (same segment layout) replaces the unpack -> dynamics -> pack wrapper: 2 input copies + 1 replay
         # + 1 clone per evaluation

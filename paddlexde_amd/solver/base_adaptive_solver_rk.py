@@ -167,6 +167,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         callback_reject=None,
         _xde_segments=None,
         _xde_segment_shapes=None,
+        _short_solves=False,
         **kwargs,
     ):
         super().__init__(xde=xde, dtype=dtype, y0=y0, **kwargs)
@@ -218,6 +219,10 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # the reference would report for the same solve (+1 here).  Off by default; odeint_adjoint switches it on for its
         # backward intervals, where that evaluation is one of nine per interval.
         self._reuse_f0 = bool(reuse_f0)
+        # odeint_adjoint's backward runs one solve per output interval, most of them a single attempted step long: the speculative
+        # pipeline then waits for the verdict of a solve's FIRST attempt (whose step size the host never saw) before it enqueues a
+        # second one, instead of discarding a whole attempt per interval
+        self._short_solves = bool(_short_solves)
         # options["stats_out"] = {}: a dict of the caller's that receives the solve's counters (attempts, accepted, rejected, func
         # evaluations, final time and step) when it ends — `odeint()` returns the solution only, as the reference's does
         self._stats_out = stats_out
@@ -941,7 +946,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
         (`t_plan`); when that is at or past the last output time, the host waits for attempt n's verdict before it enqueues anything
         else — a stall of one poll instead of a whole discarded attempt (six func evaluations and ~35 N elements of traffic; 9 % of
         config 2's `odeint` over [0, 1]).  Only a solve that ends with its very FIRST attempts, whose step size the host never
-        saw, still pays for one discarded attempt."""
+        saw, still pays for one discarded attempt — unless the caller says its solves are short (`_short_solves`: odeint_adjoint's
+        backward intervals), in which case the first attempt's verdict is waited for too."""
         be = self.backend
         c = self._last
         done = 0
@@ -975,6 +981,8 @@ class AdaptiveRKSolver(AdaptiveSolver):
             # 256 MiB Infinity Cache instead of spilling out of it).
             self._pending = (y1, ks[-1:], handle)
             del ks
+            if planned_end is None and self._short_solves:
+                planned_end = t_last  # (the first attempt of a solve that is expected to be short: taken as its last)
             if to_end and planned_end is not None and d * planned_end >= d * t_last:
                 c = self._resolve_pending()  # this attempt ends the solve if it is accepted: do not speculate past it
                 if c.done:

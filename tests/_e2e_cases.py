@@ -2023,3 +2023,38 @@ def test_adjoint_captured_interval_solves_larger_state(dev):
         ivs = [iv for g in OA._GRAPH_CACHE.get(m, {}).values() if not isinstance(g, OA._NoGraph) for iv in getattr(g, "_intervals", {}).values()]
         used = [iv for iv in ivs if isinstance(iv, OA._IntervalSolver)]
         assert len(used) == 1 and used[0].solver.nfe > 0 and not used[0].solver._small_state, ivs
+
+
+def test_adjoint_backward_under_lag_discards_no_attempt(dev):
+    """odeint_adjoint's backward solves one short interval after the other; where the speculative pipeline runs them (named here; by
+    itself for large states and process groups) it waits for the verdict of every interval's first attempt instead of enqueuing a
+    second one that the end of the interval would discard: func receives exactly the calls the "sync" pipeline makes, and the
+    gradients are the same bit for bit."""
+    dtype = torch.float64
+    y0 = (torch.rand(64, 2, generator=torch.Generator().manual_seed(8), dtype=dtype) * 4 - 2).to(dev)
+    t = torch.linspace(0.0, 0.06, 7, dtype=dtype).to(dev)  # six intervals of ONE attempted step each
+
+    class Counting(ODEFunc):
+        calls = 0
+
+        def forward(self, t_, y):
+            Counting.calls += 1
+            return super().forward(t_, y)
+
+    m = Counting(dtype).to(dev)
+
+    def grads(pipeline):
+        for p_ in m.parameters():
+            p_.grad = None
+        y = y0.clone().requires_grad_(True)
+        sol = odeint_adjoint(m, y, t, solver=Dopri5, rtol=1e-3, atol=1e-5, options={"norm": _rms_norm, "dtype": dtype},
+                             adjoint_options={"dtype": dtype, "pipeline": pipeline, "graph_func": False})
+        Counting.calls = 0
+        (sol * sol).mean().backward()
+        return Counting.calls, [y.grad.clone()] + [p_.grad.clone() for p_ in m.parameters()]
+
+    n_sync, g_sync = grads("sync")
+    n_lag, g_lag = grads("lag")
+    assert n_lag == n_sync == 6 * 8, (n_lag, n_sync)  # per interval: f0, the heuristic's probe, six stages (84 with a discarded attempt each)
+    for a, b in zip(g_lag, g_sync):
+        assert torch.equal(a, b)
