@@ -222,7 +222,7 @@ class AdaptiveRKSolver(AdaptiveSolver):
         # odeint_adjoint's backward runs one solve per output interval, most of them a single attempted step long: the speculative
         # pipeline then waits for the verdict of a solve's FIRST attempt (whose step size the host never saw) before it enqueues a
         # second one, instead of discarding a whole attempt per interval
-        self._short_solves = bool(_short_solves)
+        self._short_solves = bool(_short_solves) and os.environ.get("XDE_SHORT_SOLVES", "1") != "0"  # (0: for measuring it)
         # options["stats_out"] = {}: a dict of the caller's that receives the solve's counters (attempts, accepted, rejected, func
         # evaluations, final time and step) when it ends — `odeint()` returns the solution only, as the reference's does
         self._stats_out = stats_out
