@@ -584,6 +584,21 @@ class HipBackend:
         self._check(self.lib.xde_ctrl_read(ctrl.data_ptr(), C.byref(host), self._stream(ctrl)), "xde_ctrl_read")
         return host
 
+    def ctrl_peek_async(self, ctrl):
+        """Enqueue a copy of the control block AS IT IS AT THIS POINT OF THE STREAM into pinned host memory (a freshly constructed block
+        has no mirror slot); ``ctrl_peek_result(handle)`` waits for that copy only — not for anything enqueued after it."""
+        self._require_device(ctrl)
+        host = torch.empty(C.sizeof(XdeCtrl), dtype=torch.uint8).pin_memory()
+        host.copy_(ctrl, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return (host, ev)
+
+    def ctrl_peek_result(self, handle) -> XdeCtrl:
+        host, ev = handle
+        ev.synchronize()
+        return XdeCtrl.from_buffer_copy(host.numpy().tobytes())
+
     def ctrl_read_async(self, ctrl):
         """Handle for the control block of the newest controller launch; nothing is enqueued on the stream."""
         self._require_device(ctrl)

@@ -460,6 +460,13 @@ class AdaptiveRKSolver(AdaptiveSolver):
         if not self._ctrl_ready:  # (the fused initial step has constructed the control block already)
             be.ctrl_init(self._ctrl, p, float(t_span[0]), 0.0 if first_step is None else float(d * abs(first_step)), len(t_span),
                          self._t_span_dev, self._step_t_dev, self._t_stage, first_step_dev=first_dev)
+        # The speculative pipeline wants to know where the FIRST attempt lands if it is accepted (`t_plan` of the block just
+        # constructed — on the device when the heuristic chose the step): a copy of the block is enqueued here, behind the
+        # heuristic's kernels and ahead of the first attempt's, and read when the second attempt is about to be enqueued
+        self._init_peek = None
+        if (hasattr(be, "ctrl_peek_async") and os.environ.get("XDE_SHORT_SOLVES", "1") != "0"
+                and (self.pipeline == "lag" or (self.pipeline == "auto" and self._auto_pick() == "lag"))):
+            self._init_peek = be.ctrl_peek_async(self._ctrl)
 
     def _setup(self, t_span):
         """Buffers, output times and controller parameters of a solve over ``t_span`` (everything before the first evaluation)."""
@@ -946,8 +953,9 @@ class AdaptiveRKSolver(AdaptiveSolver):
         (`t_plan`); when that is at or past the last output time, the host waits for attempt n's verdict before it enqueues anything
         else — a stall of one poll instead of a whole discarded attempt (six func evaluations and ~35 N elements of traffic; 9 % of
         config 2's `odeint` over [0, 1]).  Only a solve that ends with its very FIRST attempts, whose step size the host never
-        saw, still pays for one discarded attempt — unless the caller says its solves are short (`_short_solves`: odeint_adjoint's
-        backward intervals), in which case the first attempt's verdict is waited for too."""
+        saw, would still pay for one discarded attempt: `_before_integrate` therefore enqueues a copy of the freshly constructed block
+        (ahead of the first attempt's kernels), whose `t_plan` is read here — by then long on the host — before a second attempt is
+        enqueued.  (`_short_solves`, odeint_adjoint's hint that its interval solves are short, covers a backend without that copy.)"""
         be = self.backend
         c = self._last
         done = 0
@@ -981,8 +989,12 @@ class AdaptiveRKSolver(AdaptiveSolver):
             # 256 MiB Infinity Cache instead of spilling out of it).
             self._pending = (y1, ks[-1:], handle)
             del ks
+            if planned_end is None and getattr(self, "_init_peek", None) is not None:
+                # the first attempt of the solve: its landing point is in the block the heuristic / ctrl_init constructed
+                planned_end = be.ctrl_peek_result(self._init_peek).t_plan
+                self._init_peek = None
             if planned_end is None and self._short_solves:
-                planned_end = t_last  # (the first attempt of a solve that is expected to be short: taken as its last)
+                planned_end = t_last  # (no copy of that block: a solve that is expected to be short takes its first attempt as its last)
             if to_end and planned_end is not None and d * planned_end >= d * t_last:
                 c = self._resolve_pending()  # this attempt ends the solve if it is accepted: do not speculate past it
                 if c.done:

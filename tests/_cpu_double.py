@@ -455,6 +455,12 @@ class NumpyDoubleBackend:
     def ctrl_read_async(self, ctrl):
         return self.ctrl_read(ctrl)
 
+    def ctrl_peek_async(self, ctrl):
+        return self.ctrl_read(ctrl)
+
+    def ctrl_peek_result(self, handle):
+        return handle
+
     def ctrl_wait(self, handle):
         return handle
 

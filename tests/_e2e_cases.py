@@ -1798,11 +1798,12 @@ def P_rms():
     return _rms_norm
 
 
-def test_lag_pipeline_does_not_speculate_past_the_end_of_a_solve(dev):
+def test_lag_pipeline_does_not_speculate_past_the_end_of_a_solve(dev, monkeypatch):
     """The speculative pipeline enqueues attempt n+1 before it knows attempt n's verdict — except at the end: the predecessor's block
     says where attempt n lands if accepted (`t_plan`), and when that is the last output time the host waits for the verdict first.
     So a solve of several attempts calls func exactly as often under "lag" as under "sync" (no discarded attempt), with the same
-    rows bit for bit; only a solve that ends within its first attempts, whose step size the host never saw, pays for one."""
+    rows bit for bit; so does a solve that ends with its FIRST attempt, whose step size was chosen on the device: a copy of the
+    freshly constructed block tells the host where it lands (switched off, that solve pays for one discarded attempt)."""
     from paddlexde_amd.xde import BaseODE
 
     A = P.skew_matrix(8).double().to(dev)
@@ -1824,13 +1825,16 @@ def test_lag_pipeline_does_not_speculate_past_the_end_of_a_solve(dev):
         assert got["sync"][3] >= 3  # (several attempts: the end is predictable)
         assert torch.equal(got["sync"][0], got["lag"][0])
         assert got["lag"][1] == got["sync"][1] == got["sync"][2] == got["lag"][2], got  # calls == nfe, identical under both pipelines
-    # a one-attempt solve: its only attempt's step size was chosen on the device, the host could not see the end coming
+    # a one-attempt solve: its only attempt's step size was chosen on the device
     t = torch.tensor([0.0, 1e-6], dtype=torch.float64)
-    calls[0] = 0
-    s = Dopri5(xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-8, atol=1e-10, norm=_rms_norm, dtype=torch.float64, pipeline="lag")
-    with torch.no_grad():
-        s.integrate(t)
-    assert s.stats["n_steps"] == 1 and calls[0] == s.stats["nfe"] + 6  # one speculative attempt ran for nothing, and is not counted
+    for peek, wasted in (("1", 0), ("0", 6)):
+        monkeypatch.setenv("XDE_SHORT_SOLVES", peek)
+        calls[0] = 0
+        s = Dopri5(xde=BaseODE(f, y0=y0, t_span=t), y0=y0, rtol=1e-8, atol=1e-10, norm=_rms_norm, dtype=torch.float64, pipeline="lag")
+        with torch.no_grad():
+            s.integrate(t)
+        # (switched off: one speculative attempt runs for nothing, and is not counted)
+        assert s.stats["n_steps"] == 1 and calls[0] == s.stats["nfe"] + wasted, (peek, calls[0], s.stats)
 
 
 @pytest.mark.parametrize("solver_name,dtype,n_out,t_end", [("dopri5", torch.float32, 9, 1.0), ("dopri5", torch.float64, 5, 6.0),
@@ -2058,3 +2062,11 @@ def test_adjoint_backward_under_lag_discards_no_attempt(dev):
     assert n_lag == n_sync == 6 * 8, (n_lag, n_sync)  # per interval: f0, the heuristic's probe, six stages (84 with a discarded attempt each)
     for a, b in zip(g_lag, g_sync):
         assert torch.equal(a, b)
+    # the same for any caller's one-step solve: the block the heuristic constructed says where the first attempt lands
+    sols = []
+    for pipeline in ("sync", "lag"):
+        Counting.calls = 0
+        with torch.no_grad():
+            sols.append(odeint(m, y0, t[:2], solver=Dopri5, rtol=1e-3, atol=1e-5, options={"norm": _rms_norm, "dtype": dtype, "pipeline": pipeline}))
+        assert Counting.calls == 3 + 6, (pipeline, Counting.calls)  # f0 twice (as the reference does), the probe, six stages
+    assert torch.equal(sols[0], sols[1])
