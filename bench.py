@@ -298,7 +298,7 @@ def side_workload(args):
             if name == "rk4":
                 opts["pipeline"] = "graph"  # forward: one captured RK4 step replayed over the 31 intervals
             if "pipeline" in aopts:
-                aopts["pipeline"] = "sync"  # adjoint intervals are 1-3 steps long: speculation would waste an attempt each
+                aopts["pipeline"] = "sync"  # adjoint intervals are 1-3 steps long: every attempt is resolved before the next (what the captured interval solve does anyway)
             if args.graph_func != "auto":
                 aopts["graph_func"] = args.graph_func == "on"
             pred = odeint_adjoint(func, y0, t, solver=solver, rtol=1e-5, atol=1e-7, options=opts, adjoint_options=aopts)
