@@ -344,10 +344,11 @@ class HipBackend:
 
     # -- host mirror ring of the control block (see xde_rk_control / xde_ctrl_wait) -------------
     class _Mirror:
-        __slots__ = ("ptr", "seq", "seq0")
+        __slots__ = ("ptr", "seq", "seq0", "peek")
 
         def __init__(self, ptr):
             self.ptr, self.seq, self.seq0 = ptr, 0, 0
+            self.peek = None  # ctrl_peek_async's pinned buffer + event (+ the device they were used on)
 
     def _acquire_mirror(self):
         if self._mirror_pool:
@@ -588,10 +589,16 @@ class HipBackend:
         """Enqueue a copy of the control block AS IT IS AT THIS POINT OF THE STREAM into pinned host memory (a freshly constructed block
         has no mirror slot); ``ctrl_peek_result(handle)`` waits for that copy only — not for anything enqueued after it."""
         self._require_device(ctrl)
-        host = torch.empty(C.sizeof(XdeCtrl), dtype=torch.uint8).pin_memory()
-        host.copy_(ctrl, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        m = self._mirrors.get(ctrl.data_ptr())
+        kept = m.peek if m is not None else None
+        if kept is None or kept[2] != ctrl.device:  # (kept with the block's mirror: control blocks are recycled between solves)
+            kept = (torch.empty(C.sizeof(XdeCtrl), dtype=torch.uint8).pin_memory(), torch.cuda.Event(), ctrl.device)
+            if m is not None:
+                m.peek = kept
+        host, ev = kept[0], kept[1]
+        with torch.cuda.device(ctrl.device):
+            host.copy_(ctrl, non_blocking=True)
+            ev.record()
         return (host, ev)
 
     def ctrl_peek_result(self, handle) -> XdeCtrl:
