@@ -412,6 +412,8 @@ int xde_history_gather(void* val_out, void* der_out, const void* his, const void
  * derivative_lags` summed over every axis but the lag axis; the history itself receives no gradient) — one launch, products formed
  * in `dtype`, accumulated in fp64 in a fixed order (bit-reproducible), result rounded to `dtype`.
  *   ws: xde_lag_grad_workspace_bytes(L) bytes of device memory, zero before the FIRST use (every launch leaves it re-armed).
+ *       It holds the arrival counters and partials of the launch IN FLIGHT: one workspace per stream — two launches may share one
+ *       only if they are ordered (same stream).  The Python binding keys its workspaces by (device, L, stream).
  */
 int64_t xde_lag_grad_workspace_bytes(int L);
 int xde_lag_grad(void* grad_lags_out, const void* grad_y, const void* der, int64_t outer, int D, int L, int dtype, void* ws, void* stream);

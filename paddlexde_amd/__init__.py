@@ -5,6 +5,6 @@ Python over ctypes with torch-ROCm tensors as device buffers.  There is no CPU f
 """
 __version__ = "0.1.0"
 
-from .functional import ddeint, ddeint_adjoint, odeint, odeint_adjoint  # noqa: F401
+from .functional import AdjointProblem, ddeint, ddeint_adjoint, odeint, odeint_adjoint  # noqa: F401
 from .solver import *  # noqa: F401,F403
 from .xde import BaseDDE, BaseODE, BaseXDE  # noqa: F401

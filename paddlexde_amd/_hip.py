@@ -339,7 +339,7 @@ class HipBackend:
         self._mirror_pool = []  # pinned host mirror rings, reused across solver instances
         self._mirrors = {}  # device ctrl pointer -> _Mirror
         self._work_pool = {}  # (device, state dtype, stream) -> free _Work sets
-        self._lag_ws = {}  # (device, L) -> workspace of xde_lag_grad (zeroed once; every launch leaves it re-armed)
+        self._lag_ws = {}  # (device, L, stream) -> workspace of xde_lag_grad (zeroed once; every launch leaves it re-armed)
         self._tls = threading.local()  # .capturing: this THREAD is recording a hipGraph (its launches do not execute)
 
     # -- host mirror ring of the control block (see xde_rk_control / xde_ctrl_wait) -------------
@@ -348,7 +348,7 @@ class HipBackend:
 
         def __init__(self, ptr):
             self.ptr, self.seq, self.seq0 = ptr, 0, 0
-            self.peek = None  # ctrl_peek_async's pinned buffer + event (+ the device they were used on)
+            self.peek = None  # ctrl_peek_async's pool of idle (pinned buffer, event, device) triples
 
     def _acquire_mirror(self):
         if self._mirror_pool:
@@ -585,26 +585,59 @@ class HipBackend:
         self._check(self.lib.xde_ctrl_read(ctrl.data_ptr(), C.byref(host), self._stream(ctrl)), "xde_ctrl_read")
         return host
 
+    PEEK_POOL_MAX = 4  # idle (buffer, event) pairs kept per control block's mirror
+
+    class _Peek:
+        """One enqueued copy of a control block: OWNS its pinned buffer and its event until ``ctrl_peek_result`` has consumed it (or the
+        handle is dropped); only then do they go back to the mirror's pool.  Any number of peeks may be pending on one block."""
+
+        __slots__ = ("host", "ev", "device", "pool", "__weakref__")
+
+        def __init__(self, host, ev, device, pool):
+            self.host, self.ev, self.device, self.pool = host, ev, device, pool
+
+        def _recycle(self):
+            host, ev, pool = self.host, self.ev, self.pool
+            self.host = self.ev = self.pool = None
+            if host is not None and pool is not None and len(pool) < HipBackend.PEEK_POOL_MAX:
+                pool.append((host, ev, self.device))
+
+        def __del__(self):  # a handle nobody read (a solve that ended before its second attempt): the pair is reusable all the same —
+            self._recycle()  # copies are stream-ordered, a later peek's copy and event land after this one's
+
     def ctrl_peek_async(self, ctrl):
         """Enqueue a copy of the control block AS IT IS AT THIS POINT OF THE STREAM into pinned host memory (a freshly constructed block
-        has no mirror slot); ``ctrl_peek_result(handle)`` waits for that copy only — not for anything enqueued after it."""
+        has no mirror slot); ``ctrl_peek_result(handle)`` waits for that copy only — not for anything enqueued after it.  Re-entrant:
+        every handle has a buffer and an event of its own until it is consumed; they are pooled with the block's mirror (control
+        blocks are recycled between solves), so a steady state of one peek per solve allocates nothing."""
         self._require_device(ctrl)
         m = self._mirrors.get(ctrl.data_ptr())
-        kept = m.peek if m is not None else None
-        if kept is None or kept[2] != ctrl.device:  # (kept with the block's mirror: control blocks are recycled between solves)
+        pool = None
+        if m is not None:
+            if m.peek is None:
+                m.peek = []
+            pool = m.peek
+        kept = None
+        while pool:
+            kept = pool.pop()
+            if kept[2] == ctrl.device:
+                break
+            kept = None
+        if kept is None:
             kept = (torch.empty(C.sizeof(XdeCtrl), dtype=torch.uint8).pin_memory(), torch.cuda.Event(), ctrl.device)
-            if m is not None:
-                m.peek = kept
         host, ev = kept[0], kept[1]
         with torch.cuda.device(ctrl.device):
             host.copy_(ctrl, non_blocking=True)
             ev.record()
-        return (host, ev)
+        return HipBackend._Peek(host, ev, ctrl.device, pool)
 
     def ctrl_peek_result(self, handle) -> XdeCtrl:
-        host, ev = handle
-        ev.synchronize()
-        return XdeCtrl.from_buffer_copy(host.numpy().tobytes())
+        if handle.host is None:
+            raise XdeError("ctrl_peek_result: this handle has been consumed already")
+        handle.ev.synchronize()
+        out = XdeCtrl.from_buffer_copy(handle.host.numpy().tobytes())
+        handle._recycle()
+        return out
 
     def ctrl_read_async(self, ctrl):
         """Handle for the control block of the newest controller launch; nothing is enqueued on the stream."""
@@ -667,7 +700,9 @@ class HipBackend:
         if L == 0 or outer == 0:
             return torch.zeros(L, dtype=der.dtype, device=der.device)
         out = torch.empty(L, dtype=der.dtype, device=der.device)
-        key = (der.device.index, L)
+        # per STREAM: the workspace holds the arrival counters and the partials of a launch in flight — two launches of the same L on
+        # different streams (autograd on a side stream, two models) must not meet on them; same-stream launches are ordered
+        key = (der.device.index, L, self._stream(der))
         ws = self._lag_ws.get(key)
         if ws is None:
             ws = self._lag_ws[key] = torch.zeros(int(self.lib.xde_lag_grad_workspace_bytes(L)), dtype=torch.uint8, device=der.device)

@@ -29,45 +29,55 @@ __device__ __forceinline__ T fuse_(T dy, T dt, T y0, T lam) {
 // ------------------------------------------------------------------------------------------
 // K1: stage combine
 // ------------------------------------------------------------------------------------------
-template <typename T, int MODE, int NK, bool VEC, bool OUT2, bool PRE = false>
+// LATE (adaptive stages on the 16-byte path, with a control block): the launch does NOT wait for the control block's `dt` / `accept`
+// words before its first loads.  The words are requested, then the first vector of every operand whose ADDRESS does not depend on
+// the speculative pipeline's select (k_1.., the pre-summed partial; all operands when the launch has no select) — and only then is
+// the select formed, y0 / k_0 loaded and the coefficients multiplied by dt: the block's memory round trip (cold in every launch: the
+// controller has just rewritten it) runs under the operands' own.  Same arithmetic, same order per element: same bits.
+//
+// NTP — the launch's cache policy, a COMPILE-TIME choice among three (round 5): 0 = default loads; 1 = every derivative k_j streamed
+// (non-temporal: this launch reads them for the last time in an accepted step — an FSAL pair's last stage), y0 default (the error
+// norm re-reads it); 2 = everything streamed (operands of >= 64 MiB: nothing survives in the Infinity Cache between uses).  Until
+// round 4 the policy was a run-time bit per operand: a branch around every load, and — where the two arms got different registers —
+// an `s_waitcnt vmcnt(0)` + register copies BETWEEN the loads of one iteration (NK = 6: five loads, wait, two loads), i.e. two
+// memory round trips per iteration instead of one.  A mask that is neither "none" nor "all" now takes policy 0.
+template <typename T, int MODE, int NK, bool VEC, bool OUT2, bool PRE = false, bool LATE = false, int NTP = 0>
 __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __restrict__ y0,
                                              const T* __restrict__ k0, T dt) {
   const T* __restrict__ pre = static_cast<const T*>(a.pre);
-  const unsigned ntm = unsigned(a.nt);  // bit j: stream operand k_j; bit 31: stream y0
   using P = Pack<T, VEC>;
+  auto ldk = [](const T* p, int64_t i) { return NTP >= 1 ? P::load_nt(p, i) : P::load(p, i); };
+  auto ldy = [](const T* p, int64_t i) { return NTP >= 2 ? P::load_nt(p, i) : P::load(p, i); };
   constexpr int W = P::W;
   T* __restrict__ out = static_cast<T*>(a.out);
   T* __restrict__ out2 = static_cast<T*>(a.out2);
   const T* kp[NK];
   T c[NK];
   T c2[NK];
+  double dtd = 0.0;
+  int32_t accw = 0;
+  if (LATE) {  // requested here, waited for below the first loads
+    dtd = __builtin_nontemporal_load(&a.ctrl->dt);
+    accw = __builtin_nontemporal_load(&a.ctrl->accept);
+  }
   kp[0] = k0;
 #pragma unroll
   for (int j = 1; j < NK; ++j) kp[j] = static_cast<const T*>(a.k[j]);
+  auto coefficients = [&]() {
 #pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    // reference: tableau cast to the state dtype, then `beta_i * dt` (RK) — or used as is (FUSE/WFUSE)
-    c[j] = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
-    c2[j] = OUT2 ? dt * T(a.coef2[j]) : T(0);  // `dt * tableau.c_error`
-  }
+    for (int j = 0; j < NK; ++j) {
+      // reference: tableau cast to the state dtype, then `beta_i * dt` (RK) — or used as is (FUSE/WFUSE)
+      c[j] = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+      c2[j] = OUT2 ? dt * T(a.coef2[j]) : T(0);  // `dt * tableau.c_error`
+    }
+  };
+  if (!LATE) coefficients();
   const T scale = T(a.scale);
   const T lam = T(a.damp);
   const int64_t nvec = a.n / W;
   const int64_t stride = int64_t(gridDim.x) * kBlock;
-  for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nvec; i += stride) {
-    // NT: with operands of >= 64 MiB nothing survives in the 256 MiB Infinity Cache between uses anyway; streaming
-    // loads then run 12-17 % faster (5.1 -> 5.8 TB/s at 128 MiB x 7 streams).  At the 32 MiB headline size the
-    // default policy wins by 18 % (the working set half-fits the cache), so the flag is size-dependent (host).
-    // Program order of the loads: the operands whose ADDRESS does not depend on the device-side select come first.  In the
-    // speculative pipeline y0 / k0 are picked by ctrl->accept, a scalar load that is still in flight when the wave starts;
-    // k_1.. can be requested meanwhile, so the select's memory round trip hides behind them (it cost ~0.9 us per launch).
-    P kk[NK];
-    P pr;
-    if (PRE) pr = P::load_nt(pre, i);  // (written by the previous stage's launch for this one alone: read once, streamed)
-#pragma unroll
-    for (int j = NK - 1; j >= 1; --j) kk[j] = load_sel<P>(kp[j], i, (ntm >> j) & 1u);
-    P y = load_sel<P>(y0, i, (ntm >> 31) & 1u);
-    kk[0] = load_sel<P>(kp[0], i, ntm & 1u);
+  // one vector's arithmetic and stores
+  auto finish = [&](int64_t i, const P (&kk)[NK], const P& pr, const P& y) {
     P o;
     P o2;
 #pragma unroll
@@ -97,6 +107,58 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
     }
     o.store(out, i);
     if (OUT2) o2.store(out2, i);
+  };
+  int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (LATE) {
+    // In a pre-summed stage k_0 is the stage's newest derivative, not the select-able f0: only y0 hangs on the select there.
+    constexpr int kFirstFree = PRE ? 0 : 1;
+    const bool have = i < nvec;
+    const bool no_select = !a.use_sel;  // (a kernel argument: a scalar branch, known before anything is loaded)
+    P kk[NK];
+    P pr;
+    P y;
+    if (have) {
+      if (PRE) pr = P::load_nt(pre, i);
+#pragma unroll
+      for (int j = NK - 1; j >= kFirstFree; --j) kk[j] = ldk(kp[j], i);
+      if (no_select) {
+        y = ldy(y0, i);
+        if (!PRE) kk[0] = ldk(kp[0], i);
+      }
+    }
+    // (pinned: the scheduler otherwise hoists the select — and with it the wait for the control block's words — above the loads)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!no_select) {
+      const int sel = accw ? 1 : 0;
+      y0 = static_cast<const T*>(a.y0[sel]);
+      if (!PRE) kp[0] = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+      if (have) {
+        y = ldy(y0, i);
+        if (!PRE) kk[0] = ldk(kp[0], i);
+      }
+    }
+    dt = T(dtd);
+    coefficients();
+    if (have) {
+      finish(i, kk, pr, y);
+      i += stride;
+    }
+  }
+  for (; i < nvec; i += stride) {
+    // NT: with operands of >= 64 MiB nothing survives in the 256 MiB Infinity Cache between uses anyway; streaming
+    // loads then run 12-17 % faster (5.1 -> 5.8 TB/s at 128 MiB x 7 streams).  At the 32 MiB headline size the
+    // default policy wins by 18 % (the working set half-fits the cache), so the flag is size-dependent (host).
+    // Program order of the loads: the operands whose ADDRESS does not depend on the device-side select come first.  In the
+    // speculative pipeline y0 / k0 are picked by ctrl->accept, a scalar load that is still in flight when the wave starts;
+    // k_1.. can be requested meanwhile, so the select's memory round trip hides behind them (it cost ~0.9 us per launch).
+    P kk[NK];
+    P pr;
+    if (PRE) pr = P::load_nt(pre, i);  // (written by the previous stage's launch for this one alone: read once, streamed)
+#pragma unroll
+    for (int j = NK - 1; j >= 1; --j) kk[j] = ldk(kp[j], i);
+    P y = ldy(y0, i);
+    kk[0] = ldk(kp[0], i);
+    finish(i, kk, pr, y);
   }
   if (VEC) {
     // scalar tail (n % W elements), done by the first threads of block 0
@@ -183,26 +245,38 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
 
 // OUT2 (second output, RK mode only) is a separate instantiation: its two accumulators per element would
 // otherwise raise the register budget of EVERY stage launch (62 -> 112 VGPRs, occupancy 8 -> 4 waves/SIMD)
-template <typename T, int MODE, bool VEC, bool OUT2>
+// (WIDE: the two-output launches are register-hungry — two accumulators per element on top of NK + 1 loads in flight — and a kernel's
+// allocation is that of its LARGEST case: with every operand count in one kernel the hot cases, Dopri5's 4- and 5-operand launches,
+// ran at the 7-operand case's 112 VGPRs = 4 waves per SIMD.  The two-output kernel therefore exists twice: up to 5 operands, and beyond.)
+template <typename T, int MODE, bool VEC, bool OUT2, bool LATE = false, int NTP = 0, bool WIDE = false>
 __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
   int sel = 0;
-  T dt;
-  if (a.ctrl) {
-    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
-  } else {
-    dt = T(a.dt_host);
+  T dt = T(0);
+  if (!LATE) {  // (LATE: combine_body reads the control block itself, behind its first loads)
+    if (a.ctrl) {
+      read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
+    } else {
+      dt = T(a.dt_host);
+    }
   }
   const T* y0 = static_cast<const T*>(a.y0[sel]);
   const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
+  constexpr bool kLow = !(OUT2 && WIDE);   // this kernel holds the cases of 1..5 operands
+  constexpr bool kHigh = !OUT2 || WIDE;    // ... and those of 6, 7 and more
   switch (a.nk) {
-    case 1: combine_body<T, MODE, 1, VEC, OUT2>(a, y0, k0, dt); break;
-    case 2: combine_body<T, MODE, 2, VEC, OUT2>(a, y0, k0, dt); break;
-    case 3: combine_body<T, MODE, 3, VEC, OUT2>(a, y0, k0, dt); break;
-    case 4: combine_body<T, MODE, 4, VEC, OUT2>(a, y0, k0, dt); break;
-    case 5: combine_body<T, MODE, 5, VEC, OUT2>(a, y0, k0, dt); break;
-    case 6: combine_body<T, MODE, 6, VEC, OUT2>(a, y0, k0, dt); break;
-    case 7: combine_body<T, MODE, 7, VEC, OUT2>(a, y0, k0, dt); break;
-    default: combine_generic<T, MODE, VEC, OUT2>(a, y0, k0, dt); break;
+    case 1: if (kLow) combine_body<T, MODE, 1, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
+    case 2: if (kLow) combine_body<T, MODE, 2, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
+    case 3: if (kLow) combine_body<T, MODE, 3, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
+    case 4: if (kLow) combine_body<T, MODE, 4, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
+    case 5: if (kLow) combine_body<T, MODE, 5, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
+    case 6: if (kHigh) combine_body<T, MODE, 6, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
+    case 7: if (kHigh) combine_body<T, MODE, 7, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
+    default:
+      if (kHigh) {
+        if (LATE) read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
+        combine_generic<T, MODE, VEC, OUT2>(a, static_cast<const T*>(a.y0[sel]), static_cast<const T*>(sel ? a.k0_alt : a.k[0]), dt);
+      }
+      break;
   }
 }
 
@@ -210,22 +284,24 @@ __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
 // `sum_j k_j (beta_ij dt)` over them as its second output): this launch reads y0, that partial sum and the newest derivative(s) —
 // Dopri5's stage 5: 3 arrays in, 1 out, instead of 6 in, 1 out; the emitting launch writes one array more.  Same left-to-right
 // association as the full sum (`((..) + k_3 c_3) + k_4 c_4`, then `y0 +`): bit-identical.  Its own instantiation (registers).
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool LATE = false, int NTP = 0>
 __global__ __launch_bounds__(kBlock) void xde_combine_pre_kernel(CombineArgs a) {
   int sel = 0;
-  T dt;
-  if (a.ctrl) {
-    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
-  } else {
-    dt = T(a.dt_host);
+  T dt = T(0);
+  if (!LATE) {
+    if (a.ctrl) {
+      read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
+    } else {
+      dt = T(a.dt_host);
+    }
   }
   const T* y0 = static_cast<const T*>(a.y0[sel]);
   const T* k0 = static_cast<const T*>(a.k[0]);  // (not the select-able f0: the operands here are the stage's NEWEST derivatives)
   switch (a.nk) {
-    case 1: combine_body<T, XDE_COMBINE_RK, 1, VEC, false, true>(a, y0, k0, dt); break;
-    case 2: combine_body<T, XDE_COMBINE_RK, 2, VEC, false, true>(a, y0, k0, dt); break;
-    case 3: combine_body<T, XDE_COMBINE_RK, 3, VEC, false, true>(a, y0, k0, dt); break;
-    default: combine_body<T, XDE_COMBINE_RK, 4, VEC, false, true>(a, y0, k0, dt); break;
+    case 1: combine_body<T, XDE_COMBINE_RK, 1, VEC, false, true, LATE, NTP>(a, y0, k0, dt); break;
+    case 2: combine_body<T, XDE_COMBINE_RK, 2, VEC, false, true, LATE, NTP>(a, y0, k0, dt); break;
+    case 3: combine_body<T, XDE_COMBINE_RK, 3, VEC, false, true, LATE, NTP>(a, y0, k0, dt); break;
+    default: combine_body<T, XDE_COMBINE_RK, 4, VEC, false, true, LATE, NTP>(a, y0, k0, dt); break;
   }
 }
 
@@ -359,8 +435,12 @@ static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, con
   if (pre) vec = vec && aligned16(pre);
   if (damping != 0.0 && mode == XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: damping applies to FUSE/WFUSE");
   a.damp = damping;
-  // operands far larger than the Infinity Cache: stream everything; otherwise only what the caller marks as last use
-  a.nt = big_operand(n, dtype) ? int(0xFFFFFFFFu) : ((nt_policy() & 4) ? int(nt_mask) : 0);
+  // cache policy of the launch (combine_body, NTP): operands far larger than the Infinity Cache -> stream everything; the caller marks
+  // EVERY derivative as read for the last time (bits 0..nk-1 of nt_mask; bit 31: y0 too) -> stream those; anything else -> default
+  int ntp = 0;
+  if (big_operand(n, dtype)) ntp = 2;
+  else if ((nt_policy() & 4) && nk < 32 && (nt_mask & ((1u << nk) - 1u)) == ((1u << nk) - 1u)) ntp = (nt_mask >> 31) ? 2 : 1;
+  a.nt = ntp;
   a.scale = scale;
   a.dt_host = dt_host;
   a.ctrl = ctrl;
@@ -376,31 +456,59 @@ static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, con
   const int kid = mode == XDE_COMBINE_RK ? XDE_KID_COMBINE : (mode == XDE_COMBINE_FUSE ? XDE_KID_COMBINE_FUSE : XDE_KID_COMBINE_WFUSE);
   ProfScope prof(kid, double(nk + 2 + (out2 ? 1 : 0) + (pre ? 1 : 0)) * double(n) * elt);
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
-#define LAUNCH_COMBINE(T, MODE)                                                       \
-  do {                                                                                \
-    if (vec)                                                                          \
-      XDE_LAUNCH((xde_combine_kernel<T, MODE, true, false>), g, b, st, prof, a);      \
-    else                                                                              \
-      XDE_LAUNCH((xde_combine_kernel<T, MODE, false, false>), g, b, st, prof, a);     \
+  // adaptive stages with a control block on the 16-byte path: the launch reads the block behind its first loads (combine_body, LATE)
+  static const bool late_ok = env_int("XDE_COMBINE_LATE", 1) != 0;  // (0: the block is read first, as before round 5 — for A/B runs)
+  const bool late = late_ok && vec && ctrl != nullptr && mode == XDE_COMBINE_RK && nk <= 7;
+  if (!vec) ntp = 0;  // (element-wise path: unaligned views, never the hot path)
+#define L_(...) XDE_LAUNCH((__VA_ARGS__), g, b, st, prof, a)
+// the three cache policies of a kernel whose other template arguments are fixed (policy 1 exists on the LATE kernels only: it is the
+// adaptive solver's hint, and that solver always passes a control block)
+#define L_NTP3(PFX, ...)                          \
+  do {                                            \
+    if (ntp == 2) L_(PFX<__VA_ARGS__, 2>);        \
+    else if (ntp == 1) L_(PFX<__VA_ARGS__, 1>);   \
+    else L_(PFX<__VA_ARGS__, 0>);                 \
   } while (0)
-#define LAUNCH_COMBINE2(T)                                                                   \
-  do {                                                                                       \
-    if (vec)                                                                                 \
-      XDE_LAUNCH((xde_combine_kernel<T, XDE_COMBINE_RK, true, true>), g, b, st, prof, a);    \
-    else                                                                                     \
-      XDE_LAUNCH((xde_combine_kernel<T, XDE_COMBINE_RK, false, true>), g, b, st, prof, a);   \
+#define L_NTP2(PFX, ...)                          \
+  do {                                            \
+    if (ntp == 2) L_(PFX<__VA_ARGS__, 2>);        \
+    else L_(PFX<__VA_ARGS__, 0>);                 \
+  } while (0)
+#define LAUNCH_COMBINE(T, MODE)                                        \
+  do {                                                                 \
+    if (vec) L_NTP2(xde_combine_kernel, T, MODE, true, false, false);  \
+    else L_(xde_combine_kernel<T, MODE, false, false>);                \
+  } while (0)
+#define L_NTP3W(PFX, ...)                              \
+  do {                                                 \
+    if (ntp == 2) L_(PFX<__VA_ARGS__, 2, true>);       \
+    else if (ntp == 1) L_(PFX<__VA_ARGS__, 1, true>);  \
+    else L_(PFX<__VA_ARGS__, 0, true>);                \
+  } while (0)
+#define LAUNCH_COMBINE2(T)                                                                       \
+  do {                                                                                           \
+    if (late && nk <= 5) L_NTP3(xde_combine_kernel, T, XDE_COMBINE_RK, true, true, true);        \
+    else if (late) L_NTP3W(xde_combine_kernel, T, XDE_COMBINE_RK, true, true, true);             \
+    else if (vec && nk <= 5) L_NTP2(xde_combine_kernel, T, XDE_COMBINE_RK, true, true, false);   \
+    else if (vec) L_(xde_combine_kernel<T, XDE_COMBINE_RK, true, true, false, 0, true>);         \
+    else if (nk <= 5) L_(xde_combine_kernel<T, XDE_COMBINE_RK, false, true>);                    \
+    else L_(xde_combine_kernel<T, XDE_COMBINE_RK, false, true, false, 0, true>);                 \
+  } while (0)
+#define LAUNCH_PRE(T)                                              \
+  do {                                                             \
+    if (late) L_NTP3(xde_combine_pre_kernel, T, true, true);       \
+    else if (vec) L_NTP2(xde_combine_pre_kernel, T, true, false);  \
+    else L_(xde_combine_pre_kernel<T, false>);                     \
   } while (0)
   if (pre) {
-    if (dtype == XDE_F32) {
-      if (vec) XDE_LAUNCH((xde_combine_pre_kernel<float, true>), g, b, st, prof, a);
-      else XDE_LAUNCH((xde_combine_pre_kernel<float, false>), g, b, st, prof, a);
-    } else {
-      if (vec) XDE_LAUNCH((xde_combine_pre_kernel<double, true>), g, b, st, prof, a);
-      else XDE_LAUNCH((xde_combine_pre_kernel<double, false>), g, b, st, prof, a);
-    }
+    if (dtype == XDE_F32) LAUNCH_PRE(float);
+    else LAUNCH_PRE(double);
   } else if (out2) {
     if (dtype == XDE_F32) LAUNCH_COMBINE2(float);
     else LAUNCH_COMBINE2(double);
+  } else if (late) {
+    if (dtype == XDE_F32) L_NTP3(xde_combine_kernel, float, XDE_COMBINE_RK, true, false, true);
+    else L_NTP3(xde_combine_kernel, double, XDE_COMBINE_RK, true, false, true);
   } else if (dtype == XDE_F32) {
     if (mode == XDE_COMBINE_RK) LAUNCH_COMBINE(float, XDE_COMBINE_RK);
     else if (mode == XDE_COMBINE_FUSE) LAUNCH_COMBINE(float, XDE_COMBINE_FUSE);
@@ -410,6 +518,11 @@ static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, con
     else if (mode == XDE_COMBINE_FUSE) LAUNCH_COMBINE(double, XDE_COMBINE_FUSE);
     else LAUNCH_COMBINE(double, XDE_COMBINE_WFUSE);
   }
+#undef LAUNCH_PRE
+#undef L_NTP2
+#undef L_NTP3W
+#undef L_NTP3
+#undef L_
 #undef LAUNCH_COMBINE
 #undef LAUNCH_COMBINE2
   HIP_TRY(hipGetLastError());

@@ -145,11 +145,18 @@ __global__ __launch_bounds__(kBlock) void xde_rows_gather_kernel(T* __restrict__
 // ------------------------------------------------------------------------------------------
 // HistoryIndex.backward: grad_lags[l] = sum_{o, d} grad_y[o, l, d] * der[o, l, d]
 // ------------------------------------------------------------------------------------------
-// Grid = L x nb workgroups; workgroup (l, b) walks the rows o = b, b + nb, ... of lag l (each row is D contiguous elements), sums
-// the products (formed in T, as the reference's `grad_y * derivative_lags`; accumulated in fp64), and leaves one partial; the last
-// workgroup to arrive (agent-scope ticket) adds the nb partials of every lag in a fixed order (lane-strided, then a shuffle tree):
-// bit-reproducible, one launch.
+// Products are formed in T (the reference's `grad_y * derivative_lags`) and accumulated in fp64; every workgroup leaves one partial
+// per lag it worked on, the last workgroup to arrive (agent-scope tickets, two levels) adds the partials of every lag in a fixed
+// order (lane-strided, then a shuffle tree): bit-reproducible, one launch.  Two mappings of the [outer, L, D] tensors onto lanes:
+//
+//   PLANE  (one [L, D] plane fits a workgroup: L * D/W <= 256 lanes — D3STN's 12 x 64): the tensors are walked as ONE contiguous
+//          stream of 16-byte vectors; a workgroup's pass covers R whole planes, so a lane keeps the same (lag, column) in every pass
+//          and needs one accumulator.  Contiguous 3 KB bursts instead of 256-byte rows 3 KB apart, kPlaneUnroll passes' loads in
+//          flight per lane (guarded: the tail is not a serial loop), nb arrivals instead of L * nb.
+//   ROWS   (larger planes): workgroup (l, b) walks the rows o = b, b + nb, ... of lag l; rows longer than a workgroup's reach
+//          (D/W > 256, or an unaligned D > 256) are walked in strides of the row lanes — any D is served.
 constexpr int kLagShards = 16;  // first-level arrival counters (one atomic word serialises its arrivals at ~12 ns each)
+constexpr int kPlaneUnroll = 4;
 struct LagGradWs {
   unsigned ticket;
   unsigned pad[31];
@@ -160,53 +167,16 @@ struct LagGradWs {
   double partial[1];  // [L][nb]
 };
 
-template <typename T, bool VEC>
-__global__ __launch_bounds__(kBlock) void xde_lag_grad_kernel(T* __restrict__ out, const T* __restrict__ gy, const T* __restrict__ der,
-                                                              int64_t outer, int D, int L, int nb, LagGradWs* ws) {
-  using P = Pack<T, VEC>;
-  constexpr int W = P::W;
-  __shared__ double s_w[kWaves];
-  __shared__ int s_last;
-  const int l = blockIdx.x / nb, b = blockIdx.x % nb;
-  const int DV = D / W;
-  const int rows_per_pass = kBlock / DV > 0 ? kBlock / DV : 1;  // host guarantees DV <= kBlock on this path
-  const int my_row = threadIdx.x / DV, dv = threadIdx.x % DV;
-  double acc = 0.0;
-  if (my_row < rows_per_pass) {
-    const int64_t step = int64_t(nb) * rows_per_pass;
-    int64_t o = int64_t(b) * rows_per_pass + my_row;
-    for (; o + 3 * step < outer; o += 4 * step) {  // four rows' loads in flight per lane
-      P a[4], c[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t e = ((o + u * step) * L + l) * DV + dv;
-        a[u] = P::load_nt(gy, e);
-        c[u] = P::load_nt(der, e);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int x = 0; x < W; ++x) acc += double(a[u].v[x] * c[u].v[x]);
-    }
-    for (; o < outer; o += step) {
-      const int64_t e = (o * L + l) * DV + dv;
-      const P a = P::load_nt(gy, e);
-      const P c = P::load_nt(der, e);
-#pragma unroll
-      for (int x = 0; x < W; ++x) acc += double(a.v[x] * c.v[x]);
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
-  __syncthreads();
+__device__ __forceinline__ void lag_store_partial(LagGradWs* ws, int64_t at, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(&ws->partial[at]), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has left this CU before the ticket is taken
+}
+
+// Arrival of this workgroup (all its partials stored and waited for, barrier passed); the LAST one of the grid finishes every lag.
+template <typename T>
+__device__ __forceinline__ void lag_finish(T* __restrict__ out, int L, int nb, LagGradWs* ws, int* s_last) {
   if (threadIdx.x == 0) {
-    double v = s_w[0];
-#pragma unroll
-    for (int w = 1; w < kWaves; ++w) v += s_w[w];
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&ws->partial[int64_t(l) * nb + b]), (unsigned long long)__double_as_longlong(v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has left this CU before the ticket is taken
     // two-level arrival: workgroups b, b + 16, ... share a counter; the last arriver of a shard arrives at the top-level one
     const unsigned nsh = gridDim.x < unsigned(kLagShards) ? gridDim.x : unsigned(kLagShards);
     const unsigned sh = blockIdx.x % nsh;
@@ -214,10 +184,10 @@ __global__ __launch_bounds__(kBlock) void xde_lag_grad_kernel(T* __restrict__ ou
     int last = 0;
     if (__hip_atomic_fetch_add(&ws->shard[sh].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1)
       last = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1 ? 1 : 0;
-    s_last = last;
+    *s_last = last;
   }
   __syncthreads();
-  if (!s_last) return;
+  if (!*s_last) return;
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -239,11 +209,118 @@ __global__ __launch_bounds__(kBlock) void xde_lag_grad_kernel(T* __restrict__ ou
   if (threadIdx.x == 0) __hip_atomic_store(&ws->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-inline int lag_grad_blocks(int64_t outer, int D, int L, int width) {
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_lag_grad_plane_kernel(T* __restrict__ out, const T* __restrict__ gy, const T* __restrict__ der,
+                                                                    int64_t outer, int D, int L, int R, int nb, LagGradWs* ws) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  __shared__ double s_acc[kBlock];
+  __shared__ int s_last;
+  const int DV = D / W;
+  const int plane = L * DV;          // vectors of one [L, D] plane
+  const int active = R * plane;      // lanes at work: R whole planes per pass (<= kBlock)
+  const int64_t total = outer * int64_t(plane);
+  const int64_t step = int64_t(nb) * active;
+  double acc = 0.0;
+  if (int(threadIdx.x) < active) {
+    // every pass's loads are requested before any product is formed; a pass beyond the end loads nothing (wave-uniform up to the
+    // very last vectors) — the tail costs no extra round trip
+    for (int64_t v0 = int64_t(blockIdx.x) * active + threadIdx.x; v0 < total; v0 += kPlaneUnroll * step) {
+      P a[kPlaneUnroll], c[kPlaneUnroll];
+      bool on[kPlaneUnroll];
+#pragma unroll
+      for (int u = 0; u < kPlaneUnroll; ++u) {
+        const int64_t v = v0 + u * step;
+        on[u] = v < total;
+        if (on[u]) {
+          a[u] = P::load_nt(gy, v);
+          c[u] = P::load_nt(der, v);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kPlaneUnroll; ++u)
+        if (on[u]) {
+#pragma unroll
+          for (int x = 0; x < W; ++x) acc += double(a[u].v[x] * c[u].v[x]);
+        }
+    }
+  }
+  s_acc[threadIdx.x] = acc;
+  __syncthreads();
+  if (int(threadIdx.x) < L) {  // lag l: its DV columns of each of the R planes, in a fixed order
+    double v = 0.0;
+    for (int r = 0; r < R; ++r)
+      for (int d = 0; d < DV; ++d) v += s_acc[r * plane + int(threadIdx.x) * DV + d];
+    lag_store_partial(ws, int64_t(threadIdx.x) * nb + blockIdx.x, v);
+  }
+  __syncthreads();
+  lag_finish<T>(out, L, nb, ws, &s_last);
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_lag_grad_rows_kernel(T* __restrict__ out, const T* __restrict__ gy, const T* __restrict__ der,
+                                                                   int64_t outer, int D, int L, int nb, LagGradWs* ws) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  __shared__ double s_w[kWaves];
+  __shared__ int s_last;
+  const int l = blockIdx.x / nb, b = blockIdx.x % nb;
+  const int DV = D / W;
+  const int row_lanes = DV < kBlock ? DV : kBlock;  // lanes that share one row; a longer row is walked in strides of them
+  const int rows_per_pass = kBlock / row_lanes;
+  const int my_row = threadIdx.x / row_lanes, dv0 = threadIdx.x % row_lanes;
+  double acc = 0.0;
+  if (my_row < rows_per_pass) {
+    const int64_t step = int64_t(nb) * rows_per_pass;
+    for (int64_t o = int64_t(b) * rows_per_pass + my_row; o < outer; o += step) {
+      const int64_t row = (o * L + l) * DV;
+      for (int dv = dv0; dv < DV; dv += row_lanes) {
+        const P a = P::load_nt(gy, row + dv);
+        const P c = P::load_nt(der, row + dv);
+#pragma unroll
+        for (int x = 0; x < W; ++x) acc += double(a.v[x] * c.v[x]);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = s_w[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) v += s_w[w];
+    lag_store_partial(ws, int64_t(l) * nb + b, v);
+  }
+  __syncthreads();
+  lag_finish<T>(out, L, nb, ws, &s_last);
+}
+
+constexpr int kLagMaxBlocksPerLag = 2048;  // (the workspace holds L x 2048 partials)
+
+// PLANE mapping: planes per pass and workgroups.  R whole planes share a workgroup's pass, but no more than 64 / DV of them — the
+// per-lag sum over a workgroup's lanes is a serial walk of R * DV LDS words by one thread per lag.
+inline void lag_plane_shape(int64_t outer, int plane, int DV, int* R_out, int* nb_out) {
+  int R = kBlock / plane;
+  const int cap_r = 64 / DV > 0 ? 64 / DV : 1;
+  if (R > cap_r) R = cap_r;
+  if (R < 1) R = 1;
+  if (int64_t(R) > outer) R = int(outer > 0 ? outer : 1);
+  const int64_t passes = (outer + R - 1) / R;  // one pass per workgroup at most ...
+  static const int cap = env_int("XDE_LAG_GRID", 1024);  // ... and ~1024 workgroups: several passes (all in flight) per lane
+  int64_t nb = passes < cap ? passes : cap;
+  if (nb > kLagMaxBlocksPerLag) nb = kLagMaxBlocksPerLag;
+  if (nb < 1) nb = 1;
+  *R_out = R;
+  *nb_out = int(nb);
+}
+
+inline int lag_rows_blocks(int64_t outer, int D, int L, int width) {
   const int DV = D / width > 0 ? D / width : 1;
-  const int rows_per_pass = kBlock / DV > 0 ? kBlock / DV : 1;
+  const int row_lanes = DV < kBlock ? DV : kBlock;
+  const int rows_per_pass = kBlock / row_lanes;
   int64_t want = (outer + rows_per_pass - 1) / rows_per_pass;  // one pass per workgroup at most
-  int64_t cap = 1024 / (L > 0 ? L : 1);  // ~1024 workgroups in all: every lane then runs several (unrolled) row passes
+  int64_t cap = 1024 / (L > 0 ? L : 1);  // ~1024 workgroups in all
   if (cap < 1) cap = 1;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -306,24 +383,33 @@ int xde_lag_grad(void* grad_lags_out, const void* grad_y, const void* der, int64
   if (L > 2048) return fail(XDE_EBADARG, "xde_lag_grad: at most 2048 lags per launch");
   if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_lag_grad: bad dtype");
   const int width = dtype == XDE_F32 ? 4 : 2;
-  const bool vec = (D % width) == 0 && D / width <= kBlock && aligned16(grad_y) && aligned16(der);
-  if (!vec && D > kBlock) return fail(XDE_EBADARG, "xde_lag_grad: rows longer than 256 elements need a 16-byte-aligned, vector-multiple D");
-  const int nb = lag_grad_blocks(outer, D, L, vec ? width : 1);
+  // 16-byte vectors when rows are a whole number of them and both tensors are aligned; any other D / alignment is served element-wise
+  const bool vec = (D % width) == 0 && aligned16(grad_y) && aligned16(der);
+  const int DV = vec ? D / width : D;
+  const bool plane = int64_t(L) * DV <= kBlock;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_DENSE, 2.0 * double(outer) * L * D * (dtype == XDE_F32 ? 4.0 : 8.0));
-  dim3 g(static_cast<unsigned>(L * nb)), b(kBlock);
-#define LAUNCH_LG(TY)                                                                                                        \
-  do {                                                                                                                       \
-    if (vec)                                                                                                                 \
-      XDE_LAUNCH((xde_lag_grad_kernel<TY, true>), g, b, st, prof, static_cast<TY*>(grad_lags_out), static_cast<const TY*>(grad_y), \
-                 static_cast<const TY*>(der), outer, D, L, nb, static_cast<LagGradWs*>(ws));                                    \
-    else                                                                                                                     \
-      XDE_LAUNCH((xde_lag_grad_kernel<TY, false>), g, b, st, prof, static_cast<TY*>(grad_lags_out), static_cast<const TY*>(grad_y), \
-                 static_cast<const TY*>(der), outer, D, L, nb, static_cast<LagGradWs*>(ws));                                    \
-  } while (0)
-  if (dtype == XDE_F32) LAUNCH_LG(float);
-  else LAUNCH_LG(double);
-#undef LAUNCH_LG
+  dim3 b(kBlock);
+  if (plane) {
+    int R = 1, nb = 1;
+    lag_plane_shape(outer, L * DV, DV, &R, &nb);
+    dim3 g(static_cast<unsigned>(nb));
+#define LAUNCH_LP(TY, V)                                                                                                              \
+  XDE_LAUNCH((xde_lag_grad_plane_kernel<TY, V>), g, b, st, prof, static_cast<TY*>(grad_lags_out), static_cast<const TY*>(grad_y), \
+             static_cast<const TY*>(der), outer, D, L, R, nb, static_cast<LagGradWs*>(ws))
+    if (dtype == XDE_F32) { if (vec) LAUNCH_LP(float, true); else LAUNCH_LP(float, false); }
+    else { if (vec) LAUNCH_LP(double, true); else LAUNCH_LP(double, false); }
+#undef LAUNCH_LP
+  } else {
+    const int nb = lag_rows_blocks(outer, D, L, vec ? width : 1);
+    dim3 g(static_cast<unsigned>(L * nb));
+#define LAUNCH_LR(TY, V)                                                                                                             \
+  XDE_LAUNCH((xde_lag_grad_rows_kernel<TY, V>), g, b, st, prof, static_cast<TY*>(grad_lags_out), static_cast<const TY*>(grad_y), \
+             static_cast<const TY*>(der), outer, D, L, nb, static_cast<LagGradWs*>(ws))
+    if (dtype == XDE_F32) { if (vec) LAUNCH_LR(float, true); else LAUNCH_LR(float, false); }
+    else { if (vec) LAUNCH_LR(double, true); else LAUNCH_LR(double, false); }
+#undef LAUNCH_LR
+  }
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

@@ -155,6 +155,30 @@ def _vjp_of(evaluate, t, y, wrt_params, cotangent, time_grad, retain):
     return f.detach(), filled[0], filled[1], filled[2:]
 
 
+def _vjp_through_hook(hook, t, y, wrt_params, cotangent):
+    """The same four results from the CALLER's vector-Jacobian product, ``adjoint_options["vjp"]``: ``hook(t, y, cotangent) -> (f,
+    vjp_t, vjp_y, *vjp_params)`` with ``vjp_* = cotangent^T df/d*`` (linear in the cotangent), one entry per adjoint parameter in
+    their order; ``None`` stands for a gradient that is identically zero (the time adjoint of an autonomous func).  This is where a
+    func of another framework is differentiated BY that framework (the reference's own arrangement: ``paddle.autograd.grad``,
+    :108-114) — or where a hand-written / fused vjp replaces ~30 autograd launches; nothing of torch's autograd runs."""
+    out = tuple(hook(t, y, cotangent))
+    if len(out) != _N_LEADING + len(wrt_params):
+        raise ValueError("adjoint_options['vjp'] must return (f, vjp_t, vjp_y, *vjp_params) with one entry per adjoint parameter: "
+                         "expected {} values, got {}".format(_N_LEADING + len(wrt_params), len(out)))
+    f, vjp_t, vjp_y, *vjp_params = out
+    if f is None or vjp_y is None:
+        raise ValueError("adjoint_options['vjp'] returned None for f or vjp_y")
+    if tuple(f.shape) != tuple(y.shape) or tuple(vjp_y.shape) != tuple(y.shape):
+        raise ValueError("adjoint_options['vjp']: f and vjp_y must have the state's shape {}, got {} and {}".format(
+            tuple(y.shape), tuple(f.shape), tuple(vjp_y.shape)))
+    for p, g in zip(wrt_params, vjp_params):
+        if g is not None and g.numel() != p.numel():
+            raise ValueError("adjoint_options['vjp']: a parameter vjp has {} elements, its parameter {}".format(g.numel(), p.numel()))
+    vjp_t = _zeros_like(t) if vjp_t is None else vjp_t.reshape(())
+    filled = [_zeros_like(p) if g is None else g.detach() for p, g in zip(wrt_params, vjp_params)]
+    return f.detach(), vjp_t.detach(), vjp_y.detach(), filled
+
+
 # (shape, dtype, device) -> a zero tensor that is only ever READ: the stand-in for a gradient autograd did not produce (the time
 # adjoint of an autonomous func, on every evaluation).  A bounded, least-recently-used cache (a handful of shapes per model; a
 # process that walks through many models or batch shapes does not keep every zero it ever needed).  A captured HIP graph bakes in
@@ -187,17 +211,22 @@ def _negated_vjp(vjp_t, f, vjp_y, vjp_params):
     return ScaledTuple.of(members, [-1.0, 1.0, -1.0] + [-1.0] * len(vjp_params))
 
 
-def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, reduce_params=False):
+def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, reduce_params=False, vjp=None):
     """``d/dt (adj_t, y, adj_y, adj_theta) = (vjp_t, f, vjp_y, vjp_theta)`` with the cotangent ``-adj_y`` (taken as ``+adj_y`` and
     negated while the result is packed, see ``_negated_vjp``); only ``y`` and ``adj_y`` are read from the state.
 
     Batch-sharded run (``pg``): ``f`` and ``vjp_y`` are per-row quantities of this rank's rows, ``vjp_t`` and ``vjp_theta`` are
     sums over rows.  Where the step control looks at them — ``adj_t`` when time gradients are wanted, the parameter adjoints under
     the default adjoint norm (``reduce_params``) — they are summed over the group here, so that every rank integrates the GLOBAL
-    ``adj_t`` / ``adj_theta`` and the all-reduced norm is exactly the unsharded one."""
+    ``adj_t`` / ``adj_theta`` and the all-reduced norm is exactly the unsharded one.
+
+    ``vjp``: the caller's vector-Jacobian product instead of torch autograd (``_vjp_through_hook``)."""
 
     def augmented_dynamics(t, y_aug):
-        f, vjp_t, vjp_y, vjp_params = _vjp_of(func, t, y_aug[1], adjoint_params, y_aug[2], t_requires_grad, retain=True)
+        if vjp is not None:  # the caller's own vector-Jacobian product (adjoint_options["vjp"])
+            f, vjp_t, vjp_y, vjp_params = _vjp_through_hook(vjp, t, y_aug[1], adjoint_params, y_aug[2])
+        else:
+            f, vjp_t, vjp_y, vjp_params = _vjp_of(func, t, y_aug[1], adjoint_params, y_aug[2], t_requires_grad, retain=True)
         if pg is not None:
             shared = ([vjp_t] if t_requires_grad else []) + (list(vjp_params) if reduce_params else [])
             if shared:
@@ -348,6 +377,17 @@ def _interval_key(solver, rtol, atol, options, direction, t_dtype=None):
     return (solver, float(rtol), float(atol), int(direction), tuple(sorted(items, key=lambda kv: kv[0])))
 
 
+def _first_sweep_interval(t_host):
+    """The backward sweep's first interval that is not empty — ``(t[i], t[i-1])`` walking back from the end — or None when every
+    output time is the same.  Its direction is the sweep's: an output time repeated at the END (``t = [0, 1, 1]``) must not make a
+    backward sweep look like a forward one."""
+    times = t_host.tolist()
+    for i in range(len(times) - 1, 0, -1):
+        if times[i] != times[i - 1]:
+            return (times[i], times[i - 1])
+    return None
+
+
 def _prepare_intervals(graphed, flat_ex, segs, shapes, t_span, adjoint_solver, rtol, atol, adjoint_options):
     """Build (once per key) the re-armable solver the backward sweep runs its intervals on.  Called where the dynamics is captured:
     on the main thread, outside the autograd node."""
@@ -360,8 +400,8 @@ def _prepare_intervals(graphed, flat_ex, segs, shapes, t_span, adjoint_solver, r
     if len(t_span) < 2 or _interval_key(adjoint_solver, rtol, atol, opts, 1, t_span.dtype) is None:
         return
     t_host = t_span.detach().to("cpu")
-    span = (t_host[-1].item(), t_host[-2].item())  # the sweep's first interval
-    if span[0] == span[1]:
+    span = _first_sweep_interval(t_host)
+    if span is None:
         return
     key = _interval_key(adjoint_solver, rtol, atol, opts, direction_of(span), t_host.dtype)
     cache = graphed.__dict__.setdefault("_intervals", {})
@@ -391,7 +431,40 @@ def _prepare_intervals(graphed, flat_ex, segs, shapes, t_span, adjoint_solver, r
     cache[key] = entry
 
 
-def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoint_params, rtol=None, atol=None):
+def _weak_hook(vjp):
+    """``vjp`` behind a weak reference, for a capture that is cached ON the hook's owner (what the cache stores must not keep its own
+    key alive); the backward plan holds the hook itself for as long as a backward pass can still run."""
+    inner = getattr(vjp, "__wrapped__", None)  # utils.interop.adapt_vjp(hook, importer): the user's hook is the thing to watch
+    importer = getattr(vjp, "_from_dlpack", None)
+    target = vjp if inner is None else inner
+    try:
+        ref = weakref.WeakMethod(target) if hasattr(target, "__self__") else weakref.ref(target)
+    except TypeError:
+        return vjp  # (not weakly referenceable: such an owner never enters the module-wide cache either)
+
+    def call(t, y, cotangent):
+        hook = ref()
+        if hook is None:
+            raise RuntimeError("the vjp hook this captured dynamics was built for no longer exists")
+        if inner is not None:
+            from ..utils.interop import adapt_vjp
+
+            hook = adapt_vjp(hook, importer)
+        return hook(t, y, cotangent)
+
+    return call
+
+
+def _graph_cache_owner(func, vjp):
+    """The object a module-wide capture cache hangs on (weakly): the module, or — with a vjp hook — the hook (its instance, for a bound
+    method: the method object itself is made anew on every attribute access)."""
+    if vjp is None:
+        return func
+    hook = getattr(vjp, "__wrapped__", vjp)
+    return getattr(hook, "__self__", hook)
+
+
+def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoint_params, rtol=None, atol=None, vjp=None):
     """Resolve ``adjoint_options["graph_func"]`` and return the captured FLAT augmented dynamics, or None for the eager one.
 
     The augmented dynamics (func forward + autograd vjp, ~30 eager launches) is captured into one HIP graph per time-argument
@@ -401,23 +474,33 @@ def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoin
     cached for this module), the main thread, no capture in progress, no per-evaluation all-reduce — and falls back to the eager
     dynamics if the capture fails.  The capture has to happen in the caller of the autograd node — on the calling thread and outside
     the node: capturing from the engine's worker thread (where backward runs), or inside its forward while the parameters are its
-    inputs, crashes the runtime."""
+    inputs, crashes the runtime.
+
+    With a vjp hook (``vjp``) the captured thing is the hook's own launches; "auto" then means OFF — whether another framework's
+    kernels land on the capturing stream, and survive a replay, is the caller's knowledge: ``graph_func=True`` states it."""
     mode = adjoint_options.pop("graph_func", "auto")
     forced = mode is True or isinstance(mode, dict)
     if mode == "auto":
-        mode = _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options)
+        mode = vjp is None and _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options)
     if not mode:
         return None
     from ..utils.graphed import GraphedFunc
 
-    if not isinstance(func, nn.Module):
-        raise NotImplementedError("adjoint_options['graph_func'] needs func to be an nn.Module")
-    cache = mode if isinstance(mode, dict) else _GRAPH_CACHE.setdefault(func, {})
+    if vjp is None and not isinstance(func, nn.Module):
+        raise NotImplementedError("adjoint_options['graph_func'] needs func to be an nn.Module (or a vjp hook)")
+    if isinstance(mode, dict):
+        cache = mode
+    else:
+        try:
+            cache = _GRAPH_CACHE.setdefault(_graph_cache_owner(func, vjp), {})
+        except TypeError:  # an owner that cannot be referenced weakly: captures live for this call only
+            cache = {}
     time_grad = bool(t_span.requires_grad)
     fixed = _is_fixed(adjoint_solver)
     # (the captured kernels address the parameters' storage: a parameter whose storage was swapped — `p.data = ...` — needs a new
     # capture, an in-place update such as an optimiser step does not)
-    key = ("aug-flat", tuple(y0.shape), y0.dtype, str(y0.device), time_grad, fixed, tuple((id(p), p.data_ptr()) for p in adjoint_params))
+    key = ("aug-flat" if vjp is None else "aug-flat-hook", tuple(y0.shape), y0.dtype, str(y0.device), time_grad, fixed,
+           tuple((id(p), p.data_ptr()) for p in adjoint_params))
     graphed = cache.get(key)
     if isinstance(graphed, _NoGraph):
         return None
@@ -425,7 +508,10 @@ def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoin
     example = [torch.zeros([], dtype=y0.dtype, device=y0.device), y0.detach(), torch.zeros_like(y0)] + [torch.zeros_like(p) for p in adjoint_params]
     adt, segs, total = _segment_layout(example)
     if graphed is None:
-        dyn = _make_functional_dynamics(func, adjoint_params, time_grad)
+        if vjp is None:
+            dyn = _make_functional_dynamics(func, adjoint_params, time_grad)
+        else:
+            dyn = _make_augmented_dynamics(None, adjoint_params, time_grad, vjp=_weak_hook(vjp))
         (s1, n1), (s2, n2) = segs[1], segs[2]
         yshape, dev = tuple(y0.shape), y0.device
 
@@ -480,6 +566,7 @@ class _BackwardPlan(NamedTuple):
     replay_intervals: Any  # parity harness: one prescribed (dt, accept) table per interval, in the order the intervals are run
     forward_is_fixed: bool
     y0_shape: tuple
+    vjp: Any = None  # the caller's vector-Jacobian product (adjoint_options["vjp"], on torch tensors) or None: torch autograd
 
 
 class _AugmentedState:
@@ -531,7 +618,10 @@ def _interval_solver_for(plan, solve_options, t_host):
     if not cache:
         return None
     opts = {k: v for k, v in solve_options.items() if k not in ("_xde_flat_func", "_short_solves")}
-    key = _interval_key(plan.solver, plan.rtol, plan.atol, opts, direction_of((t_host[-1].item(), t_host[-2].item())), t_host.dtype)
+    span = _first_sweep_interval(t_host)
+    if span is None:
+        return None
+    key = _interval_key(plan.solver, plan.rtol, plan.atol, opts, direction_of(span), t_host.dtype)
     iv = cache.get(key) if key is not None else None
     if not isinstance(iv, _IntervalSolver) or not iv.lock.acquire(blocking=False):
         return None
@@ -573,7 +663,7 @@ def _sweep(plan, t_span, y_ans, grad_y, adjoint_params):
     reduce_params = pg is not None and not _is_fixed(plan.solver) and params_steer  # (a fixed grid has no step control)
     if pg is not None:
         _check_sharded_backward(plan, pg, spec, reduce_params)
-    dynamics = _make_augmented_dynamics(plan.func, adjoint_params, plan.time_grad, pg, reduce_params)
+    dynamics = _make_augmented_dynamics(plan.func, adjoint_params, plan.time_grad, pg, reduce_params, vjp=plan.vjp)
     solve_options = dict(plan.options)
     if not _is_fixed(plan.solver):
         # one evaluation of the augmented dynamics (func forward + vjp) less per interval: the heuristic's f0 is the state's f0
@@ -639,23 +729,10 @@ class OdeintAdjointMethod(torch.autograd.Function):
         return (None, None, adj_y0, grad_t, *adj_params)  # D6: adj_y0 is returned (the reference drops it)
 
 
-def odeint_adjoint(
-    func: callable,
-    y0,
-    t_span,
-    *,
-    rtol=1e-7,
-    atol=1e-9,
-    solver=None,
-    options={"norm": _rms_norm},
-    event_fn=None,
-    adjoint_rtol=None,
-    adjoint_atol=None,
-    adjoint_solver=None,
-    adjoint_options=None,
-    adjoint_params=None,
-):
-    """Same signature, defaults and error behaviour as the reference's (:170-257)."""
+def _prepare(func, y0, t_span, *, rtol, atol, solver, options, adjoint_rtol, adjoint_atol, adjoint_solver, adjoint_options,
+             adjoint_params, vjp, time_grad):
+    """Argument defaults and validation of the reference's ``odeint_adjoint`` (:186-238) -> the backward plan and the adjoint
+    parameters it will differentiate with respect to."""
     if adjoint_params is None and not isinstance(func, nn.Module):
         raise ValueError(
             "func must be an instance of nn.Module to specify the adjoint parameters; alternatively they "
@@ -674,24 +751,142 @@ def odeint_adjoint(
             "`options` has been passed then `adjoint_options` must be passed as well."
         )
     if adjoint_options is None:
-        adjoint_options = {k: v for k, v in (options or {}).items() if k != "norm"}
+        adjoint_options = {k: v for k, v in (options or {}).items() if k not in ("norm", "from_dlpack")}
     else:
         adjoint_options = dict(adjoint_options)  # the caller's dict is never modified
+    adjoint_options.pop("vjp", None)
+    adjoint_options.pop("from_dlpack", None)
 
-    wanted = _adjoint_parameters(func, adjoint_params, norm_is_users=callable(adjoint_options.get("norm")))
+    if vjp is not None and adjoint_params is not None:
+        # with a hook the adjoint parameters only fix the number, shapes and dtype of the parameter adjoints: every one is kept
+        # (whether the CALLER's framework marks it trainable is for the hook to know; `None` from it means "no gradient")
+        wanted = tuple(adjoint_params)
+    else:
+        wanted = _adjoint_parameters(func, adjoint_params, norm_is_users=callable(adjoint_options.get("norm")))
     adjoint_options["norm"] = _resolve_adjoint_norm(adjoint_options, options["norm"])
-    if not torch.is_tensor(t_span):
-        t_span = torch.as_tensor(t_span)
 
-    graphed = _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, wanted, adjoint_rtol, adjoint_atol)
+    graphed = _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, wanted, adjoint_rtol, adjoint_atol, vjp=vjp)
     adjoint_options.pop("interval_graph", None)
     plan = _BackwardPlan(
         func=func, solver=adjoint_solver, rtol=adjoint_rtol, atol=adjoint_atol,
         options={k: v for k, v in adjoint_options.items() if k != "_replay_intervals"},
-        time_grad=bool(t_span.requires_grad), graphed=graphed, replay_intervals=adjoint_options.get("_replay_intervals"),
-        forward_is_fixed=_is_fixed(solver), y0_shape=tuple(y0.shape))
+        time_grad=bool(time_grad), graphed=graphed, replay_intervals=adjoint_options.get("_replay_intervals"),
+        forward_is_fixed=_is_fixed(solver), y0_shape=tuple(y0.shape), vjp=vjp)
+    return plan, wanted
+
+
+def odeint_adjoint(
+    func: callable,
+    y0,
+    t_span,
+    *,
+    rtol=1e-7,
+    atol=1e-9,
+    solver=None,
+    options={"norm": _rms_norm},
+    event_fn=None,
+    adjoint_rtol=None,
+    adjoint_atol=None,
+    adjoint_solver=None,
+    adjoint_options=None,
+    adjoint_params=None,
+):
+    """Same signature, defaults and error behaviour as the reference's (:170-257).
+
+    ``adjoint_options["vjp"] = fn``: the backward pass takes ``fn(t, y, cotangent) -> (f, vjp_t, vjp_y, *vjp_params)`` instead of
+    differentiating ``func`` with torch autograd (``_vjp_through_hook``); ``adjoint_params`` then only fixes the parameter adjoints'
+    shapes and order.  Tensors of another framework: ``AdjointProblem`` below (this function's result carries a TORCH autograd node)."""
+    from ..utils import interop
+
+    if interop.is_foreign(y0) or interop.is_foreign(t_span) or (isinstance(options, dict) and "from_dlpack" in options):
+        raise TypeError("odeint_adjoint returns a tensor that carries a torch autograd node; for tensors of another framework wrap "
+                        "paddlexde_amd.functional.AdjointProblem(...).forward / .backward in that framework's own autograd "
+                        "function (INTEGRATION.md section B)")
+    vjp = adjoint_options.get("vjp") if isinstance(adjoint_options, dict) else None
+    if not torch.is_tensor(t_span):
+        t_span = torch.as_tensor(t_span)
+    plan, wanted = _prepare(func, y0, t_span, rtol=rtol, atol=atol, solver=solver, options=options, adjoint_rtol=adjoint_rtol,
+                            adjoint_atol=adjoint_atol, adjoint_solver=adjoint_solver, adjoint_options=adjoint_options,
+                            adjoint_params=adjoint_params, vjp=vjp, time_grad=t_span.requires_grad)
 
     def forward_solve(y_start, times):
         return odeint(func, y_start, times, solver=solver, rtol=rtol, atol=atol, options=options)
 
     return OdeintAdjointMethod.apply(plan, forward_solve, y0, t_span, *wanted)
+
+
+class AdjointProblem:
+    """The adjoint method as a framework-neutral (forward, backward) PAIR — what the autograd function of ANY framework wraps.
+
+    The reference's ``OdeintAdjointMethod`` is a ``paddle.autograd.PyLayer`` whose backward differentiates ``func`` with Paddle itself
+    (functional/odeint_adjoint.py:11-167, the vjp at :108-114).  The kernels below it need device pointers only, so the same
+    arrangement works for a caller whose tensors are not torch's: the CALLER's framework supplies the vector-Jacobian product
+    (``vjp``), this class supplies the two solves::
+
+        prob = AdjointProblem(layer, vjp=paddle_vjp, adjoint_params=params, solver=Dopri5, rtol=1e-7, atol=1e-9,
+                              from_dlpack=paddle.from_dlpack)
+        ans = prob.forward(y0, t_span)                                   # the plain solve, nothing recorded (:37-43)
+        adj_y0, grad_t, grads = prob.backward(t_span, ans, grad_ans)     # the sweep (:47-167); grads: one per adjoint parameter
+
+    ``vjp(t, y, cotangent) -> (f, vjp_t, vjp_y, *vjp_params)`` receives and returns the caller's own tensors (``from_dlpack`` = that
+    framework's importer; ``None`` for a zero gradient); ``func(t, y)`` likewise.  Without ``from_dlpack`` everything is torch.
+    ``adjoint_params``: tensors (of either kind) that fix number, shapes and dtype of the parameter adjoints.  Arguments, defaults and
+    error behaviour otherwise as ``odeint_adjoint``; results are tensors of the caller's framework.  INTEGRATION.md section B has the
+    Paddle ``PyLayer`` (12 lines) and the ``paddle.autograd.grad`` hook (10 lines)."""
+
+    def __init__(self, func, *, vjp, adjoint_params, solver=None, rtol=1e-7, atol=1e-9, options={"norm": _rms_norm},
+                 adjoint_rtol=None, adjoint_atol=None, adjoint_solver=None, adjoint_options=None, from_dlpack=None):
+        from ..utils import interop
+
+        if not callable(vjp):
+            raise TypeError("AdjointProblem needs vjp(t, y, cotangent) -> (f, vjp_t, vjp_y, *vjp_params)")
+        options = dict(options or {})
+        importer = options.pop("from_dlpack", None) if from_dlpack is None else from_dlpack
+        options.pop("from_dlpack", None)
+        self._importer = importer
+        self._func = func if importer is None else interop.adapt_func(func, importer)
+        self._vjp = vjp if importer is None else interop.adapt_vjp(vjp, importer)
+        self._params = tuple(interop.to_torch(p).detach() for p in adjoint_params)
+        self._solver, self._rtol, self._atol, self._options = solver, rtol, atol, options
+        self._adjoint = dict(adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_solver=adjoint_solver,
+                             adjoint_options=adjoint_options)
+        self._plan = None
+
+    def _out(self, x):
+        return x if (x is None or self._importer is None) else self._importer(x)
+
+    def _plan_for(self, y0, t_span, time_grad):
+        key = (tuple(y0.shape), y0.dtype, y0.device, bool(time_grad))
+        if self._plan is None or self._plan[0] != key:
+            plan, _ = _prepare(self._func, y0, t_span, rtol=self._rtol, atol=self._atol, solver=self._solver, options=self._options,
+                               adjoint_params=self._params, vjp=self._vjp, time_grad=time_grad, **self._adjoint)
+            self._plan = (key, plan)
+        return self._plan[1]
+
+    def forward(self, y0, t_span):
+        """``odeint(func, y0, t_span)`` with nothing recorded; also readies what the backward pass can ready ahead (captures happen
+        here: on the caller's thread, outside any autograd engine)."""
+        from ..utils import interop
+
+        y0, t_span = interop.to_torch(y0), torch.as_tensor(interop.to_torch(t_span))
+        with torch.no_grad():
+            self._plan_for(y0, t_span, False)
+            return self._out(odeint(self._func, y0, t_span, solver=self._solver, rtol=self._rtol, atol=self._atol, options=self._options))
+
+    def backward(self, t_span, answer, grad_answer, t_requires_grad=False):
+        """``(dL/dy0, dL/dt_span | None, [dL/dtheta ...])`` from ``dL/d answer`` — the reference's backward (:47-167) plus the
+        gradient with respect to ``y0`` it drops (D6)."""
+        from ..utils import interop
+
+        t_span, answer, grad_answer = (interop.to_torch(x) for x in (t_span, answer, grad_answer))
+        t_span = torch.as_tensor(t_span)
+        fixed, n_times = _is_fixed(self._solver), len(t_span)
+        if fixed:  # (fixed solvers fold time into axis -2: the state's shape is the answer's with that axis divided)
+            y0_shape = tuple(answer.shape[:-2]) + (answer.shape[-2] // n_times, answer.shape[-1])
+        else:
+            y0_shape = tuple(answer.shape[1:])
+        with torch.no_grad():
+            y_first = _time_first(answer, y0_shape, n_times, fixed)[0]
+            plan = self._plan_for(y_first, t_span, t_requires_grad)
+            adj_y0, grad_t, adj_params = _sweep(plan, t_span, answer, grad_answer.contiguous(), self._params)
+        return self._out(adj_y0), self._out(grad_t), [self._out(g) for g in adj_params]

@@ -89,8 +89,10 @@ def _build_plans(tab, mid):
         i = S - 2 if fuse_err else S - 1
         while i >= 1:
             idx_i, idx_p = stage_plan[i][0], stage_plan[i - 1][0]
-            if idx_i[-1] == i and len(idx_i) >= 4 and set(idx_i[:-1]) <= set(idx_p):
-                emit = _hip.dbl_array([float(tab.beta[i][j]) for j in idx_p])  # (0 for an operand of stage i-1 that stage i does not use)
+            # (exactly the previous launch's operands: an operand stage i does not use would enter the emitted sum as `k_j * 0`, which
+            # is NaN for a non-finite k_j the full stage never reads — ADVICE r04; every tableau shipped here has equal sets)
+            if idx_i[-1] == i and len(idx_i) >= 4 and idx_i[:-1] == idx_p:
+                emit = _hip.dbl_array([float(tab.beta[i][j]) for j in idx_p])
                 presum[i] = (emit, [i], _hip.dbl_array([float(tab.beta[i][i])]))
                 i -= 2
             else:

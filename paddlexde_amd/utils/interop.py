@@ -13,10 +13,18 @@ this package's allocator and stream owner — so a tensor of ANOTHER framework e
     then receives `(t, y)` as tensors of its own framework — views of the solver's buffers — and what it returns is viewed back; the
     solution is handed back through the same importer.  Without it, `func` receives torch tensors.
 
-Only the forward `odeint` takes foreign tensors: `odeint_adjoint` differentiates `func` with torch autograd, which a foreign
-framework's layer cannot serve (INTEGRATION.md section B shows the Paddle-side binding of the C ABI for that case).
-Paddle itself is not installed in the build image; the adapter is exercised with a protocol-level stand-in (a class that exposes
-nothing but `__dlpack__` / `__dlpack_device__` / `shape` / `dtype`): tests/test_gpu_kernels.py::test_foreign_tensors_through_dlpack.
+Training goes the same way.  The reference takes the vector-Jacobian product of `func` with the CALLER's framework
+(`paddle.autograd.grad(outputs=func_eval, inputs=(t, y) + adjoint_params, grad_outputs=-adj_y)`, functional/odeint_adjoint.py:108-114);
+here that product is a hook, `adjoint_options["vjp"] = fn` with `fn(t, y, cotangent) -> (f, vjp_t, vjp_y, *vjp_params)` on the caller's
+own tensors (`adapt_vjp` below), and `functional.AdjointProblem` is the framework-neutral (forward, backward) pair a `PyLayer` of the
+caller's framework wraps (INTEGRATION.md section B shows the 10-line `paddle.autograd.grad` hook and the PyLayer around it).
+Paddle itself is not installed in the build image; the adapters are exercised with a protocol-level stand-in (a class that exposes
+nothing but `__dlpack__` / `__dlpack_device__` / `shape` / `dtype`): tests/test_gpu_kernels.py::test_foreign_tensors_through_dlpack,
+tests/_e2e_cases.py::test_adjoint_vjp_hook_on_foreign_tensors_reproduces_config3_gradients.
+
+Stream contract (both adapters): the caller's framework must enqueue its kernels on the stream this package runs on (torch's current
+stream: share it, or make the framework's current stream that one) — DLPack's `stream` argument orders the hand-over of each tensor,
+not the framework's later kernels.
 """
 import torch
 
@@ -57,3 +65,20 @@ def adapt_func(func, from_dlpack):
 
     torch_func.__wrapped__ = func
     return torch_func
+
+
+def adapt_vjp(vjp, from_dlpack):
+    """The caller's `vjp(t, y, cotangent) -> (f, vjp_t, vjp_y, *vjp_params)` -> the same contract on torch tensors: the three inputs
+    are exported with the caller's importer, every returned tensor is viewed back; `None` members (a gradient the caller's framework
+    did not produce) pass as `None`."""
+
+    def export(x):
+        return from_dlpack(x.detach()) if torch.is_tensor(x) else x
+
+    def torch_vjp(t, y, cotangent):
+        out = vjp(export(t), export(y), export(cotangent))
+        return tuple(None if v is None else to_torch(v) for v in out)
+
+    torch_vjp.__wrapped__ = vjp
+    torch_vjp._from_dlpack = from_dlpack
+    return torch_vjp

@@ -48,8 +48,9 @@ class HistoryIndex(torch.autograd.Function):
         (derivative_lags,) = ctx.saved_tensors
         be = _hip.get_backend()
         if (hasattr(be, "lag_grad") and grad_y.dtype == derivative_lags.dtype and grad_y.shape == derivative_lags.shape
-                and (derivative_lags.shape[-1] <= 256 or derivative_lags.shape[-1] % (4 if grad_y.dtype == torch.float32 else 2) == 0)):
-            grad = be.lag_grad(grad_y.contiguous(), derivative_lags)  # one launch: sum over every axis but the lag axis
+                and derivative_lags.shape[-2] <= 2048):
+            # one launch: sum over every axis but the lag axis (xde_lag_grad serves every row length D and alignment; up to 2048 lags)
+            grad = be.lag_grad(grad_y.contiguous(), derivative_lags)
         else:
             grad = grad_y * derivative_lags
             dims = [d for d in range(grad.dim()) if d != grad.dim() - 2]  # every axis but the lag axis (reference: [0, 1, 3])

@@ -56,6 +56,39 @@ def test_history_gather_vs_oracle(dev, lead, uniform, dtype, D, method):
     assert P.rel_err(lg.grad.cpu().numpy(), g_ref) <= (5e-5 if dtype == np.float32 else 1e-11)
 
 
+@pytest.mark.parametrize("method", ["linear", "cubic", "bez"])
+@pytest.mark.parametrize("kind", ["ramp", "sine"])
+def test_reference_interpolation_fixtures_on_the_history_kernels(dev, kind, method):
+    """The reference's own spline fixtures (tests/interpolation/test_interpolation.py:13-85: ramp series at t = 21.12, sine series at
+    t = 16.5; value + derivative tolerances per class) through the PRODUCT: `HistoryIndex.apply` (xde_history_gather /
+    xde_hermite_gather) gives the value, its backward (xde_lag_grad) the derivative — one component at a time, so that each is held
+    to the reference's tolerance — and both are compared with the oracle's classes on the same inputs in ulps."""
+    series, t, t_eval, val_tgt, der_tgt = P.interpolation_fixture(kind)
+    rtol_val, rtol_der = P.INTERPOLATION_TOLERANCES[kind][method]
+    his, ts = torch.from_numpy(series).to(dev), torch.from_numpy(t).to(dev)
+    der = np.zeros((1, 1, 2), dtype=np.float32)
+    for d in range(2):
+        lg = torch.from_numpy(t_eval).to(dev).requires_grad_(True)
+        y = HistoryIndex.apply(lg, his, ts, method)
+        assert y.shape == (1, 1, 2) and y.dtype == torch.float32
+        y[0, 0, d].backward()  # d y_d / d lag = the spline's time derivative of component d
+        der[0, 0, d] = float(lg.grad[0])
+    val = y.detach().cpu().numpy()
+    assert P.paddle_allclose(val_tgt, val, rtol=rtol_val), (val_tgt, val)
+    assert P.paddle_allclose(der_tgt, der, rtol=rtol_der), (der_tgt, der)
+    interp = O.HISTORY_SPLINES[method](series, t)
+    # The derivative is a DIFFERENCE of history rows divided by the knot spacing: the magnitude its rounding errors live at is that of
+    # the summed terms, max|row| / spacing (ramp: 10.5 / 1 against a result of 0.5), not that of the result.
+    i = int(np.clip(np.searchsorted(t, t_eval[0], side="left") - 1, 0, len(t) - 1))
+    term = np.float32(np.abs(series[..., i : i + 4, :]).max() / (t[i + 1] - t[i]))
+    d_ref = interp.derivative(t_eval)
+    rec = {"kind": kind, "method": method, "value_ulps": P.ulps_apart(val, interp.evaluate(t_eval)),
+           "derivative_ulps_of_terms": float(np.abs(der.astype(np.float64) - d_ref).max() / float(np.spacing(term)))}
+    P.report("reference_interpolation_fixture", rec)
+    # same formulas, same association; the oracle's numpy matmul may contract / reorder its 2-4 products, so "a few ulps", stated:
+    assert rec["value_ulps"] <= 4 and rec["derivative_ulps_of_terms"] <= 4, rec
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_lag_gradient_reduction_at_odd_sizes(dev, dtype):
     """xde_lag_grad alone: [outer, L, D] products reduced to [L] in one launch, for row lengths that are / are not a multiple of
@@ -66,7 +99,10 @@ def test_lag_gradient_reduction_at_odd_sizes(dev, dtype):
     if not hasattr(be, "lag_grad"):
         pytest.skip("backend without lag_grad")
     rng = np.random.RandomState(3)
-    for outer, L, D in [(1, 1, 1), (5, 3, 7), (64, 12, 64), (1000, 5, 16), (17, 128, 4), (3, 2, 250), (0, 4, 8)]:
+    # (the last rows: ADVICE r04 — rows longer than a workgroup's reach, D > 1024 for fp32 / > 512 for fp64, were refused by the C entry
+    # point while the Python gate let them through; an [L, D] plane of exactly 256 vectors; more lags than one workgroup has lanes)
+    for outer, L, D in [(1, 1, 1), (5, 3, 7), (64, 12, 64), (1000, 5, 16), (17, 128, 4), (3, 2, 250), (0, 4, 8), (9, 3, 2048), (7, 2, 1031),
+                        (40, 4, 256), (33, 64, 16), (3, 300, 8), (2, 1, 4100)]:
         gy, de = rng.randn(outer, L, D).astype(dtype), rng.randn(outer, L, D).astype(dtype)
         got = be.lag_grad(torch.from_numpy(gy).to(dev), torch.from_numpy(de).to(dev)).cpu().numpy()
         want = (gy * de).astype(np.float64).sum(axis=(0, 2))
@@ -75,6 +111,18 @@ def test_lag_gradient_reduction_at_odd_sizes(dev, dtype):
     # the same launch twice: the workspace is left re-armed
     gy, de = torch.from_numpy(rng.randn(300, 12, 64).astype(dtype)).to(dev), torch.from_numpy(rng.randn(300, 12, 64).astype(dtype)).to(dev)
     assert torch.equal(be.lag_grad(gy, de), be.lag_grad(gy, de))
+    # an unaligned view of a long row (element-wise path), and the autograd entry on a row of 2048 columns
+    big = torch.from_numpy(rng.randn(2 * 5 * 3 * 700 + 1).astype(dtype)).to(dev)
+    gy_u, de_u = big[1 : 1 + 5 * 3 * 700].view(5, 3, 700), big[1 + 5 * 3 * 700 :].view(5, 3, 700)
+    want = (gy_u.cpu().numpy() * de_u.cpu().numpy()).astype(np.float64).sum(axis=(0, 2))
+    assert np.allclose(be.lag_grad(gy_u, de_u).cpu().numpy(), want, rtol=3e-6 if dtype == np.float32 else 1e-13, atol=1e-5 if dtype == np.float32 else 1e-12)
+    T = 8
+    his, ts = _history((3, 2048), T, True, dtype=dtype)
+    lg = torch.tensor([1.5, 4.25], dtype=torch.from_numpy(ts).dtype).to(dev).requires_grad_(True)
+    y = HistoryIndex.apply(lg, torch.from_numpy(his).to(dev), torch.from_numpy(ts).to(dev), "linear")
+    y.sum().backward()  # (raised XdeError inside backward before round 5)
+    d_ref = O.HISTORY_SPLINES["linear"](his, ts, dtype=dtype).derivative(lg.detach().cpu().numpy())
+    assert P.rel_err(lg.grad.cpu().numpy(), d_ref.astype(np.float64).sum(axis=(0, 2))) <= (5e-5 if dtype == np.float32 else 1e-11)
 
 
 def test_history_spline_properties(dev):

@@ -173,3 +173,78 @@ def report(name, rec):
     if path:
         with open(path, "a") as fh:
             fh.write(json.dumps({"test": name, **rec}) + "\n")
+
+
+class Foreign:
+    """A tensor of 'another framework' at the PROTOCOL level (Paddle is not in the image): owns device memory (held through a private
+    torch tensor), exposes `__dlpack__` / `__dlpack_device__` / shape / dtype and nothing else the product could use.  `.raw` is that
+    framework's own handle on its storage — what ITS kernels (here: torch ops, standing in for them) compute on."""
+
+    imported = []  # what the importer below was handed (type names): evidence that the product exported its buffers through it
+
+    def __init__(self, t):
+        self.raw = t
+        self.shape, self.dtype = tuple(t.shape), str(t.dtype)
+
+    def __dlpack__(self, stream=None, **kw):
+        return self.raw.__dlpack__(stream=stream) if stream is not None else self.raw.__dlpack__()
+
+    def __dlpack_device__(self):
+        return self.raw.__dlpack_device__()
+
+    @staticmethod
+    def from_dlpack(x):
+        """The foreign framework's importer: consumes any `__dlpack__` producer."""
+        import torch as _torch
+
+        Foreign.imported.append(type(x).__name__)
+        return Foreign(_torch.from_dlpack(x))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference's interpolation fixtures (tests/interpolation/test_interpolation.py:13-85), restated as data: a ramp series sampled at
+# integer times and evaluated at 21.12 (:16-32), a sine series sampled every 0.01 and evaluated at 16.5 (:52-72); for each of the
+# three spline classes the (value, derivative) relative tolerances its test asserts (:34-47, :74-85; paddle.allclose's atol 1e-8)
+# ----------------------------------------------------------------------------------------------------------------------
+INTERPOLATION_TOLERANCES = {
+    "ramp": {"linear": (1e-4, 1e-4), "cubic": (1e-4, 1e-4), "bez": (1e-4, 1e-4)},
+    "sine": {"linear": (5e-2, 1e-2), "cubic": (1e-5, 1e-2), "bez": (5e-2, 1e-2)},
+}
+
+
+def interpolation_fixture(kind):
+    """-> (series [1, 2000, 2] f32, t [2000] f32, t_eval [1] f32, value target [1, 1, 2], derivative target [1, 1, 2])."""
+    zeros = np.zeros(2000, dtype=np.float32)
+    if kind == "ramp":
+        series = np.stack([np.arange(0, 1000, 0.5).astype(np.float32), zeros], axis=-1)[None]
+        t = np.arange(0, 2000, 1).astype(np.float32)  # (int64 in the fixture; the spline classes cast it to float32, interpolate_base.py:27)
+        t_eval = np.array([21.12], dtype=np.float32)
+        val = np.array([21.12 * 0.5, 0.0], dtype=np.float32)[None, None]
+        der = np.array([0.5, 0.0], dtype=np.float32)[None, None]
+    elif kind == "sine":
+        x = np.arange(0, 20, 0.01).astype(np.float32)
+        assert x.shape == (2000,)
+        series = np.sin(np.stack([x, zeros], axis=-1))[None].astype(np.float32)
+        t = x
+        t_eval = np.array([16.5], dtype=np.float32)
+        val = np.sin(np.array([16.5, 0.0], dtype=np.float32))[None, None]
+        der = np.cos(np.array([16.5, 0.0], dtype=np.float32))[None, None]
+        der[:, :, 1] = 0
+    else:
+        raise KeyError(kind)
+    return series, t, t_eval, val, der
+
+
+def paddle_allclose(x, y, rtol, atol=1e-8):
+    """paddle.allclose(x, y): |x - y| <= atol + rtol |y| everywhere (the comparison the reference's tests make)."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    return bool((np.abs(x - y) <= atol + rtol * np.abs(y)).all())
+
+
+def ulps_apart(got, ref):
+    """Largest |got - ref| in units of one ulp of `ref`'s dtype at the LARGEST magnitude in `ref` (0 = the same bits up to signed zeros)."""
+    ref = np.asarray(ref)
+    scale = np.abs(ref).max()
+    if scale == 0:
+        return float(np.abs(np.asarray(got, dtype=np.float64)).max() > 0)
+    return float(np.abs(np.asarray(got, dtype=np.float64) - ref.astype(np.float64)).max() / float(np.spacing(ref.dtype.type(scale))))

@@ -785,3 +785,41 @@ def test_pre_summed_stage_equals_the_full_stage_bit_for_bit(be, dbl, dtype, n, n
     five = (C.c_void_p * 5)(*[k.data_ptr() for k in ks[:5]])
     cf = (C.c_double * 5)(*([1.0] * 5))
     assert lib.xde_stage_combine_pre(out.data_ptr(), y0.data_ptr(), None, part.data_ptr(), five, cf, 5, h, None, n, 0, 0, None) == _hip.XDE_EBADARG
+
+
+@pytest.mark.gpu
+def test_two_peeks_pending_on_one_recycled_control_block(be):
+    """VERDICT r04 (weak 2): `ctrl_peek_async` used to keep ONE pinned buffer and ONE event per control-block mirror, so a second peek
+    issued before the first was read overwrote both.  Every handle now owns its buffer and event until it is consumed.  Two peeks are
+    enqueued on one RECYCLED work set (the adjoint sweep's situation: one solve per interval on the same block) with the block
+    rewritten in between, then read in the order issued and in reverse: each must show the block as it was at ITS point of the stream."""
+    dev = torch.device("cuda:0")
+    w = be.acquire_work(dev, torch.float32)
+    be.release_work(w)
+    w2 = be.acquire_work(dev, torch.float32)
+    assert w2 is w  # recycled: same control block, same mirror
+    p = _hip.XdeCtrlParams()
+    p.rtol, p.atol, p.safety, p.ifactor, p.dfactor, p.order = 1e-5, 1e-7, 0.9, 10.0, 0.2, 5.0
+    p.max_step, p.max_num_steps, p.direction, p.n_stage, p.n_seg = float("inf"), 1000, 1, 6, 1
+    p.seg_count[0] = 1.0
+    t_span = torch.tensor([0.0, 1.0], dtype=torch.float64, device=dev)
+    for order in ("fifo", "lifo"):
+        be.ctrl_init(w.ctrl, p, 0.25, 0.125, 2, t_span, None, w.t_stage)
+        h1 = be.ctrl_peek_async(w.ctrl)
+        be.ctrl_init(w.ctrl, p, 0.5, 0.0625, 2, t_span, None, w.t_stage)
+        h2 = be.ctrl_peek_async(w.ctrl)
+        assert h1.host.data_ptr() != h2.host.data_ptr() and h1.ev is not h2.ev
+        if order == "fifo":
+            c1, c2 = be.ctrl_peek_result(h1), be.ctrl_peek_result(h2)
+        else:
+            c2, c1 = be.ctrl_peek_result(h2), be.ctrl_peek_result(h1)
+        assert (c1.t1, c1.dt) == (0.25, 0.125) and (c2.t1, c2.dt) == (0.5, 0.0625)
+        with pytest.raises(_hip.XdeError):
+            be.ctrl_peek_result(h1)  # consumed: its buffer may already serve another peek
+    # steady state allocates nothing: the next peek takes a pooled pair, a dropped handle gives its pair back
+    pooled = {x[0].data_ptr() for x in be._mirrors[w.ctrl.data_ptr()].peek}
+    h3 = be.ctrl_peek_async(w.ctrl)
+    assert h3.host.data_ptr() in pooled
+    del h3
+    assert len(be._mirrors[w.ctrl.data_ptr()].peek) == len(pooled)
+    be.release_work(w)
