@@ -543,7 +543,8 @@ class Watchdog:
     ends the process (os._exit, after saying on stderr which stage of which rank ran out) when a stage outlives its limit — a
     rendezvous that never completes, a communicator initialisation a peer never joins, a kernel that never returns.  Every
     stage change is also written to $XDE_BENCH_STATUS_DIR/rank<r>.json, which the launching parent reads when it has to kill the
-    job.  XDE_BENCH_STAGE_SCALE multiplies every limit."""
+    job.  `on_expire(stage) -> exit code` lets a stage say goodbye in its own way (the extra measurements print the main line, marked
+    with the stage that ran out) — an expiry never ends in exit code 0.  XDE_BENCH_STAGE_SCALE multiplies every limit."""
 
     def __init__(self, rank):
         import threading
@@ -596,10 +597,10 @@ class Watchdog:
                 code = 70
                 if hook is not None:
                     try:
-                        code = hook()
+                        code = hook(stage)
                     except Exception as e:
                         print("bench.py[rank {}]: {}".format(self.rank, e), file=sys.stderr, flush=True)
-                os._exit(70 if code is None else code)
+                os._exit(70 if not code else code)  # (a hang is never reported as success, whatever the hook returns)
 
 
 def _stage_report(status_dir, n):
@@ -669,6 +670,8 @@ def self_launch(args):
     if proc.returncode != 0:
         print("bench.py: the {}-rank job exited with {}.  Last reported stages:\n{}".format(n, proc.returncode, _stage_report(status_dir, n)),
               file=sys.stderr)
+        if len(lines) == 1 and "watchdog_expired" in lines[0]:
+            print(lines[0], flush=True)  # the headline survived an extra measurement that hung: relayed, marked, and the exit code says so
         return proc.returncode or 1
     import shutil
 
@@ -1029,7 +1032,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_run(kind, ex, steps, warmup, events, pipeline=None):
+    def timed_run(kind, ex, steps, warmup, events, pipeline=None, blocks=1):
         """Build a solver on transport `kind`, let it settle, warm up, and time EXACTLY `steps` attempted steps between barriers:
         every rank's own clock stops after its stream has drained, the job's time is the MAX over the ranks."""
         if os.environ.get("XDE_BENCH_TEST_HANG") == str(rank):  # test hook: this rank never joins the set-up's first collective
@@ -1055,23 +1058,48 @@ def main():
         barrier()
         if events:
             be.prof_enable(args.event_period)
-        t0 = time.perf_counter()
-        c = solver.advance(steps)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        barrier()
+
+        def block():
+            """EXACTLY `steps` attempted steps between barriers; this rank's clock stops after its stream has drained; MAX over ranks."""
+            t0 = time.perf_counter()
+            cb = solver.advance(steps)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            barrier()
+            if dist is not None:
+                tmax = torch.tensor([el], dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            return cb, el
+
+        c, elapsed = block()  # THE timed region: `value` / `ms_per_step` come from this block alone
+        # ... and the same block twice more, back to back on the same solver: the line then says how far a 20-step block moves from
+        # one run to the next on this box (`ms_per_step_blocks`), which one shot cannot
+        repeats = [elapsed]
+        for _ in range(blocks - 1):
+            _c, el = block()  # (`c`, the counters the line reports, stay those of the timed region)
+            repeats.append(el)
         prof = None
         if events:
-            prof = be.prof_collect()
+            prof = be.prof_collect()  # (kernel averages over all the blocks)
             be.prof_enable(False)
-        if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+        timed_run.blocks = repeats
         return solver, c, elapsed, prof, settle
 
     wd.stage("set-up + warm-up + timed region", 600)
-    solver, c, elapsed, prof, settle = timed_run(exchange_kind, exchange, args.steps, args.warmup, not args.no_kernel_events)
+    solver, c, elapsed, prof, settle = timed_run(exchange_kind, exchange, args.steps, args.warmup, not args.no_kernel_events, blocks=3)
+    block_ms = [1e3 * el / args.steps for el in timed_run.blocks]
+    # func's own share of a step, measured apart (the same GEMM, back to back, on torch's stream — where func runs)
+    with torch.no_grad():
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            func(None, y0)
+        ev0.record()
+        for _ in range(30):
+            func(None, y0)
+        ev1.record()
+        ev1.synchronize()
+        func_ms_per_step = n_stage * ev0.elapsed_time(ev1) / 30.0
 
     N_local = B * D
     N_global = N_local * world
@@ -1086,6 +1114,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        # the same `steps`-step block three times back to back (the first is the one `value` is computed from): the spread of a short
+        # timed region on THIS box, in the line itself
+        "ms_per_step_blocks": block_ms,
         "higher_is_better": True,
         "scaling": scaling,
         "vs_baseline": None,
@@ -1147,11 +1178,20 @@ def main():
         solver_ms = sum(per_step[k] * prof[k]["ms"] / prof[k]["launches"] for k in per_step if prof[k]["launches"])
         out["solver_kernel_ms_per_step"] = solver_ms
         out["solver_only_states_per_s"] = N_local / (solver_ms * 1e-3) if solver_ms > 0 else None
+        # what of a step is inside NO kernel (dependent launch boundaries, the host's enqueue when it is the slower side): the step minus
+        # this library's kernels (events, in situ) minus func's GEMMs (timed apart, back to back: in situ they run on colder caches)
+        out["func_ms_per_step"] = func_ms_per_step
+        out["gap_ms_per_step"] = ms_per_step - (solver_ms + func_ms_per_step)
+        out["gap_ms_per_step_blocks"] = [b - (solver_ms + func_ms_per_step) for b in block_ms]
 
-    def emit_main_line():  # (also what a watchdog does when an EXTRA measurement below outlives its limit: the line is never lost to one)
+    def emit_main_line(expired_stage=None):
+        """The job's one JSON line.  Also what a watchdog does when an EXTRA measurement below outlives its limit: the headline is
+        never lost to one — but the line then names the stage that hung (`watchdog_expired`) and the process exits non-zero."""
+        if expired_stage is not None:
+            out["watchdog_expired"] = expired_stage
         if rank == 0:
             emit(out)
-        return 0
+        return 0 if expired_stage is None else 75
 
     if sharded:
         # who ran where: one row per rank, and whether each rank's device can address each other rank's (hipDeviceCanAccessPeer)
@@ -1196,6 +1236,18 @@ def main():
             ab["p2p, pipeline=graph"] = {"ms_per_step": 1e3 * el3 / steps2, "steps": steps2}
             del _s
         out["exchange_ab"] = ab
+    if sharded:
+        # BASELINE.json configs[3] names "RCCL error-norm all-reduce": that transport's step time at top level, whatever the headline ran on
+        # ("rccl": ncclAllReduce issued on the solver's stream; else torch.distributed's all_reduce over the nccl group)
+        ab_ = out.get("exchange_ab") or {exchange_kind: {"ms_per_step": ms_per_step, "steps": args.steps}}
+        out["rccl_allreduce_ms_per_step"] = None  # (no RCCL group: one-GPU rehearsal over gloo)
+        for kind, label in (("rccl", "ncclAllReduce on the solver's stream (RcclExchange)"),
+                            ("allreduce", "torch.distributed.all_reduce over the nccl (= RCCL) group")):
+            if nccl_pg is not None and isinstance(ab_.get(kind), dict) and "ms_per_step" in ab_[kind]:
+                out["rccl_allreduce_ms_per_step"] = ab_[kind]["ms_per_step"]
+                out["rccl_allreduce_transport"] = label + (" — the headline transport" if kind == exchange_kind
+                                                           else " — a {}-step run after the timed region".format(ab_[kind]["steps"]))
+                break
 
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline and args.dtype == "f32":
         wd.stage("cpu baseline", 600, on_expire=emit_main_line)
@@ -1230,7 +1282,8 @@ def main():
 
     emit_main_line()
     if dist is not None:
-        wd.stage("teardown", 90, on_expire=lambda: 0)  # the line is out: a teardown that hangs must not turn it into a failure
+        # (the line is out; a teardown that hangs — a rank that never reaches the barrier — still ends this process non-zero, named on stderr)
+        wd.stage("teardown", 90, on_expire=lambda stage: 76)
         dist.barrier()
         dist.destroy_process_group()
     wd.done()

@@ -233,3 +233,66 @@ def test_header_is_plain_c_and_the_cpp_example_builds(tmp_path):
                         os.path.join(ROOT, "examples", "cabi_dopri5.cpp"), "-L", lib_dir, "-lxde_hip", "-o", str(tmp_path / "cabi_dopri5")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_host_halves_run_up_to_the_launch_without_a_gpu():
+    """SURVEY section 5 ("ASan host build") / VERDICT r04 (missing 4): everything an entry point does on the HOST before its launch —
+    argument blocks, alignment and vector-path decisions, segment maps with their block shares, grid sizes, cache-policy selection,
+    profiling scopes — executed with well-formed arguments on a box WITHOUT a GPU: the launch itself then fails (no device) and the call
+    returns XDE_EHIP with the HIP error's text, never touching the (fake, never dereferenced on the host) device addresses.  Under
+    `python -m paddlexde_amd.csrc.build --sanitize` these paths run instrumented (profiles/r05_sanitize_cabi.txt)."""
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible: the launches would run on the fake addresses")
+    lib = _hip.load_library()
+    vp = C.c_void_p
+    dev = lambda i: 0x7F0000000000 + 0x100000 * i  # noqa: E731  16-byte aligned "device" addresses
+    P = _hip.XdeCtrlParams()
+    P.rtol, P.atol, P.safety, P.ifactor, P.dfactor, P.order = 1e-5, 1e-7, 0.9, 10.0, 0.2, 5.0
+    P.max_step, P.max_num_steps, P.direction, P.n_stage, P.n_seg = float("inf"), 100, 1, 6, 3
+    segs = _hip.make_segments([(0, 4), (4, 1000), (1004, 36)])
+    for i, (_, n_) in enumerate([(0, 4), (4, 1000), (1004, 36)]):
+        P.seg_count[i] = float(n_)
+    n = 1040
+    ks = (vp * 7)(*[dev(10 + j) for j in range(7)])
+    coef = (C.c_double * 7)(*[0.1 * (j + 1) for j in range(7)])
+    outs = (vp * 3)(dev(30), dev(31), dev(32))
+    lens = (C.c_int64 * 3)(4, 1000, 36)
+    starts = (C.c_int64 * 3)(0, 4, 1004)
+    calls = {
+        "stage_combine vec": lambda: lib.xde_stage_combine(dev(1), dev(2), dev(3), ks, dev(4), coef, 5, 0, 1.0, 0.0, dev(5), n, 0, dev(6), coef, 0.0, 0x1F, None),
+        "stage_combine scalar path": lambda: lib.xde_stage_combine(dev(1) + 4, dev(2), None, ks, None, coef, 7, 2, 0.125, 0.01, None, n + 3, 1, None, None, 0.001, 0, None),
+        "stage_combine 14 operands": lambda: lib.xde_stage_combine(dev(1), dev(2), None, (vp * 14)(*[dev(40 + j) for j in range(14)]), None,
+                                                                  (C.c_double * 14)(*([0.5] * 14)), 14, 0, 1.0, 0.1, None, n, 0, None, None, 0.0, 0, None),
+        "stage_combine_pre": lambda: lib.xde_stage_combine_pre(dev(1), dev(2), dev(3), dev(7), ks, coef, 1, 0.0, dev(5), n, 0, 1, None),
+        "error_norm_partial 3 segments": lambda: lib.xde_error_norm_partial(ks, None, coef, 6, dev(2), None, dev(8), 1e-5, 1e-7, 0.01, None, C.byref(segs), 0, 0,
+                                                                           dev(9), None, None),
+        "error_norm_partial fsal": lambda: lib.xde_error_norm_partial(ks, None, coef, 1, dev(2), dev(3), dev(8), 1e-5, 1e-7, 0.0, dev(5), C.byref(segs), 1, 1,
+                                                                     dev(9), dev(6), None),
+        "error_norm_control": lambda: lib.xde_error_norm_control(ks, None, coef, 1, dev(2), None, dev(8), C.byref(segs), 0, dev(9), dev(6), dev(5), C.byref(P),
+                                                                dev(20), None, dev(21), None, None),
+        "scaled_norm_partial": lambda: lib.xde_scaled_norm_partial(dev(1), dev(2), dev(3), 1e-5, 1e-7, C.byref(segs), 0, 0, dev(9), 1, None),
+        "norm_finalize": lambda: lib.xde_norm_finalize(dev(9), 0, dev(22), None),
+        "rk_control": lambda: lib.xde_rk_control(dev(5), C.byref(P), dev(9), None, dev(20), None, dev(21), None, None),
+        "ctrl_init": lambda: lib.xde_ctrl_init(dev(5), C.byref(P), 0.0, 0.1, 2, dev(20), None, dev(21), 0, None, None),
+        "initial_step_fused": lambda: lib.xde_initial_step_fused(0, dev(1), None, dev(2), C.byref(segs), 0, dev(23), C.byref(P), 0.0, dev(24), 0, dev(5), 2, dev(20),
+                                                                None, dev(21), 0, None),
+        "dense_eval": lambda: lib.xde_dense_eval(dev(25), ks, None, coef, 6, dev(2), None, dev(8), dev(16), dev(5), dev(20), 0, n, 0, -1, None),
+        "pack_segments": lambda: lib.xde_pack_segments(dev(1), outs, starts, lens, None, 3, n, 0, None),
+        "history_gather bez": lambda: lib.xde_history_gather(dev(1), dev(2), dev(3), dev(4), dev(6), 100, 24, 64, 12, 0, 2, None),
+        "lag_grad plane": lambda: lib.xde_lag_grad(dev(1), dev(2), dev(3), 9824, 64, 12, 0, dev(9), None),
+        "lag_grad long rows": lambda: lib.xde_lag_grad(dev(1), dev(2), dev(3), 9, 4100, 3, 1, dev(9), None),
+        "lag_grad unaligned": lambda: lib.xde_lag_grad(dev(1), dev(2) + 8, dev(3), 50, 700, 3, 0, dev(9), None),
+        "scale_fanout": lambda: lib.xde_scale_fanout(outs, dev(1), coef, 3, None, n, 1, None),
+        "commit": lambda: lib.xde_commit(dev(5), dev(1), dev(2), dev(3), dev(4), n, 0, None),
+    }
+    for name, call in calls.items():
+        rc = call()
+        msg = lib.xde_last_error().decode()
+        assert rc == _hip.XDE_EHIP, (name, rc, msg)  # the arguments were fine; only the device is missing
+        assert msg, name
+    # with kernel timing on, the profiling scope's event bookkeeping runs too (events cannot be created without a device: refused, not crashed)
+    assert lib.xde_prof_enable(1) in (_hip.XDE_OK, _hip.XDE_EHIP)
+    lib.xde_stage_combine(dev(1), dev(2), None, ks, None, coef, 2, 0, 1.0, 0.1, None, n, 0, None, None, 0.0, 0, None)
+    assert lib.xde_prof_enable(0) in (_hip.XDE_OK, _hip.XDE_EHIP)

@@ -34,6 +34,11 @@ def test_bench_json_contract():
     # warmup + steps attempted, nothing skipped (+ the untimed settle attempts after which pipeline="auto" has captured its graph)
     assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"] and j["solver"]["settle_steps"] == 0
 
+    # VERDICT r04 (next 6): the same K-step block three times in one run (the first is `ms_per_step`), and what of a step is inside no kernel
+    assert len(j["ms_per_step_blocks"]) == 3 and j["ms_per_step_blocks"][0] == j["ms_per_step"] and all(b > 0 for b in j["ms_per_step_blocks"])
+    assert abs(j["gap_ms_per_step"] - (j["ms_per_step"] - j["solver_kernel_ms_per_step"] - j["func_ms_per_step"])) < 1e-9
+    assert len(j["gap_ms_per_step_blocks"]) == 3 and j["func_ms_per_step"] > 0
+
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["achieved"] > 0
@@ -92,10 +97,13 @@ def test_bench_gpus_2_refuses_on_a_one_gpu_box():
 
 
 def test_bench_rccl_group_of_one_reports_its_ranks():
-    r = _launch({"XDE_BENCH_FORCE_DIST": "1"}, "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "4096", "--pipeline", "lag", "--no-cpu-baseline")
+    r = _launch({"XDE_BENCH_FORCE_DIST": "1"}, "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "4096", "--pipeline", "lag", "--no-cpu-baseline",
+                "--exchange", "rccl")
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert j["rccl_ranks"] == 1 and j["n_gpus"] == 1
+    # BASELINE configs[3] names the RCCL all-reduce: its step time is a top-level key of every sharded line (here it IS the headline transport)
+    assert j["rccl_allreduce_ms_per_step"] == j["ms_per_step"] and "headline" in j["rccl_allreduce_transport"]
 
 
 def test_bench_parent_stops_a_job_that_never_finishes():
@@ -124,6 +132,7 @@ def test_bench_n_rank_line_names_devices_transport_and_alternatives():
     assert "xde_p2p_rk_control" in j["norm_exchange"]
     ab = j["exchange_ab"]
     assert ab["p2p"]["headline"] is True and ab["p2p"]["ms_per_step"] == j["ms_per_step"] and ab["allreduce"]["ms_per_step"] > 0
+    assert "rccl_allreduce_ms_per_step" in j and j["rccl_allreduce_ms_per_step"] is None  # (gloo rehearsal: there is no RCCL group to time)
 
 
 def test_bench_survives_a_peer_to_peer_probe_that_crashes():

@@ -37,8 +37,9 @@ def test_bench_refuses_more_ranks_than_gpus_without_touching_a_gpu():
 
 def test_bench_stage_watchdog_ends_a_rank_that_outlives_its_stage(tmp_path):
     """bench.py's per-rank stage clock (no GPU needed): a stage that outlives its limit ends the PROCESS with exit code 70, a line on stderr
-    naming rank and stage, and a status file the launching parent can read; `on_expire` hooks may choose another exit code (the extra
-    measurements of the N > 1 line print the main line and leave with 0)."""
+    naming rank and stage, and a status file the launching parent can read; `on_expire(stage)` hooks may choose another NON-ZERO exit code
+    (the extra measurements of the N > 1 line print the main line, marked with the stage, and leave with 75) — a hook that returns 0 does not
+    turn a hang into a success."""
     import json
     import os
     import subprocess
@@ -56,5 +57,8 @@ def test_bench_stage_watchdog_ends_a_rank_that_outlives_its_stage(tmp_path):
     import bench
 
     assert "rank 3: in stage 'communicator'" in bench._stage_report(str(tmp_path), 4) and "rank 0: never reported" in bench._stage_report(str(tmp_path), 4)
-    r = subprocess.run([sys.executable, "-c", code.format(root=root, hook=", on_expire=lambda: 0")], capture_output=True, text=True, timeout=120, env=env)
-    assert r.returncode == 0 and "over its limit" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code.format(root=root, hook=", on_expire=lambda stage: 75 if stage == 'communicator' else 1")],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 75 and "over its limit" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code.format(root=root, hook=", on_expire=lambda stage: 0")], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 70 and "over its limit" in r.stderr
