@@ -409,7 +409,7 @@ class HipBackend:
     def acquire_work(self, device, state_dtype):
         key = (device.index, state_dtype, self._stream_of(device))
         pool = self._work_pool.setdefault(key, [])
-        if pool and os.environ.get("XDE_NO_POOL", "0") != "1":
+        if pool:
             return pool.pop()
         w = _Work()
         w.key = key

@@ -139,7 +139,30 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
     }
     dt = T(dtd);
     coefficients();
-    if (have) {
+    // Launches of few streams (1-3 operands, the pre-summed stage) run SOFTWARE-PIPELINED on a smaller grid: the loads of vector
+    // i + stride are in flight while vector i is multiplied and stored (same per-lane bytes in flight from half the workgroups;
+    // a short launch spends a measurable part of its time dispatching workgroups).  a.pipe: host's choice (XDE_COMBINE_PIPE, A/B).
+    if ((PRE || NK <= 3) && a.pipe) {
+      if (have) {
+        for (int64_t in = i + stride; in < nvec; in += stride) {
+          P kn[NK];
+          P prn;
+          if (PRE) prn = P::load_nt(pre, in);
+#pragma unroll
+          for (int j = NK - 1; j >= 1; --j) kn[j] = ldk(kp[j], in);
+          P yn = ldy(y0, in);
+          kn[0] = ldk(kp[0], in);
+          finish(i, kk, pr, y);
+#pragma unroll
+          for (int j = 0; j < NK; ++j) kk[j] = kn[j];
+          pr = prn;
+          y = yn;
+          i = in;
+        }
+        finish(i, kk, pr, y);
+      }
+      i = nvec;  // (the plain loop below has nothing left)
+    } else if (have) {
       finish(i, kk, pr, y);
       i += stride;
     }
@@ -457,8 +480,14 @@ static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, con
   ProfScope prof(kid, double(nk + 2 + (out2 ? 1 : 0) + (pre ? 1 : 0)) * double(n) * elt);
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
   // adaptive stages with a control block on the 16-byte path: the launch reads the block behind its first loads (combine_body, LATE)
-  static const bool late_ok = env_int("XDE_COMBINE_LATE", 1) != 0;  // (0: the block is read first, as before round 5 — for A/B runs)
+  static const bool late_ok = env_flag("XDE_COMBINE_LATE", true);  // (0: the block is read first, as before round 5 — for A/B runs)
   const bool late = late_ok && vec && ctrl != nullptr && mode == XDE_COMBINE_RK && nk <= 7;
+  static const bool pipe_ok = env_flag("XDE_COMBINE_PIPE", true);
+  static const int pipe_grid = env_int("XDE_COMBINE_PIPE_GRID", 1024);
+  // (not for operands of >= 64 MiB: HBM-served, where two vectors of every stream in flight per wave cost DRAM page locality —
+  //  measured on the error-norm pass, xde_norm.hip)
+  a.pipe = (late && pipe_ok && (pre || nk <= 3) && !big_operand(n, dtype)) ? 1 : 0;
+  if (a.pipe && blocks > pipe_grid) g = dim3(static_cast<unsigned>(pipe_grid));
   if (!vec) ntp = 0;  // (element-wise path: unaligned views, never the hot path)
 #define L_(...) XDE_LAUNCH((__VA_ARGS__), g, b, st, prof, a)
 // the three cache policies of a kernel whose other template arguments are fixed (policy 1 exists on the LATE kernels only: it is the

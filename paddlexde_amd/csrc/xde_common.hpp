@@ -40,6 +40,13 @@ inline int env_int(const char* name, int dflt) {
   return x > 0 ? x : dflt;
 }
 
+// 0 / 1 switches (env_int keeps its default for anything that is not a positive number)
+inline bool env_flag(const char* name, bool dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  return atoi(v) != 0;
+}
+
 // XDE_NT: bit 0 = stream the dead operands of the error-norm kernel with non-temporal loads; bit 1 = stream every
 // operand load of the combine / error-norm kernels when one operand is >= XDE_NT_BYTES (default 64 MiB); bit 2 = honour
 // the caller's per-operand last-use mask in the stage combines (-1.6 % step time on config 2).  Default 7.
@@ -59,16 +66,7 @@ inline bool big_operand(int64_t n, int dtype) {
   return (nt_policy() & 2) && n * (dtype == XDE_F32 ? 4 : 8) >= thr;
 }
 
-// grid of the (opt-in) ticketed error-norm + controller launch: the norm launches' own grid unless XDE_FUSED_GRID says
-// otherwise — with the same grid both paths reduce in the same order and give bit-identical results
 inline int norm_grid_cap();
-inline int fused_grid_cap() {
-  static int cap = [] {
-    const char* e = getenv("XDE_FUSED_GRID");
-    return (e && *e && atoi(e) > 0) ? atoi(e) : norm_grid_cap();
-  }();
-  return cap > XDE_MAX_PARTIALS ? XDE_MAX_PARTIALS : cap;
-}
 
 inline int grid_cap() {
   static int cap = env_int("XDE_GRID_BLOCKS", 2048);
@@ -195,7 +193,8 @@ struct CombineArgs {
   int64_t n;
   int nk;
   int use_sel;
-  int nt;  // non-temporal mask: bit j = stream operand k_j (its last use), bit 31 = stream y0
+  int nt;  // the launch's cache policy (combine_body, NTP): 0 default, 1 derivatives streamed, 2 everything streamed
+  int pipe;  // software-pipelined main loop (few-stream launches on a smaller grid)
 };
 
 struct SegMap {

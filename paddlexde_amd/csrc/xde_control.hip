@@ -394,7 +394,7 @@ int xde_error_norm_control(const void* const* k, const void* k0_alt, const doubl
   int nblocks = 0;
   double bytes = 0;
   rc = setup_err_args("xde_error_norm_control", k, k0_alt, c_err, nk, y0, y0_alt, y1, params->rtol, params->atol, 0.0, ctrl, segs,
-                      params->norm_kind, dtype, ws, e_pre, &a, &vec, &nblocks, &bytes, fused_grid_cap());
+                      params->norm_kind, dtype, ws, e_pre, &a, &vec, &nblocks, &bytes, norm_grid_cap());
   if (rc != XDE_OK) return rc;
   CtrlTail tl;
   tl.ctrl = ctrl;
@@ -465,7 +465,7 @@ int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void
   if (params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_rk_control: n_step_t > 0 without step_t_dev");
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_CONTROL, 0.0);
-  int cap = (norm_grid_cap() > fused_grid_cap() ? norm_grid_cap() : fused_grid_cap()) + XDE_MAX_SEG;  // the largest grid a norm launch uses (build_segmap: the cap + one block per segment)
+  int cap = norm_grid_cap() + XDE_MAX_SEG;  // the largest grid a norm launch uses (build_segmap: the cap + one block per segment)
   if (cap > XDE_MAX_PARTIALS) cap = XDE_MAX_PARTIALS;
   XDE_LAUNCH(xde_control_kernel, dim3(1), dim3(kBlock), st, prof, ctrl, *params, ws ? slot_ptr(ws, 0) : nullptr, sums,
              t_span_dev, step_t_dev, t_stage_out, host_mirror, ctrl_flags(), cap);

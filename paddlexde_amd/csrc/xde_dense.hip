@@ -369,7 +369,7 @@ static int dense_launch(const char* who_c, void* out_base, const void* const* k,
   int64_t blocks = (work + kBlock - 1) / kBlock;
   // predicated launch: most launches of the speculative pipeline exit at once, so keep the grid small (a no-op
   // launch costs ~5 us with 2048 workgroups); the streaming rate does not depend on the grid between 512 and 4096
-  static const int dense_grid = env_int("XDE_DENSE_GRID", 512);
+  constexpr int dense_grid = 512;  // (512 / 1024 / 2048 workgroups stream at the same rate, profiles/r03_dense.json; a predicated-off launch must stay cheap)
   const int64_t dense_cap = grid_cap() < dense_grid ? grid_cap() : dense_grid;
   if (blocks > dense_cap) blocks = dense_cap;
   if (blocks < 1) blocks = 1;

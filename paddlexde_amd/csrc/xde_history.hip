@@ -193,13 +193,22 @@ __device__ __forceinline__ void lag_finish(T* __restrict__ out, int L, int nb, L
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  // wave w finishes lags w, w + 4, ...: its lanes pull the lag's nb partials with independent loads (lane-strided), a shuffle tree
-  // adds them — a fixed order.  (One lane per lag adding nb dependent agent-scope loads in turn took 50 us of this kernel's 58.)
+  // wave w finishes lags w, w + 4, ...: its lanes pull the lag's nb partials lane-strided, EIGHT loads requested before the first
+  // is added (a dependent chain of agent-scope loads costs a memory round trip per link: 16 links at nb = 1024 were 24 us of a
+  // 24 us kernel), then a shuffle tree — a fixed order.
   for (int j = threadIdx.x >> 6; j < L; j += kWaves) {
     double v = 0.0;
-    for (int q = threadIdx.x & 63; q < nb; q += 64)
-      v += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(&ws->partial[int64_t(j) * nb + q]),
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&ws->partial[int64_t(j) * nb]);
+    for (int q0 = threadIdx.x & 63; q0 < nb; q0 += 64 * 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + 64 * u;
+        t[u] = q < nb ? __longlong_as_double((long long)__hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0) out[j] = T(v);

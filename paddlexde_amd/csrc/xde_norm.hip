@@ -253,15 +253,11 @@ int xde_error_norm_partial(const void* const* k, const void* k0_alt, const doubl
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_ERRNORM, bytes);
   dim3 g(nblocks), b(kBlock);
-  static const int pre_variant = [] {
-    const char* e = getenv("XDE_ERRNORM_PRE");
-    return (e && *e) ? atoi(e) : 1;
-  }();
   // (operands of >= 64 MiB are HBM-served, not Infinity-Cache-served: there the pipelined body's 8 streams per wave cost DRAM page
   //  locality — 82.4 vs 79.0 us at 128 MiB operands — so the general kernel keeps them; below, latency counts and the new body wins)
   int64_t tot_elems = 0;
   for (int s2 = 0; s2 < segs->n_seg; ++s2) tot_elems += segs->seg_len[s2];
-  const bool pre = vec && e_pre && nk == 1 && ctrl && a.k0_alt == a.k[0] && pre_variant != 0 && !big_operand(tot_elems, dtype);
+  const bool pre = vec && e_pre && nk == 1 && ctrl && a.k0_alt == a.k[0] && !big_operand(tot_elems, dtype);
 #define LAUNCH_ERR(T, NORM)                                                       \
   do {                                                                            \
     if (pre && a.nt)                                                              \

@@ -253,7 +253,7 @@ int xde_p2p_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const 
     const char* e = getenv("XDE_CTRL_FLAGS");
     return (e && *e) ? atoi(e) : 7;
   }();
-  int cap = (norm_grid_cap() > fused_grid_cap() ? norm_grid_cap() : fused_grid_cap()) + XDE_MAX_SEG;
+  int cap = norm_grid_cap() + XDE_MAX_SEG;
   if (cap > XDE_MAX_PARTIALS) cap = XDE_MAX_PARTIALS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_CONTROL, 0.0);

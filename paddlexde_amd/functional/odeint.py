@@ -39,7 +39,7 @@ def odeint(
         t_span = interop.to_torch(t_span) if interop.is_foreign(t_span) else t_span
         if importer is not None:
             inner = interop.adapt_func(func, importer)
-            with torch.no_grad():  # a foreign framework's func records no torch graph: forward only (use the C ABI binding to train)
+            with torch.no_grad():  # a foreign framework's func records no torch graph (training: functional.AdjointProblem + the caller's vjp)
                 sol = odeint(inner, y0, t_span, solver, rtol=rtol, atol=atol, options=options)
             return tuple(importer(v) for v in sol) if isinstance(sol, tuple) else importer(sol)
     if not torch.is_tensor(t_span):

@@ -2024,15 +2024,15 @@ def test_adjoint_captured_interval_solves(dev, solver_name, dtype, n_out, t_end)
                 assert torch.equal(a, b) and torch.equal(a, c), (call, float((a - b).abs().max()))
     import os
 
-    switched_off = os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0" or os.environ.get("XDE_HOST_FIRST_STEP", "0") == "1"
-    if str(dev).startswith("cuda") and not switched_off:  # (a kernel-policy run with the heuristic's scalars on the host solves per interval)
+    switched_off = os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0"
+    if str(dev).startswith("cuda") and not switched_off:  # (a kernel-policy run that solves per interval)
         ivs = [iv for g in OA._GRAPH_CACHE.get(m, {}).values() if not isinstance(g, OA._NoGraph) for iv in getattr(g, "_intervals", {}).values()]
         used = [iv for iv in ivs if isinstance(iv, OA._IntervalSolver)]
         assert len(used) == 2, ivs  # one per direction
         for iv in used:
             # three sweeps of n_out - 1 intervals each ran on it: the heuristic's 2 evaluations + at least one attempt per interval
             assert iv.solver.nfe >= 3 * (n_out - 1) * (2 + iv.solver._n_stage)
-            assert iv.solver._iv_first_graph is not None
+            assert iv.solver._intervals.first_graph is not None
 
 
 def test_adjoint_captured_sweep_with_a_repeated_final_output_time(dev):
@@ -2165,7 +2165,7 @@ def test_rearmable_interval_solver_equals_integrate(dev):
         if not s.intervals_supported():
             pytest.skip("the one-workgroup initial step is switched off by the environment")
         s.intervals_prepare((times[0], times[1]), capture=capture)
-        assert (s._iv_first_graph is not None) == capture
+        assert (s._intervals.first_graph is not None) == capture
         s.interval_state.copy_(y_start)
         for (a, b), ref in zip(zip(times[:-1], times[1:]), want):
             row = s.interval_solve((a, b))
@@ -2202,7 +2202,7 @@ def test_adjoint_captured_interval_solves_larger_state(dev):
         got = grads(graph_func=True)
         for a, b, c in zip(got, eager, per_eval):
             assert torch.equal(a, b) and torch.equal(a, c), (call, float((a - b).abs().max()))
-    switched_off = os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0" or os.environ.get("XDE_HOST_FIRST_STEP", "0") == "1"
+    switched_off = os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0"
     if str(dev).startswith("cuda") and not switched_off:
         ivs = [iv for g in OA._GRAPH_CACHE.get(m, {}).values() if not isinstance(g, OA._NoGraph) for iv in getattr(g, "_intervals", {}).values()]
         used = [iv for iv in ivs if isinstance(iv, OA._IntervalSolver)]

@@ -14,7 +14,7 @@ import torch
 
 from oracle import xde_oracle as O
 from paddlexde_amd import _hip
-from paddlexde_amd.solver.base_adaptive_solver_rk import _build_plans
+from paddlexde_amd.solver._rk_plans import build_plans as _build_plans
 from paddlexde_amd.solver.adaptive_solver import Bosh3, Dopri5, Dopri8
 
 from . import problems as P
@@ -272,7 +272,7 @@ def test_initial_step_vs_oracle_select_initial_step(dev, dtype, direction):
     s.y0 = y0d
     s._before_integrate(t_span.astype(np.float32 if dtype == np.float32 else np.float64))
     rel = 3e-6 if dtype == np.float32 else 1e-12
-    if hasattr(s, "_first_step_dbg"):  # (absent under XDE_HOST_FIRST_STEP=1, which takes the host statement of the heuristic)
+    if hasattr(s, "_first_step_dbg"):  # (absent where the heuristic's scalars go through the host: a custom norm)
         res, hs = s._first_step_dbg
         res, hs = res.cpu().numpy(), hs.cpu().numpy()
         # (1) the norms
@@ -322,13 +322,12 @@ def test_fused_initial_step_equals_the_separate_launches_and_the_oracle(dev, dty
     tsp = t_span.astype(np.float32 if dtype == np.float32 else np.float64)
 
     def run(fused):
-        monkeypatch.setenv("XDE_FUSED_FIRST_STEP", "1" if fused else "0")
-        s = Solver(xde=BaseODE(f_t, y0=y0d, t_span=torch.from_numpy(t_span)), y0=y0d, rtol=rtol, atol=atol,
+        s = Solver(xde=BaseODE(f_t, y0=y0d, t_span=torch.from_numpy(t_span)), y0=y0d, rtol=rtol, atol=atol, _fused_first_step=fused,
                    norm=_rms_norm if norm_name == "rms" else _linf_norm, dtype=tdt, step_t=torch.tensor([direction * 0.2500001, direction * 2.0]))
         s.y0 = y0d
         s._before_integrate(tsp)
-        if not s._small_state or not s._device_first_step:
-            pytest.skip("XDE_SINGLE_ELEMS=0 / XDE_HOST_FIRST_STEP=1: the one-workgroup device path of the heuristic is switched off")
+        if not s._small_state:
+            pytest.skip("XDE_SINGLE_ELEMS=0: the one-workgroup device path of the heuristic is switched off")
         assert s._fused_first_step() == fused and s._ctrl_ready == fused
         res, hs = s._first_step_dbg
         return s, float(res.cpu().numpy()[0]), hs.cpu().numpy()[:4].copy(), be.ctrl_read(s._ctrl), s._t_stage.cpu().numpy().copy()
