@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define XDE_ABI_VERSION 5
+#define XDE_ABI_VERSION 6
 
 #define XDE_OK 0
 #define XDE_EBADARG 1
@@ -158,8 +158,8 @@ int64_t xde_workspace_bytes(void);
  *   else dt_host.  If y0_alt/k0_alt != NULL and ctrl != NULL the kernel uses (y0_alt, k0_alt) in
  *   place of (y0, k[0]) when ctrl->accept != 0 (speculative enqueue: the host does not yet know
  *   whether the previous step was accepted).
- *   out2/coef2 (optional, RK mode): a second output out2 = sum_j k_j * (dt * coef2_j) formed from the SAME loaded
- *   operands.  The last stage of an FSAL pair loads exactly the operands the error estimate needs, so it emits the
+ *   out2/coef2 (optional, RK mode; FUSE mode: see xde_stage_combine_pre_weighted): a second output
+ *   out2 = sum_j k_j * (dt * coef2_j) formed from the SAME loaded operands.  The last stage of an FSAL pair loads exactly the operands the error estimate needs, so it emits the
  *   partial error sum there (`y1_error` minus its last term, base_adaptive_solver_rk.py:180) and the error-norm
  *   kernel reads 4 arrays instead of 8 (xde_error_norm_partial, e_pre).
  *   damping (FUSE/WFUSE): lambda of the delay-equation wrapper's fuse, `y = dy*dt + y0; (dy - lambda*y)*dt + y0`
@@ -185,6 +185,18 @@ int xde_stage_combine(void* out, const void* y0, const void* y0_alt, const void*
  */
 int xde_stage_combine_pre(void* out, const void* y0, const void* y0_alt, const void* pre, const void* const* k, const double* coef,
                           int nk, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, uint32_t nt_mask, void* stream);
+
+/*
+ * The same pre-summing for the FIXED-step solvers' final weighted sum (ABI 6): `y1 = (fuse(k1) w_1 + fuse(k2) w_2 + ... ) * scale`
+ * (rk4_alt_step_func, solver/base_fixed_solver.py:190-197; rk4_step_func :160-164).  The launch that forms the LAST stage input holds
+ * k_1..k_{s-1} anyway: with mode FUSE, `out2` / `coef2_j = w_j` it also emits `sum_j fuse(k_j, dt, y0) coef2_j` (left to right, no `dt`
+ * on the weights); the final launch then reads y0, that partial sum and the newest derivative(s):
+ *     out = ((pre + fuse(k_0, dt, y0) coef_0) + ...) * scale               — the full launch's association, bit for bit —
+ * RK4: 3 arrays in instead of 5, the emitting launch writes one more: 18 N -> 17 N elements per step.
+ */
+int xde_stage_combine_pre_weighted(void* out, const void* y0, const void* pre, const void* const* k, const double* coef, int nk,
+                                   double scale, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, double damping,
+                                   void* stream);
 
 /*
  * Error-norm partials — replaces `y1_error = sum(k * (dt * c_error), -1)` (base_adaptive_solver_rk.py:180),

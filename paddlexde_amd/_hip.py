@@ -14,7 +14,7 @@ import torch
 
 XDE_OK, XDE_EBADARG, XDE_EHIP, XDE_ETIMEOUT = 0, 1, 2, 3
 XDE_MIRROR_SLOTS = 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 XDE_F32, XDE_F64 = 0, 1
 XDE_MAX_K, XDE_MAX_SEG, XDE_MAX_STAGE = 14, 16, 13
 XDE_MAX_PACK = 64
@@ -37,6 +37,7 @@ SYMBOLS = (
     "xde_workspace_bytes",
     "xde_stage_combine",
     "xde_stage_combine_pre",
+    "xde_stage_combine_pre_weighted",
     "xde_error_norm_partial",
     "xde_error_norm_control",
     "xde_error_ratio",
@@ -206,6 +207,8 @@ def load_library():
         lib.xde_stage_combine.argtypes = [vp, vp, vp, vpp, vp, dp, i32, i32, dbl, dbl, vp, i64, i32, vp, dp, dbl, C.c_uint32, vp]
         lib.xde_stage_combine_pre.restype = i32
         lib.xde_stage_combine_pre.argtypes = [vp, vp, vp, vp, vpp, dp, i32, dbl, vp, i64, i32, C.c_uint32, vp]
+        lib.xde_stage_combine_pre_weighted.restype = i32
+        lib.xde_stage_combine_pre_weighted.argtypes = [vp, vp, vp, vpp, dp, i32, dbl, dbl, vp, i64, i32, dbl, vp]
         lib.xde_error_norm_partial.restype = i32
         lib.xde_error_norm_partial.argtypes = [vpp, vp, dp, i32, vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(XdeSegments), i32, i32, vp, vp, vp]
         lib.xde_error_norm_control.restype = i32
@@ -455,6 +458,17 @@ class HipBackend:
                                             len(ks), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype),
                                             int(nt_mask) & 0xFFFFFFFF, self._stream(out))
         self._check(rc, "xde_stage_combine_pre")
+
+    def stage_combine_pre_weighted(self, out, y0, pre, ks, coef, *, scale=1.0, dt_host=0.0, ctrl=None, damping=0.0):
+        """out = ((pre + fuse(ks[0]) coef[0]) + ...) * scale: a fixed-step solver's final weighted sum whose leading terms the last
+        stage-input launch (mode FUSE, ``out2`` / ``coef2``) has already summed into ``pre``."""
+        self._require_device(out, y0, pre, *ks)
+        if out.numel() == 0:
+            return
+        rc = self.lib.xde_stage_combine_pre_weighted(out.data_ptr(), y0.data_ptr(), pre.data_ptr(), _ptr_array(ks), _dbl_array(coef), len(ks),
+                                                     float(scale), float(dt_host), _ptr(ctrl), out.numel(), dtype_code(out.dtype),
+                                                     float(damping), self._stream(out))
+        self._check(rc, "xde_stage_combine_pre_weighted")
 
     def error_norm_partial(self, ks, c_err, y0, y1, rtol, atol, segs, norm_kind, ws, *, dt_host=0.0, ctrl=None,
                            y0_alt=None, k0_alt=None, e_pre=None):

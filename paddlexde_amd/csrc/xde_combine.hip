@@ -29,19 +29,19 @@ __device__ __forceinline__ T fuse_(T dy, T dt, T y0, T lam) {
 // ------------------------------------------------------------------------------------------
 // K1: stage combine
 // ------------------------------------------------------------------------------------------
-// LATE (adaptive stages on the 16-byte path, with a control block): the launch does NOT wait for the control block's `dt` / `accept`
-// words before its first loads.  The words are requested, then the first vector of every operand whose ADDRESS does not depend on
-// the speculative pipeline's select (k_1.., the pre-summed partial; all operands when the launch has no select) — and only then is
-// the select formed, y0 / k_0 loaded and the coefficients multiplied by dt: the block's memory round trip (cold in every launch: the
-// controller has just rewritten it) runs under the operands' own.  Same arithmetic, same order per element: same bits.
-//
 // NTP — the launch's cache policy, a COMPILE-TIME choice among three (round 5): 0 = default loads; 1 = every derivative k_j streamed
 // (non-temporal: this launch reads them for the last time in an accepted step — an FSAL pair's last stage), y0 default (the error
 // norm re-reads it); 2 = everything streamed (operands of >= 64 MiB: nothing survives in the Infinity Cache between uses).  Until
 // round 4 the policy was a run-time bit per operand: a branch around every load, and — where the two arms got different registers —
 // an `s_waitcnt vmcnt(0)` + register copies BETWEEN the loads of one iteration (NK = 6: five loads, wait, two loads), i.e. two
 // memory round trips per iteration instead of one.  A mask that is neither "none" nor "all" now takes policy 0.
-template <typename T, int MODE, int NK, bool VEC, bool OUT2, bool PRE = false, bool LATE = false, int NTP = 0>
+//
+// (Tried in round 5 and NOT kept, profiles/r05_combine_ab.txt — 8 alternating repetitions per variant: requesting the control block's
+// words and the select-independent operands BEFORE waiting for the block, the way the error-norm pass does: +0.46 us on the 1-3 operand
+// stages and +1.06 us on the pre-summed stage at 16 MiB operands (the compiler sinks the scalar loads behind the vector loads anyway,
+// and the peeled first iteration costs registers and code); a software-pipelined main loop on half the grid for the few-stream
+// launches: it only wins back what the first change lost.)
+template <typename T, int MODE, int NK, bool VEC, bool OUT2, bool PRE = false, int NTP = 0>
 __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __restrict__ y0,
                                              const T* __restrict__ k0, T dt) {
   const T* __restrict__ pre = static_cast<const T*>(a.pre);
@@ -54,24 +54,16 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
   const T* kp[NK];
   T c[NK];
   T c2[NK];
-  double dtd = 0.0;
-  int32_t accw = 0;
-  if (LATE) {  // requested here, waited for below the first loads
-    dtd = __builtin_nontemporal_load(&a.ctrl->dt);
-    accw = __builtin_nontemporal_load(&a.ctrl->accept);
-  }
   kp[0] = k0;
 #pragma unroll
   for (int j = 1; j < NK; ++j) kp[j] = static_cast<const T*>(a.k[j]);
-  auto coefficients = [&]() {
 #pragma unroll
-    for (int j = 0; j < NK; ++j) {
-      // reference: tableau cast to the state dtype, then `beta_i * dt` (RK) — or used as is (FUSE/WFUSE)
-      c[j] = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
-      c2[j] = OUT2 ? dt * T(a.coef2[j]) : T(0);  // `dt * tableau.c_error`
-    }
-  };
-  if (!LATE) coefficients();
+  for (int j = 0; j < NK; ++j) {
+    // reference: tableau cast to the state dtype, then `beta_i * dt` (RK) — or used as is (FUSE/WFUSE)
+    c[j] = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
+    // second output: RK -> `dt * tableau.c_error` (or the next stage's `beta * dt`); FUSE -> the weights of a later WFUSE launch
+    c2[j] = OUT2 ? (MODE == XDE_COMBINE_RK ? dt * T(a.coef2[j]) : T(a.coef2[j])) : T(0);
+  }
   const T scale = T(a.scale);
   const T lam = T(a.damp);
   const int64_t nvec = a.n / W;
@@ -98,8 +90,14 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
 #pragma unroll
         for (int j = 1; j < NK; ++j) acc = acc + kk[j].v[w] * c[j];
         o.v[w] = fuse_(acc, dt, y.v[w], lam);
+        if (OUT2) {  // the leading terms of the step's final weighted sum, from the operands this stage-input launch holds anyway
+          T e = fuse_(kk[0].v[w], dt, y.v[w], lam) * c2[0];
+#pragma unroll
+          for (int j = 1; j < NK; ++j) e = e + fuse_(kk[j].v[w], dt, y.v[w], lam) * c2[j];
+          o2.v[w] = e;
+        }
       } else {
-        T acc = fuse_(kk[0].v[w], dt, y.v[w], lam) * c[0];
+        T acc = PRE ? pr.v[w] + fuse_(kk[0].v[w], dt, y.v[w], lam) * c[0] : fuse_(kk[0].v[w], dt, y.v[w], lam) * c[0];
 #pragma unroll
         for (int j = 1; j < NK; ++j) acc = acc + fuse_(kk[j].v[w], dt, y.v[w], lam) * c[j];
         o.v[w] = acc * scale;
@@ -109,64 +107,6 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
     if (OUT2) o2.store(out2, i);
   };
   int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-  if (LATE) {
-    // In a pre-summed stage k_0 is the stage's newest derivative, not the select-able f0: only y0 hangs on the select there.
-    constexpr int kFirstFree = PRE ? 0 : 1;
-    const bool have = i < nvec;
-    const bool no_select = !a.use_sel;  // (a kernel argument: a scalar branch, known before anything is loaded)
-    P kk[NK];
-    P pr;
-    P y;
-    if (have) {
-      if (PRE) pr = P::load_nt(pre, i);
-#pragma unroll
-      for (int j = NK - 1; j >= kFirstFree; --j) kk[j] = ldk(kp[j], i);
-      if (no_select) {
-        y = ldy(y0, i);
-        if (!PRE) kk[0] = ldk(kp[0], i);
-      }
-    }
-    // (pinned: the scheduler otherwise hoists the select — and with it the wait for the control block's words — above the loads)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!no_select) {
-      const int sel = accw ? 1 : 0;
-      y0 = static_cast<const T*>(a.y0[sel]);
-      if (!PRE) kp[0] = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
-      if (have) {
-        y = ldy(y0, i);
-        if (!PRE) kk[0] = ldk(kp[0], i);
-      }
-    }
-    dt = T(dtd);
-    coefficients();
-    // Launches of few streams (1-3 operands, the pre-summed stage) run SOFTWARE-PIPELINED on a smaller grid: the loads of vector
-    // i + stride are in flight while vector i is multiplied and stored (same per-lane bytes in flight from half the workgroups;
-    // a short launch spends a measurable part of its time dispatching workgroups).  a.pipe: host's choice (XDE_COMBINE_PIPE, A/B).
-    if ((PRE || NK <= 3) && a.pipe) {
-      if (have) {
-        for (int64_t in = i + stride; in < nvec; in += stride) {
-          P kn[NK];
-          P prn;
-          if (PRE) prn = P::load_nt(pre, in);
-#pragma unroll
-          for (int j = NK - 1; j >= 1; --j) kn[j] = ldk(kp[j], in);
-          P yn = ldy(y0, in);
-          kn[0] = ldk(kp[0], in);
-          finish(i, kk, pr, y);
-#pragma unroll
-          for (int j = 0; j < NK; ++j) kk[j] = kn[j];
-          pr = prn;
-          y = yn;
-          i = in;
-        }
-        finish(i, kk, pr, y);
-      }
-      i = nvec;  // (the plain loop below has nothing left)
-    } else if (have) {
-      finish(i, kk, pr, y);
-      i += stride;
-    }
-  }
   for (; i < nvec; i += stride) {
     // NT: with operands of >= 64 MiB nothing survives in the 256 MiB Infinity Cache between uses anyway; streaming
     // loads then run 12-17 % faster (5.1 -> 5.8 TB/s at 128 MiB x 7 streams).  At the 32 MiB headline size the
@@ -191,12 +131,12 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, const T* __re
       T yv = y0[i];
       T acc;
       if (OUT2) {
-        T e = kp[0][i] * c2[0];
-        for (int j = 1; j < NK; ++j) e = e + kp[j][i] * c2[j];
+        T e = MODE == XDE_COMBINE_RK ? kp[0][i] * c2[0] : fuse_(kp[0][i], dt, yv, lam) * c2[0];
+        for (int j = 1; j < NK; ++j) e = e + (MODE == XDE_COMBINE_RK ? kp[j][i] : fuse_(kp[j][i], dt, yv, lam)) * c2[j];
         out2[i] = e;
       }
       if (MODE == XDE_COMBINE_WFUSE) {
-        acc = fuse_(kp[0][i], dt, yv, lam) * c[0];
+        acc = PRE ? pre[i] + fuse_(kp[0][i], dt, yv, lam) * c[0] : fuse_(kp[0][i], dt, yv, lam) * c[0];
         for (int j = 1; j < NK; ++j) acc = acc + fuse_(kp[j][i], dt, yv, lam) * c[j];
         out[i] = acc * scale;
       } else {
@@ -228,12 +168,15 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
       const T* kj = j == 0 ? k0 : static_cast<const T*>(a.k[j]);
       P kk = P::load(kj, i);
       T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
-      T c2j = has2 ? dt * T(a.coef2[j]) : T(0);
+      T c2j = has2 ? (MODE == XDE_COMBINE_RK ? dt * T(a.coef2[j]) : T(a.coef2[j])) : T(0);
 #pragma unroll
       for (int w = 0; w < W; ++w) {
         T term = (MODE == XDE_COMBINE_WFUSE) ? fuse_(kk.v[w], dt, y.v[w], lam) * cj : kk.v[w] * cj;
         acc.v[w] = (j == 0) ? term : acc.v[w] + term;
-        if (has2) e2.v[w] = (j == 0) ? kk.v[w] * c2j : e2.v[w] + kk.v[w] * c2j;
+        if (has2) {
+          const T t2 = (MODE == XDE_COMBINE_RK) ? kk.v[w] * c2j : fuse_(kk.v[w], dt, y.v[w], lam) * c2j;
+          e2.v[w] = (j == 0) ? t2 : e2.v[w] + t2;
+        }
       }
     }
     if (has2) e2.store(static_cast<T*>(a.out2), i);
@@ -258,7 +201,10 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
         T cj = (MODE == XDE_COMBINE_RK) ? T(a.coef[j]) * dt : T(a.coef[j]);
         T term = (MODE == XDE_COMBINE_WFUSE) ? fuse_(kj[i], dt, yv, lam) * cj : kj[i] * cj;
         acc = (j == 0) ? term : acc + term;
-        if (has2) e2 = (j == 0) ? kj[i] * (dt * T(a.coef2[j])) : e2 + kj[i] * (dt * T(a.coef2[j]));
+        if (has2) {
+          const T t2 = (MODE == XDE_COMBINE_RK) ? kj[i] * (dt * T(a.coef2[j])) : fuse_(kj[i], dt, yv, lam) * T(a.coef2[j]);
+          e2 = (j == 0) ? t2 : e2 + t2;
+        }
       }
       if (has2) static_cast<T*>(a.out2)[i] = e2;
       out[i] = (MODE == XDE_COMBINE_RK) ? yv + acc : (MODE == XDE_COMBINE_FUSE) ? fuse_(acc, dt, yv, lam) : acc * scale;
@@ -271,35 +217,28 @@ __device__ void combine_generic(const CombineArgs& a, const T* __restrict__ y0, 
 // (WIDE: the two-output launches are register-hungry — two accumulators per element on top of NK + 1 loads in flight — and a kernel's
 // allocation is that of its LARGEST case: with every operand count in one kernel the hot cases, Dopri5's 4- and 5-operand launches,
 // ran at the 7-operand case's 112 VGPRs = 4 waves per SIMD.  The two-output kernel therefore exists twice: up to 5 operands, and beyond.)
-template <typename T, int MODE, bool VEC, bool OUT2, bool LATE = false, int NTP = 0, bool WIDE = false>
+template <typename T, int MODE, bool VEC, bool OUT2, int NTP = 0, bool WIDE = false>
 __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
   int sel = 0;
-  T dt = T(0);
-  if (!LATE) {  // (LATE: combine_body reads the control block itself, behind its first loads)
-    if (a.ctrl) {
-      read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
-    } else {
-      dt = T(a.dt_host);
-    }
+  T dt;
+  if (a.ctrl) {
+    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
+  } else {
+    dt = T(a.dt_host);
   }
   const T* y0 = static_cast<const T*>(a.y0[sel]);
   const T* k0 = static_cast<const T*>(sel ? a.k0_alt : a.k[0]);
   constexpr bool kLow = !(OUT2 && WIDE);   // this kernel holds the cases of 1..5 operands
   constexpr bool kHigh = !OUT2 || WIDE;    // ... and those of 6, 7 and more
   switch (a.nk) {
-    case 1: if (kLow) combine_body<T, MODE, 1, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
-    case 2: if (kLow) combine_body<T, MODE, 2, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
-    case 3: if (kLow) combine_body<T, MODE, 3, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
-    case 4: if (kLow) combine_body<T, MODE, 4, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
-    case 5: if (kLow) combine_body<T, MODE, 5, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
-    case 6: if (kHigh) combine_body<T, MODE, 6, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
-    case 7: if (kHigh) combine_body<T, MODE, 7, VEC, OUT2, false, LATE, NTP>(a, y0, k0, dt); break;
-    default:
-      if (kHigh) {
-        if (LATE) read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
-        combine_generic<T, MODE, VEC, OUT2>(a, static_cast<const T*>(a.y0[sel]), static_cast<const T*>(sel ? a.k0_alt : a.k[0]), dt);
-      }
-      break;
+    case 1: if (kLow) combine_body<T, MODE, 1, VEC, OUT2, false, NTP>(a, y0, k0, dt); break;
+    case 2: if (kLow) combine_body<T, MODE, 2, VEC, OUT2, false, NTP>(a, y0, k0, dt); break;
+    case 3: if (kLow) combine_body<T, MODE, 3, VEC, OUT2, false, NTP>(a, y0, k0, dt); break;
+    case 4: if (kLow) combine_body<T, MODE, 4, VEC, OUT2, false, NTP>(a, y0, k0, dt); break;
+    case 5: if (kLow) combine_body<T, MODE, 5, VEC, OUT2, false, NTP>(a, y0, k0, dt); break;
+    case 6: if (kHigh) combine_body<T, MODE, 6, VEC, OUT2, false, NTP>(a, y0, k0, dt); break;
+    case 7: if (kHigh) combine_body<T, MODE, 7, VEC, OUT2, false, NTP>(a, y0, k0, dt); break;
+    default: if (kHigh) combine_generic<T, MODE, VEC, OUT2>(a, y0, k0, dt); break;
   }
 }
 
@@ -307,24 +246,22 @@ __global__ __launch_bounds__(kBlock) void xde_combine_kernel(CombineArgs a) {
 // `sum_j k_j (beta_ij dt)` over them as its second output): this launch reads y0, that partial sum and the newest derivative(s) —
 // Dopri5's stage 5: 3 arrays in, 1 out, instead of 6 in, 1 out; the emitting launch writes one array more.  Same left-to-right
 // association as the full sum (`((..) + k_3 c_3) + k_4 c_4`, then `y0 +`): bit-identical.  Its own instantiation (registers).
-template <typename T, bool VEC, bool LATE = false, int NTP = 0>
+template <typename T, bool VEC, int MODE = XDE_COMBINE_RK, int NTP = 0>
 __global__ __launch_bounds__(kBlock) void xde_combine_pre_kernel(CombineArgs a) {
   int sel = 0;
-  T dt = T(0);
-  if (!LATE) {
-    if (a.ctrl) {
-      read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
-    } else {
-      dt = T(a.dt_host);
-    }
+  T dt;
+  if (a.ctrl) {
+    read_dt_sel<T>(a.ctrl, a.use_sel, dt, sel);
+  } else {
+    dt = T(a.dt_host);
   }
   const T* y0 = static_cast<const T*>(a.y0[sel]);
   const T* k0 = static_cast<const T*>(a.k[0]);  // (not the select-able f0: the operands here are the stage's NEWEST derivatives)
   switch (a.nk) {
-    case 1: combine_body<T, XDE_COMBINE_RK, 1, VEC, false, true, LATE, NTP>(a, y0, k0, dt); break;
-    case 2: combine_body<T, XDE_COMBINE_RK, 2, VEC, false, true, LATE, NTP>(a, y0, k0, dt); break;
-    case 3: combine_body<T, XDE_COMBINE_RK, 3, VEC, false, true, LATE, NTP>(a, y0, k0, dt); break;
-    default: combine_body<T, XDE_COMBINE_RK, 4, VEC, false, true, LATE, NTP>(a, y0, k0, dt); break;
+    case 1: combine_body<T, MODE, 1, VEC, false, true, NTP>(a, y0, k0, dt); break;
+    case 2: combine_body<T, MODE, 2, VEC, false, true, NTP>(a, y0, k0, dt); break;
+    case 3: combine_body<T, MODE, 3, VEC, false, true, NTP>(a, y0, k0, dt); break;
+    default: combine_body<T, MODE, 4, VEC, false, true, NTP>(a, y0, k0, dt); break;
   }
 }
 
@@ -423,6 +360,15 @@ int xde_stage_combine_pre(void* out, const void* y0, const void* y0_alt, const v
                             nt_mask, pre, stream);
 }
 
+int xde_stage_combine_pre_weighted(void* out, const void* y0, const void* pre, const void* const* k, const double* coef, int nk,
+                                   double scale, double dt_host, const xde_ctrl_t* ctrl, int64_t n, int dtype, double damping,
+                                   void* stream) {
+  if (!pre) return fail(XDE_EBADARG, "xde_stage_combine_pre_weighted: null pointer");
+  if (nk < 1 || nk > 4) return fail(XDE_EBADARG, "xde_stage_combine_pre_weighted: 1..4 new operands");
+  return stage_combine_impl(out, y0, nullptr, k, nullptr, coef, nk, XDE_COMBINE_WFUSE, scale, dt_host, ctrl, n, dtype, nullptr, nullptr,
+                            damping, 0, pre, stream);
+}
+
 static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, const void* const* k, const void* k0_alt,
                               const double* coef, int nk, int mode, double scale, double dt_host, const xde_ctrl_t* ctrl,
                               int64_t n, int dtype, void* out2, const double* coef2, double damping, uint32_t nt_mask,
@@ -435,7 +381,8 @@ static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, con
   if (!pre && (y0_alt == nullptr) != (k0_alt == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: y0_alt/k0_alt must come together");
   if (y0_alt && !ctrl) return fail(XDE_EBADARG, "xde_stage_combine: operand select needs ctrl");
   if ((out2 == nullptr) != (coef2 == nullptr)) return fail(XDE_EBADARG, "xde_stage_combine: out2/coef2 must come together");
-  if (out2 && mode != XDE_COMBINE_RK) return fail(XDE_EBADARG, "xde_stage_combine: second output needs mode RK");
+  if (out2 && mode == XDE_COMBINE_WFUSE) return fail(XDE_EBADARG, "xde_stage_combine: second output needs mode RK or FUSE");
+  if (out2 && mode == XDE_COMBINE_FUSE && nk > 5) return fail(XDE_EBADARG, "xde_stage_combine: a FUSE launch emits for at most 5 operands");
   if (n == 0) return XDE_OK;
   CombineArgs a;
   memset(&a, 0, sizeof(a));
@@ -479,34 +426,15 @@ static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, con
   const int kid = mode == XDE_COMBINE_RK ? XDE_KID_COMBINE : (mode == XDE_COMBINE_FUSE ? XDE_KID_COMBINE_FUSE : XDE_KID_COMBINE_WFUSE);
   ProfScope prof(kid, double(nk + 2 + (out2 ? 1 : 0) + (pre ? 1 : 0)) * double(n) * elt);
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
-  // adaptive stages with a control block on the 16-byte path: the launch reads the block behind its first loads (combine_body, LATE)
-  static const bool late_ok = env_flag("XDE_COMBINE_LATE", true);  // (0: the block is read first, as before round 5 — for A/B runs)
-  const bool late = late_ok && vec && ctrl != nullptr && mode == XDE_COMBINE_RK && nk <= 7;
-  static const bool pipe_ok = env_flag("XDE_COMBINE_PIPE", true);
-  static const int pipe_grid = env_int("XDE_COMBINE_PIPE_GRID", 1024);
-  // (not for operands of >= 64 MiB: HBM-served, where two vectors of every stream in flight per wave cost DRAM page locality —
-  //  measured on the error-norm pass, xde_norm.hip)
-  a.pipe = (late && pipe_ok && (pre || nk <= 3) && !big_operand(n, dtype)) ? 1 : 0;
-  if (a.pipe && blocks > pipe_grid) g = dim3(static_cast<unsigned>(pipe_grid));
   if (!vec) ntp = 0;  // (element-wise path: unaligned views, never the hot path)
+  if (mode != XDE_COMBINE_RK && ntp == 1) ntp = 0;  // (policy 1 is the adaptive solver's hint)
 #define L_(...) XDE_LAUNCH((__VA_ARGS__), g, b, st, prof, a)
-// the three cache policies of a kernel whose other template arguments are fixed (policy 1 exists on the LATE kernels only: it is the
-// adaptive solver's hint, and that solver always passes a control block)
+// the cache policies of a kernel whose other template arguments are fixed
 #define L_NTP3(PFX, ...)                          \
   do {                                            \
     if (ntp == 2) L_(PFX<__VA_ARGS__, 2>);        \
     else if (ntp == 1) L_(PFX<__VA_ARGS__, 1>);   \
     else L_(PFX<__VA_ARGS__, 0>);                 \
-  } while (0)
-#define L_NTP2(PFX, ...)                          \
-  do {                                            \
-    if (ntp == 2) L_(PFX<__VA_ARGS__, 2>);        \
-    else L_(PFX<__VA_ARGS__, 0>);                 \
-  } while (0)
-#define LAUNCH_COMBINE(T, MODE)                                        \
-  do {                                                                 \
-    if (vec) L_NTP2(xde_combine_kernel, T, MODE, true, false, false);  \
-    else L_(xde_combine_kernel<T, MODE, false, false>);                \
   } while (0)
 #define L_NTP3W(PFX, ...)                              \
   do {                                                 \
@@ -514,30 +442,49 @@ static int stage_combine_impl(void* out, const void* y0, const void* y0_alt, con
     else if (ntp == 1) L_(PFX<__VA_ARGS__, 1, true>);  \
     else L_(PFX<__VA_ARGS__, 0, true>);                \
   } while (0)
-#define LAUNCH_COMBINE2(T)                                                                       \
-  do {                                                                                           \
-    if (late && nk <= 5) L_NTP3(xde_combine_kernel, T, XDE_COMBINE_RK, true, true, true);        \
-    else if (late) L_NTP3W(xde_combine_kernel, T, XDE_COMBINE_RK, true, true, true);             \
-    else if (vec && nk <= 5) L_NTP2(xde_combine_kernel, T, XDE_COMBINE_RK, true, true, false);   \
-    else if (vec) L_(xde_combine_kernel<T, XDE_COMBINE_RK, true, true, false, 0, true>);         \
-    else if (nk <= 5) L_(xde_combine_kernel<T, XDE_COMBINE_RK, false, true>);                    \
-    else L_(xde_combine_kernel<T, XDE_COMBINE_RK, false, true, false, 0, true>);                 \
+#define L_NTP2(PFX, ...)                          \
+  do {                                            \
+    if (ntp == 2) L_(PFX<__VA_ARGS__, 2>);        \
+    else L_(PFX<__VA_ARGS__, 0>);                 \
   } while (0)
-#define LAUNCH_PRE(T)                                              \
-  do {                                                             \
-    if (late) L_NTP3(xde_combine_pre_kernel, T, true, true);       \
-    else if (vec) L_NTP2(xde_combine_pre_kernel, T, true, false);  \
-    else L_(xde_combine_pre_kernel<T, false>);                     \
+#define LAUNCH_COMBINE(T, MODE)                                 \
+  do {                                                          \
+    if (vec) L_NTP2(xde_combine_kernel, T, MODE, true, false);  \
+    else L_(xde_combine_kernel<T, MODE, false, false>);         \
   } while (0)
-  if (pre) {
+#define LAUNCH_COMBINE2(T)                                                                \
+  do {                                                                                    \
+    if (vec && nk <= 5) L_NTP3(xde_combine_kernel, T, XDE_COMBINE_RK, true, true);        \
+    else if (vec) L_NTP3W(xde_combine_kernel, T, XDE_COMBINE_RK, true, true);             \
+    else if (nk <= 5) L_(xde_combine_kernel<T, XDE_COMBINE_RK, false, true>);             \
+    else L_(xde_combine_kernel<T, XDE_COMBINE_RK, false, true, 0, true>);                 \
+  } while (0)
+#define LAUNCH_PRE(T)                                                      \
+  do {                                                                     \
+    if (vec) L_NTP3(xde_combine_pre_kernel, T, true, XDE_COMBINE_RK);      \
+    else L_(xde_combine_pre_kernel<T, false>);                             \
+  } while (0)
+  if (pre && mode == XDE_COMBINE_WFUSE) {  // the fixed-step solvers' final weighted sum, its leading terms pre-summed (RK4: 6 -> 4 arrays)
+    if (dtype == XDE_F32) {
+      if (vec) L_NTP2(xde_combine_pre_kernel, float, true, XDE_COMBINE_WFUSE); else L_(xde_combine_pre_kernel<float, false, XDE_COMBINE_WFUSE>);
+    } else {
+      if (vec) L_NTP2(xde_combine_pre_kernel, double, true, XDE_COMBINE_WFUSE); else L_(xde_combine_pre_kernel<double, false, XDE_COMBINE_WFUSE>);
+    }
+  } else if (pre) {
     if (dtype == XDE_F32) LAUNCH_PRE(float);
     else LAUNCH_PRE(double);
+  } else if (out2 && mode == XDE_COMBINE_FUSE) {  // a fixed-step stage input that also emits the final sum's leading terms
+    if (dtype == XDE_F32) {
+      if (vec) L_NTP2(xde_combine_kernel, float, XDE_COMBINE_FUSE, true, true); else L_(xde_combine_kernel<float, XDE_COMBINE_FUSE, false, true>);
+    } else {
+      if (vec) L_NTP2(xde_combine_kernel, double, XDE_COMBINE_FUSE, true, true); else L_(xde_combine_kernel<double, XDE_COMBINE_FUSE, false, true>);
+    }
   } else if (out2) {
     if (dtype == XDE_F32) LAUNCH_COMBINE2(float);
     else LAUNCH_COMBINE2(double);
-  } else if (late) {
-    if (dtype == XDE_F32) L_NTP3(xde_combine_kernel, float, XDE_COMBINE_RK, true, false, true);
-    else L_NTP3(xde_combine_kernel, double, XDE_COMBINE_RK, true, false, true);
+  } else if (mode == XDE_COMBINE_RK && vec) {
+    if (dtype == XDE_F32) L_NTP3(xde_combine_kernel, float, XDE_COMBINE_RK, true, false);
+    else L_NTP3(xde_combine_kernel, double, XDE_COMBINE_RK, true, false);
   } else if (dtype == XDE_F32) {
     if (mode == XDE_COMBINE_RK) LAUNCH_COMBINE(float, XDE_COMBINE_RK);
     else if (mode == XDE_COMBINE_FUSE) LAUNCH_COMBINE(float, XDE_COMBINE_FUSE);

@@ -194,7 +194,6 @@ struct CombineArgs {
   int nk;
   int use_sel;
   int nt;  // the launch's cache policy (combine_body, NTP): 0 default, 1 derivatives streamed, 2 everything streamed
-  int pipe;  // software-pipelined main loop (few-stream launches on a smaller grid)
 };
 
 struct SegMap {

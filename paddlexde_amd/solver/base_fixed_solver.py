@@ -103,25 +103,53 @@ class FixedSolver(metaclass=abc.ABCMeta):
             f = f.clone()
         return f
 
-    def _combine(self, y0, ks, coef, mode, dt, scale=1.0, out=None):
+    def _combine(self, y0, ks, coef, mode, dt, scale=1.0, out=None, emit=None):
+        """One xde_stage_combine launch.  ``emit`` (a FUSE launch that is not being differentiated): the weights of the step's final
+        sum over the operands this launch holds — it then also writes that partial sum and ``(out, partial)`` is returned."""
         if self._rec is not None:
             self._rec.append(dt)
-            return None
+            return None if emit is None else (None, None)
         damp = self._damping if mode != _hip.COMBINE_RK else 0.0
+        part = torch.empty_like(y0) if emit is not None else None
         if self._g_ctrls is not None:  # graph pipeline: dt is read from device memory (rewritten before every replay)
             ctrl = self._g_ctrls[self._g_slot]
             self._g_slot += 1
             if out is None:
                 out = torch.empty_like(y0)
-            self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, ctrl=ctrl, damping=damp)
-            return out
-        if torch.is_grad_enabled() and (y0.requires_grad or any(k.requires_grad for k in ks)):
+            self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, ctrl=ctrl, damping=damp, out2=part, coef2=emit)
+            return out if emit is None else (out, part)
+        if emit is None and torch.is_grad_enabled() and (y0.requires_grad or any(k.requires_grad for k in ks)):
             # discretise-then-optimise: keep the autograd graph through the combine
             return CombineFn.apply(self.backend, list(coef), mode, scale, float(dt), damp, y0, *ks)
         if out is None:
             out = torch.empty_like(y0)
-        self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, dt_host=float(dt), damping=damp)
+        self.backend.stage_combine(out, y0, ks, coef, mode, scale=scale, dt_host=float(dt), damping=damp, out2=part, coef2=emit)
+        return out if emit is None else (out, part)
+
+    def _combine_pre(self, y0, pre, ks, coef, dt, scale, out=None):
+        """The final weighted sum with its leading terms pre-summed (xde_stage_combine_pre_weighted): reads y0, ``pre`` and the newest
+        derivative(s)."""
+        if self._rec is not None:
+            self._rec.append(dt)
+            return None
+        if out is None:
+            out = torch.empty_like(y0)
+        ctrl = None
+        if self._g_ctrls is not None:
+            ctrl = self._g_ctrls[self._g_slot]
+            self._g_slot += 1
+        self.backend.stage_combine_pre_weighted(out, y0, pre, ks, coef, scale=scale, dt_host=0.0 if ctrl is not None else float(dt), ctrl=ctrl,
+                                                damping=self._damping)
         return out
+
+    def _presum_ok(self, y0, ks):
+        """Whether the last stage-input launch may emit the final sum's leading terms: the backend offers it and nothing here is being
+        differentiated (the autograd node of a combine has one output).  Same bits either way."""
+        if not hasattr(self.backend, "stage_combine_pre_weighted"):
+            return False
+        if self._rec is not None:
+            return True  # (recording pass: the same launches, in the same order, either way)
+        return not (torch.is_grad_enabled() and (y0.requires_grad or any(k.requires_grad for k in ks)))
 
     # -- time handling ----------------------------------------------------------------------------
     def _host_dt(self, t0, t1):
@@ -431,6 +459,14 @@ class FixedSolver(metaclass=abc.ABCMeta):
             k1 = self._f(t0, dtt, y0)
         k2 = self._f(t_one_third, d13, self._combine(y0, [k1], [1.0], _hip.COMBINE_FUSE, dt * _one_third))
         k3 = self._f(t_two_thirds, d13, self._combine(y0, [k1, k2], [1.0, -_one_third], _hip.COMBINE_FUSE, dt))
-        k4 = self._f(t1, t_one_third, self._combine(y0, [k1, k2, k3], [1.0, -1.0, 1.0], _hip.COMBINE_FUSE, dt))
+        if self._presum_ok(y0, [k1, k2, k3]):
+            # the launch that forms k4's input holds k1..k3 anyway: it also emits `fuse(k1) + 3 fuse(k2) + 3 fuse(k3)` (left to right), and
+            # the final launch reads y0, that partial sum and k4 — 18 N -> 17 N elements per step, same association, same bits
+            y4, part = self._combine(y0, [k1, k2, k3], [1.0, -1.0, 1.0], _hip.COMBINE_FUSE, dt, emit=[1.0, 3.0, 3.0])
+            k4 = self._f(t1, t_one_third, y4)
+            if self._rec is not None or not (torch.is_grad_enabled() and k4.requires_grad):
+                return self._combine_pre(y0, part, [k4], [1.0], dt, 0.125, out=self._y1_out)
+        else:
+            k4 = self._f(t1, t_one_third, self._combine(y0, [k1, k2, k3], [1.0, -1.0, 1.0], _hip.COMBINE_FUSE, dt))
         return self._combine(y0, [k1, k2, k3, k4], [1.0, 3.0, 3.0, 1.0], _hip.COMBINE_WFUSE, dt, scale=0.125,
                              out=self._y1_out)

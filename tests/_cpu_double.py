@@ -90,6 +90,12 @@ class NumpyDoubleBackend:
                 for j in range(1, len(kk)):
                     acc = acc + kk[j] * cs[j]
                 o[...] = self._fuse(acc, dt, y, T(damping))
+                if out2 is not None:  # the leading terms of a later WFUSE launch: sum_j fuse(k_j) * w_j, left to right
+                    c2 = [T(c_) for c_ in coef2]
+                    e = self._fuse(kk[0], dt, y, T(damping)) * c2[0]
+                    for j in range(1, len(kk)):
+                        e = e + self._fuse(kk[j], dt, y, T(damping)) * c2[j]
+                    _np(out2).reshape(-1)[...] = e
             else:
                 cs = [T(c_) for c_ in coef]
                 acc = self._fuse(kk[0], dt, y, T(damping)) * cs[0]
@@ -115,6 +121,18 @@ class NumpyDoubleBackend:
             for k, c_ in zip(ks, coef):
                 acc = acc + _np(k).reshape(-1) * (T(c_) * dt)
             _np(out).reshape(-1)[...] = y + acc
+
+    def stage_combine_pre_weighted(self, out, y0, pre, ks, coef, *, scale=1.0, dt_host=0.0, ctrl=None, damping=0.0):
+        """Contract of xde_stage_combine_pre_weighted: out = ((pre + fuse(ks[0]) w_0) + ...) * scale."""
+        self.launches.append("combine")
+        T = _NP[out.dtype]
+        dt = T(self._c(ctrl).dt) if ctrl is not None else T(dt_host)
+        y = _np(y0).reshape(-1)
+        with np.errstate(all="ignore"):
+            acc = _np(pre).reshape(-1)
+            for k, c_ in zip(ks, coef):
+                acc = acc + self._fuse(_np(k).reshape(-1), dt, y, T(damping)) * T(c_)
+            _np(out).reshape(-1)[...] = acc * T(scale)
 
     @staticmethod
     def _fuse(dy, dt, y0, lam):

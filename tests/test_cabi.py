@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _hip.load_library()
     for sym in _declared():
         assert hasattr(lib, sym), sym
-    assert lib.xde_abi_version() == _hip.ABI_VERSION == 5
+    assert lib.xde_abi_version() == _hip.ABI_VERSION == 6
 
 
 def test_struct_layouts_match():
@@ -98,6 +98,7 @@ def test_every_entry_point_rejects_null_arguments():
     calls = {
         "xde_stage_combine": lambda: lib.xde_stage_combine(None, None, None, None, None, None, 1, 0, 1.0, 0.0, None, 8, 0, None, None, 0.0, 0, None),
         "xde_stage_combine_pre": lambda: lib.xde_stage_combine_pre(None, None, None, None, None, None, 1, 0.0, None, 8, 0, 0, None),
+        "xde_stage_combine_pre_weighted": lambda: lib.xde_stage_combine_pre_weighted(None, None, None, None, None, 1, 0.125, 0.0, None, 8, 0, 0.0, None),
         "xde_error_norm_partial": lambda: lib.xde_error_norm_partial(None, None, None, 1, None, None, None, 1e-3, 1e-6, 0.0, None, C.byref(S), 0, 0,
                                                                     None, None, None),
         "xde_error_norm_control": lambda: lib.xde_error_norm_control(None, None, None, 1, None, None, None, C.byref(S), 0, None, None, None,
@@ -266,6 +267,8 @@ def test_host_halves_run_up_to_the_launch_without_a_gpu():
         "stage_combine 14 operands": lambda: lib.xde_stage_combine(dev(1), dev(2), None, (vp * 14)(*[dev(40 + j) for j in range(14)]), None,
                                                                   (C.c_double * 14)(*([0.5] * 14)), 14, 0, 1.0, 0.1, None, n, 0, None, None, 0.0, 0, None),
         "stage_combine_pre": lambda: lib.xde_stage_combine_pre(dev(1), dev(2), dev(3), dev(7), ks, coef, 1, 0.0, dev(5), n, 0, 1, None),
+        "stage_combine FUSE + second output": lambda: lib.xde_stage_combine(dev(1), dev(2), None, ks, None, coef, 3, 1, 1.0, 0.01, None, n, 0, dev(6), coef, 0.001, 0, None),
+        "stage_combine_pre_weighted": lambda: lib.xde_stage_combine_pre_weighted(dev(1), dev(2), dev(7), ks, coef, 1, 0.125, 0.01, None, n, 1, 0.001, None),
         "error_norm_partial 3 segments": lambda: lib.xde_error_norm_partial(ks, None, coef, 6, dev(2), None, dev(8), 1e-5, 1e-7, 0.01, None, C.byref(segs), 0, 0,
                                                                            dev(9), None, None),
         "error_norm_partial fsal": lambda: lib.xde_error_norm_partial(ks, None, coef, 1, dev(2), dev(3), dev(8), 1e-5, 1e-7, 0.0, dev(5), C.byref(segs), 1, 1,

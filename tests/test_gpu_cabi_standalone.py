@@ -50,7 +50,7 @@ def test_dopri5_through_raw_c_abi():
     lib.xde_ctrl_read.argtypes = [vp, C.POINTER(Ctrl), vp]
     lib.xde_dense_eval.argtypes = [vp, vpp, vp, dp, i32, vp, vp, vp, vp, vp, vp, i32, i64, i32, i64, vp]
     lib.xde_sizeof_ctrl_params.restype = i64
-    assert lib.xde_abi_version() == 5
+    assert lib.xde_abi_version() == 6
     assert lib.xde_sizeof_ctrl() == C.sizeof(Ctrl)
     assert lib.xde_sizeof_ctrl_params() == C.sizeof(Params)  # a hand-written mirror must be checked before it is passed
 

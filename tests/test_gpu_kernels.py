@@ -823,3 +823,54 @@ def test_two_peeks_pending_on_one_recycled_control_block(be):
     del h3
     assert len(be._mirrors[w.ctrl.data_ptr()].peek) == len(pooled)
     be.release_work(w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n", [0, 1, 3, 257, 4096 + 5, 1 << 20])
+@pytest.mark.parametrize("damping", [0.0, 0.001])
+def test_pre_summed_final_weighted_sum_equals_the_full_launch_bit_for_bit(be, dbl, dtype, n, damping):
+    """VERDICT r04 (next 4b): RK4's final combine `(fuse(k1) + 3 fuse(k2) + 3 fuse(k3) + fuse(k4)) / 8` (rk4_alt_step_func,
+    solver/base_fixed_solver.py:190-197) pre-summed — the launch that forms k4's input (mode FUSE) also emits the first three terms, the
+    final launch (xde_stage_combine_pre_weighted) reads y0, that partial sum and k4: 18 N -> 17 N per step.  The pair must give EXACTLY
+    the full WFUSE launch's bits (same association), each launch must equal its numpy contract, with BaseODE's fuse and BaseDDE's damped
+    one, with `dt` from the host and from a control block, aligned and on unaligned views (scalar path)."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    y0 = _rand(n, dt, 1, dev)
+    ks = [_rand(n, dt, 10 + j, dev) for j in range(4)]
+    h = 0.0371
+    w = [1.0, 3.0, 3.0, 1.0]
+    y4, part = torch.empty_like(y0), torch.empty_like(y0)
+    be.stage_combine(y4, y0, ks[:3], [1.0, -1.0, 1.0], _hip.COMBINE_FUSE, dt_host=h, damping=damping, out2=part, coef2=w[:3])
+    alone = torch.empty_like(y0)
+    be.stage_combine(alone, y0, ks[:3], [1.0, -1.0, 1.0], _hip.COMBINE_FUSE, dt_host=h, damping=damping)
+    assert torch.equal(y4, alone)  # the second output does not disturb the first
+    out = torch.empty_like(y0)
+    be.stage_combine_pre_weighted(out, y0, part, ks[3:], w[3:], scale=0.125, dt_host=h, damping=damping)
+    full = torch.empty_like(y0)
+    be.stage_combine(full, y0, ks, w, _hip.COMBINE_WFUSE, scale=0.125, dt_host=h, damping=damping)
+    assert torch.equal(out, full)
+    ref4, refp, ref = torch.empty(n, dtype=dt), torch.empty(n, dtype=dt), torch.empty(n, dtype=dt)
+    dbl.stage_combine(ref4, y0.cpu(), [k.cpu() for k in ks[:3]], [1.0, -1.0, 1.0], _hip.COMBINE_FUSE, dt_host=h, damping=damping, out2=refp, coef2=w[:3])
+    dbl.stage_combine_pre_weighted(ref, y0.cpu(), refp, [ks[3].cpu()], w[3:], scale=0.125, dt_host=h, damping=damping)
+    assert torch.equal(y4.cpu(), ref4) and torch.equal(part.cpu(), refp) and torch.equal(out.cpu(), ref)
+    if n < 16:
+        return
+    # dt from a control block (the graph pipeline's source of dt), and unaligned partial sum / output (scalar path)
+    ctrl_h = _hip.XdeCtrl()
+    ctrl_h.dt = float(np.float32(0.0123))
+    ctrl = torch.frombuffer(bytearray(bytes(ctrl_h)), dtype=torch.uint8).to(dev)
+    big = _rand(3 * (n + 8), dt, 7, dev)
+    part_u, out_u = big[1 : 1 + n], big[n + 9 : 2 * n + 9]
+    be.stage_combine(y4, y0, ks[:3], [1.0, -1.0, 1.0], _hip.COMBINE_FUSE, ctrl=ctrl, damping=damping, out2=part_u, coef2=w[:3])
+    be.stage_combine_pre_weighted(out_u, y0, part_u, ks[3:], w[3:], scale=0.125, ctrl=ctrl, damping=damping)
+    be.stage_combine(full, y0, ks, w, _hip.COMBINE_WFUSE, scale=0.125, ctrl=ctrl, damping=damping)
+    assert torch.equal(out_u, full)
+    # refused: a second output in WFUSE mode; more than 5 emitting operands in FUSE mode; a null partial sum
+    lib = be.lib
+    six = (C.c_void_p * 6)(*[ks[j % 4].data_ptr() for j in range(6)])
+    cf = (C.c_double * 6)(*([1.0] * 6))
+    assert lib.xde_stage_combine(out.data_ptr(), y0.data_ptr(), None, six, None, cf, 3, _hip.COMBINE_WFUSE, 1.0, h, None, n, 0, part.data_ptr(), cf, 0.0, 0, None) == _hip.XDE_EBADARG
+    assert lib.xde_stage_combine(out.data_ptr(), y0.data_ptr(), None, six, None, cf, 6, _hip.COMBINE_FUSE, 1.0, h, None, n, 0, part.data_ptr(), cf, 0.0, 0, None) == _hip.XDE_EBADARG
+    assert lib.xde_stage_combine_pre_weighted(out.data_ptr(), y0.data_ptr(), None, six, cf, 1, 0.125, h, None, n, 0, 0.0, None) == _hip.XDE_EBADARG
