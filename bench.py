@@ -318,10 +318,15 @@ def side_workload(args):
 
 def rk4_workload(args):
     """The bandwidth-bound fixed-step line: the reference's RK4 (`rk4_alt_step_func`, solver/base_fixed_solver.py:166-197) on
-    config 2's state (65536 x 128 fp32, func = torch matmul).  One step = 4 func calls + 3 FUSE stage combines (3, 4, 5
-    arrays) + the WFUSE final combine (6 arrays, written straight into the output slice): 18 N 4 B = 604 MB algorithmic."""
+    config 2's state (65536 x 128 fp32, func = torch matmul).  One step = 4 func calls + 3 FUSE stage combines (3, 4, 5 + 1
+    arrays: the last one also emits the final sum's leading terms) + the final combine (4 arrays, written straight into the
+    output slice): 17 N 4 B = 570 MB (18 N before round 5's pre-summing; `--rk4-presum off` measures that form: same bits)."""
     from paddlexde_amd import RK4, _hip, odeint
+    from paddlexde_amd.solver.base_fixed_solver import FixedSolver
     from paddlexde_amd.utils import _rms_norm
+
+    if args.rk4_presum == "off":  # (A/B only: the full final combine)
+        FixedSolver._presum_ok = lambda self, y0, ks: False
 
     dev = torch.device("cuda", 0)
     B = 65536 if args.batch is None else args.batch
@@ -352,7 +357,8 @@ def rk4_workload(args):
         "value": N * K / elapsed, "unit": "states/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "linear ODE dy/dt=Ay, RK4 reference variant (rk4_alt_step_func), batch={} x dim={}, {} fixed steps, "
-                               "func = torch matmul".format(B, D, K), "global_batch": B, "dim": D},
+                               "func = torch matmul; final combine {}".format(B, D, K, "pre-summed (17 N per step)" if args.rk4_presum == "on" else "full (18 N per step)"),
+                   "global_batch": B, "dim": D},
         "finite": bool(torch.isfinite(sol[-B:]).all()),
     }
     if prof is not None:
@@ -856,6 +862,7 @@ def main():
     ap.add_argument("--no-ab", action="store_true", help="N>1: skip the short runs on the other norm-exchange transports (exchange_ab)")
     ap.add_argument("--no-odeint", action="store_true", help="N=1 headline: skip the whole-odeint() calls (odeint_ms_T2 / odeint_ms_T11)")
     ap.add_argument("--probe-p2p", action="store_true", help=argparse.SUPPRESS)  # internal: the child of a rank, see run_p2p_probe
+    ap.add_argument("--rk4-presum", default="on", choices=["on", "off"], help="--workload rk4: A/B of the pre-summed final combine")
     ap.add_argument("--no-n1", action="store_true", help="N>1: skip rank 0's extra single-GPU run of the same global problem (n1_same_workload)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-tunable-op", action="store_true",

@@ -92,7 +92,8 @@ typedef struct xde_ctrl {
   int32_t next_step_index; /* index into step_t (base_adaptive_solver_rk.py:109-111) */
   int32_t on_step_t; /* the pending dt was clipped to step_t[next_step_index] */
   int64_t seq;       /* controller launches so far (incl. no-op ones after `done`); orders the host mirror */
-  int32_t reserved[4];
+  uint64_t chk;      /* checksum of the block's other words (host mirror: a copy is accepted only if it holds; see xde_ctrl_wait) */
+  int32_t reserved[2];
 } xde_ctrl_t;
 
 #define XDE_MIRROR_SLOTS 16 /* host mirror ring: slot[seq % XDE_MIRROR_SLOTS] (a replayed hipGraph may hold several controller launches) */

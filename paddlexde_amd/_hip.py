@@ -106,7 +106,8 @@ class XdeCtrl(C.Structure):
         ("next_step_index", C.c_int32),
         ("on_step_t", C.c_int32),
         ("seq", C.c_int64),
-        ("reserved", C.c_int32 * 4),
+        ("chk", C.c_uint64),
+        ("reserved", C.c_int32 * 2),
     ]
 
 

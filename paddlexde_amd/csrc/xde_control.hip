@@ -28,15 +28,6 @@ __global__ __launch_bounds__(kBlock) void xde_control_kernel(xde_ctrl_t* c, xde_
   control_block<false>(c, p, slot, sums, t_span, step_t, t_stage_out, mirror, 0, 0, flags, partial_cap);
 }
 
-// XDE_CTRL_FLAGS: see publish_block (xde_control_device.hpp)
-inline int ctrl_flags() {
-  static int v = [] {
-    const char* e = getenv("XDE_CTRL_FLAGS");
-    return (e && *e) ? atoi(e) : 7;
-  }();
-  return v;
-}
-
 // Controller arguments of the fused launch
 struct CtrlTail {
   xde_ctrl_t* ctrl;
@@ -45,6 +36,7 @@ struct CtrlTail {
   const double* step_t;
   void* t_stage_out;
   xde_ctrl_t* mirror;
+  int flags;
 };
 
 // K2+K3 fused: every workgroup does the error-norm pass and publishes its partial; the workgroup whose ticket is the
@@ -71,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void xde_errnorm_control_kernel(ErrArgs a, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  control_block<true>(tl.ctrl, tl.p, a.slot, nullptr, tl.t_span, tl.step_t, tl.t_stage_out, tl.mirror, int(gridDim.x), NORM);
+  control_block<true>(tl.ctrl, tl.p, a.slot, nullptr, tl.t_span, tl.step_t, tl.t_stage_out, tl.mirror, int(gridDim.x), NORM, tl.flags);
   // every workgroup has arrived: re-arm the ticket words for the next launch
   if (threadIdx.x < kTicketShards)
     __hip_atomic_store(&a.slot->shard[threadIdx.x].count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -185,13 +177,13 @@ __global__ void xde_ctrl_init_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, double 
 // list that the last ACCEPTED step already covers are reported at once (the reference's `while next_t > rk_state.t1` is
 // false for them and it interpolates in the retained step); the `max_num_steps` count restarts, as it does per step() call.
 __global__ __launch_bounds__(64) void xde_ctrl_retarget_kernel(xde_ctrl_t* c, xde_ctrl_params_t p, const double* t_span,
-                                                               int32_t n_out, xde_ctrl_t* mirror) {
+                                                               int32_t n_out, xde_ctrl_t* mirror, int flags) {
   __shared__ xde_ctrl_t zs;
   constexpr int kWords = sizeof(xde_ctrl_t) / 8;
   if (threadIdx.x < kWords) {
     const uint64_t word = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
     reinterpret_cast<uint64_t*>(&zs)[threadIdx.x] = word;
-    if (mirror && threadIdx.x == offsetof(xde_ctrl_t, seq) / 8) invalidate_slot(mirror, int64_t(word) + 1);
+    if (mirror && !(flags & kCtrlChecksum) && threadIdx.x == offsetof(xde_ctrl_t, seq) / 8) invalidate_slot(mirror, int64_t(word) + 1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -210,7 +202,7 @@ __global__ __launch_bounds__(64) void xde_ctrl_retarget_kernel(xde_ctrl_t* c, xd
     if (z.status == XDE_STATUS_MAX_STEPS) z.status = XDE_STATUS_OK;
   }
   __syncthreads();
-  publish_block(c, zs, mirror);
+  publish_block(c, zs, mirror, flags);
 }
 
 // Hairer's initial-step heuristic, scalar part (solver/base_adaptive_solver.py:55-72), in the state dtype Y with the
@@ -403,6 +395,7 @@ int xde_error_norm_control(const void* const* k, const void* k0_alt, const doubl
   tl.step_t = step_t_dev;
   tl.t_stage_out = t_stage_out;
   tl.mirror = host_mirror;
+  tl.flags = ctrl_flags();
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_ERRNORM, bytes);
   {
@@ -495,7 +488,7 @@ int xde_ctrl_retarget(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const d
   if (rc != XDE_OK) return rc;
   if (n_out < 1) return fail(XDE_EBADARG, "xde_ctrl_retarget: n_out must be >= 1");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(xde_ctrl_retarget_kernel, dim3(1), dim3(64), 0, st, ctrl, *params, t_span_dev, n_out, host_mirror);
+  hipLaunchKernelGGL(xde_ctrl_retarget_kernel, dim3(1), dim3(64), 0, st, ctrl, *params, t_span_dev, n_out, host_mirror, ctrl_flags());
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }
@@ -602,16 +595,32 @@ int xde_host_free(void* ptr) {
   return XDE_OK;
 }
 
+// whether a copy of a mirror slot is one whole published block (CHECKSUMMED protocol, publish_block)
+static bool ctrl_copy_holds(const xde_ctrl_t& z) {
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(&z);
+  uint64_t sum = 0;
+  for (int i = 0; i < kCtrlWords; ++i) sum += ctrl_chk_term(w[i], i);
+  return sum == z.chk;
+}
+
 int xde_ctrl_wait(const xde_ctrl_t* host_mirror, int64_t seq, double timeout_ms, xde_ctrl_t* host_out) {
   if (!host_mirror || !host_out || seq < 0) return fail(XDE_EBADARG, "xde_ctrl_wait: bad argument");
   const xde_ctrl_t* slot = host_mirror + (seq % XDE_MIRROR_SLOTS);
+  const bool checksummed = (ctrl_flags() & kCtrlChecksum) != 0;
   const auto t_begin = std::chrono::steady_clock::now();
   uint64_t spins = 0;
   bool slow = false;
   for (;;) {
     int64_t cur = __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE);
-    if (cur == seq) break;
-    if (cur > seq) return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot already overwritten by a later launch");
+    if (cur == seq) {
+      if (!checksummed) break;
+      // the block's words arrive in no particular order: the copy counts only if it is one whole block (else: words still landing)
+      memcpy(host_out, slot, sizeof(xde_ctrl_t));
+      if (host_out->seq == seq && ctrl_copy_holds(*host_out)) return XDE_OK;
+    } else if (cur > seq && (!checksummed || cur - seq >= XDE_MIRROR_SLOTS)) {
+      // (checksummed: a sequence number ahead of ours can only be a LATER launch's word in this slot, i.e. seq + k * SLOTS)
+      return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot already overwritten by a later launch");
+    }
     if (slow || (++spins & 0x3ff) == 0) {
       double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
       if (ms > timeout_ms) return fail(XDE_ETIMEOUT, "xde_ctrl_wait: timed out waiting for the controller launch");

@@ -162,50 +162,89 @@ __device__ __forceinline__ void control_step(xde_ctrl_t* c, const xde_ctrl_param
   plan_next<TT>(c, p, step_t, t_stage_out, pf);
 }
 
-// The pinned host mirror slot of a control block is a seqlock (slot[seq % SLOTS]): its seq word is invalidated FIRST
-// (invalidate_slot — by one lane of wave 0, as early as the launch knows its sequence number, so that the store has long
-// landed when the payload is ready), the payload words follow, and the new seq is stored last after a system-scope
-// release.  A reader that sees the same valid seq before and after its copy has an untorn block (xde_ctrl_wait).
+// The pinned host mirror of a control block is a ring of XDE_MIRROR_SLOTS copies (slot[seq % SLOTS]).  Two publish protocols
+// (XDE_CTRL_FLAGS bit 8 selects; both leave the same block in device memory and in the slot):
+//
+//   CHECKSUMMED (default, round 5): the block carries a 64-bit checksum of its other words (`chk`, salted per position).  ONE wave
+//   stores all 36 words — sequence number and checksum included — to the slot in one instruction, with no ordering among them and no
+//   wait: the launch's only PCIe round trip is the one its end waits for anyway.  The reader (xde_ctrl_wait) polls `seq`, copies the
+//   slot and accepts the copy only if its sequence number is the expected one AND its checksum holds — a copy taken while words were
+//   still landing (a mix of this block and the one published 16 launches earlier) fails the check and is taken again.
+//
+//   SEQLOCK (rounds 2-4): `seq` is invalidated FIRST (invalidate_slot — by one lane of the publishing wave, as early as the launch
+//   knows its sequence number), the payload words follow, the new seq is stored last, each group acknowledged before the next is issued
+//   (`s_waitcnt vmcnt(0)` within the one publishing wave; full system-scope fences without bit 1): three dependent PCIe writes, 0.9-1.2
+//   us of the controller's 7, and — in the sharded attempt's one-launch controller — a host write in flight under the mailbox
+//   exchange's system-scope fences, which then wait for it: 3.7 us of its 9.6 (profiles/r05_ctrl_decomposition.txt).
 __device__ inline void invalidate_slot(xde_ctrl_t* mirror, int64_t seq_next) {
   __hip_atomic_store(&mirror[seq_next % XDE_MIRROR_SLOTS].seq, int64_t(-1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Write a finished control block back: one wave instruction to the device block, one to the mirror slot.  Called by all
-// threads of the block after `zs` is complete and visible in LDS and after invalidate_slot(mirror, zs.seq) by wave 0.
-// XDE_CTRL_FLAGS bits (kernel argument `flags`; all variants publish the same block and keep the same ordering contract):
-//   1  light ordering of the mirror stores: the invalidation, the payload and the new seq are write-through system-scope
-//      stores to fine-grained host memory issued by ONE wave, separated by `s_waitcnt vmcnt(0)` (each group is acknowledged
-//      before the next is issued) instead of full system-scope release fences, whose L2 write-back has nothing to do with
-//      these stores
+// XDE_CTRL_FLAGS bits (kernel argument `flags`; all variants publish the same block):
+//   1  SEQLOCK protocol only: light ordering of the mirror stores (`s_waitcnt` instead of system-scope release fences)
 //   2  header and partial records in one memory round trip (reduce_partials_speculative)
 //   4  the next output time / forced step time prefetched by spare lanes (TimePrefetch)
-constexpr int kCtrlLightPublish = 1, kCtrlSpecPartials = 2, kCtrlPrefetchTimes = 4;
+//   8  CHECKSUMMED publish (host side: xde_ctrl_wait validates instead of trusting the order of arrival)
+constexpr int kCtrlLightPublish = 1, kCtrlSpecPartials = 2, kCtrlPrefetchTimes = 4, kCtrlChecksum = 8;
 
-__device__ inline void publish_block(xde_ctrl_t* c, const xde_ctrl_t& zs, xde_ctrl_t* mirror, int flags = 0) {
-  constexpr int kWords = sizeof(xde_ctrl_t) / 8;
-  constexpr int kSeqWord = offsetof(xde_ctrl_t, seq) / 8;
+// splitmix64's finaliser: every input bit reaches every output bit
+__host__ __device__ inline uint64_t ctrl_mix64(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+constexpr int kCtrlWords = sizeof(xde_ctrl_t) / 8;
+constexpr int kCtrlSeqWord = offsetof(xde_ctrl_t, seq) / 8;
+constexpr int kCtrlChkWord = offsetof(xde_ctrl_t, chk) / 8;
+// word i's contribution to the checksum (position-salted; the checksum word itself does not take part): a SUM of contributions, so
+// that one wave can form it with a butterfly and the host with a loop, in any order
+__host__ __device__ inline uint64_t ctrl_chk_term(uint64_t word, int i) {
+  return i == kCtrlChkWord ? 0ull : ctrl_mix64(word + 0x9E3779B97F4A7C15ull * uint64_t(i + 1));
+}
+
+// Write a finished control block back: one wave instruction to the device block, one to the mirror slot.  Called by all threads of
+// the block after `zs` is complete and visible in LDS.  `pub_wave`: the wave that publishes (SEQLOCK: it must be the wave that issued
+// the invalidation in control_prologue — the light ordering is program order + `s_waitcnt` WITHIN one wave).
+__device__ inline void publish_block(xde_ctrl_t* c, const xde_ctrl_t& zs, xde_ctrl_t* mirror, int flags = 0, int pub_wave = 0) {
+  constexpr int kWords = kCtrlWords;
+  constexpr int kSeqWord = kCtrlSeqWord;
   static_assert(kWords <= 64, "the control block is published by ONE wave");
   xde_ctrl_t* ms = mirror ? mirror + (zs.seq % XDE_MIRROR_SLOTS) : nullptr;
+  const int lane = int(threadIdx.x) - 64 * pub_wave;
+  if (lane < 0 || lane >= 64) return;
+  if (flags & kCtrlChecksum) {
+    uint64_t word = lane < kWords ? reinterpret_cast<const uint64_t*>(&zs)[lane] : 0ull;
+    uint64_t sum = lane < kWords ? ctrl_chk_term(word, lane) : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, off, 64);
+    if (lane == kCtrlChkWord) word = sum;
+    if (lane < kWords) {
+      reinterpret_cast<uint64_t*>(c)[lane] = word;
+      if (mirror) __hip_atomic_store(reinterpret_cast<uint64_t*>(ms) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   const bool light = (flags & kCtrlLightPublish) != 0;
-  if (threadIdx.x < 64) {
-    if (mirror) {  // the invalidation (issued by this wave long ago) is ordered before the payload stores
-      if (light) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else __threadfence_system();
-    }
-    if (threadIdx.x < kWords) {
-      const uint64_t word = reinterpret_cast<const uint64_t*>(&zs)[threadIdx.x];
-      reinterpret_cast<uint64_t*>(c)[threadIdx.x] = word;
-      if (mirror && threadIdx.x != kSeqWord)
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(ms) + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (mirror) {  // the wave that wrote the words waits for them to be acknowledged, then publishes seq
-      if (light) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      } else {
-        __threadfence_system();
-        if (threadIdx.x == 0) __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+  if (mirror) {  // the invalidation (issued by this wave long ago) is ordered before the payload stores
+    if (light) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else __threadfence_system();
+  }
+  if (lane < kWords) {
+    const uint64_t word = reinterpret_cast<const uint64_t*>(&zs)[lane];
+    reinterpret_cast<uint64_t*>(c)[lane] = word;
+    if (mirror && lane != kSeqWord)
+      __hip_atomic_store(reinterpret_cast<uint64_t*>(ms) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (mirror) {  // the wave that wrote the words waits for them to be acknowledged, then publishes seq
+    if (light) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(&ms->seq, zs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -217,8 +256,9 @@ __device__ inline void publish_block(xde_ctrl_t* c, const xde_ctrl_t& zs, xde_ct
 //   control_tail      lane 0 runs the controller on the LDS block in place, one wave publishes it.
 __device__ __forceinline__ void control_prologue(const xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* t_span,
                                                  const double* step_t, xde_ctrl_t* mirror, int flags, xde_ctrl_t* zs,
-                                                 TimePrefetch* pfs) {
+                                                 TimePrefetch* pfs, int pub_wave = 0) {
   constexpr int kWords = sizeof(xde_ctrl_t) / 8;
+  constexpr int kSeqWord = offsetof(xde_ctrl_t, seq) / 8;
   const bool prefetch = (flags & kCtrlPrefetchTimes) != 0;
   if (prefetch && threadIdx.x == 64) {  // a lane of wave 1: two dependent loads, off lane 0's critical path
     const int i = c->next_out;
@@ -238,14 +278,18 @@ __device__ __forceinline__ void control_prologue(const xde_ctrl_t* c, const xde_
   if (threadIdx.x < kWords) {
     const uint64_t word = reinterpret_cast<const uint64_t*>(c)[threadIdx.x];
     reinterpret_cast<uint64_t*>(zs)[threadIdx.x] = word;
-    if (mirror && threadIdx.x == offsetof(xde_ctrl_t, seq) / 8) invalidate_slot(mirror, int64_t(word) + 1);
+    if (mirror && !(flags & kCtrlChecksum) && pub_wave == 0 && threadIdx.x == kSeqWord) invalidate_slot(mirror, int64_t(word) + 1);
   }
+  // (a publishing wave other than wave 0 fetches the sequence number for itself: the invalidation must come from the wave that
+  //  publishes, see publish_block)
+  if (mirror && !(flags & kCtrlChecksum) && pub_wave != 0 && int(threadIdx.x) == 64 * pub_wave)
+    invalidate_slot(mirror, reinterpret_cast<const int64_t*>(c)[kSeqWord] + 1);
 }
 
 // Call after a __syncthreads that made zs / pfs / seg_val / seg_nf visible.
 __device__ __forceinline__ void control_tail(xde_ctrl_t* c, const xde_ctrl_params_t& p, const double* seg_val, const double* seg_nf,
                                              const double* t_span, const double* step_t, void* t_stage_out, xde_ctrl_t* mirror,
-                                             int flags, xde_ctrl_t* zs, const TimePrefetch* pfs) {
+                                             int flags, xde_ctrl_t* zs, const TimePrefetch* pfs, int pub_wave = 0) {
   if (threadIdx.x == 0) {
     // The controller works on the LDS copy in place.  (A private copy of the 288-byte block — it has arrays indexed at run
     // time — lives in SCRATCH memory: every field access is a memory round trip and, worse, a dispatch that needs scratch
@@ -269,7 +313,7 @@ __device__ __forceinline__ void control_tail(xde_ctrl_t* c, const xde_ctrl_param
     }
   }
   __syncthreads();
-  publish_block(c, *zs, mirror, flags);
+  publish_block(c, *zs, mirror, flags, pub_wave);
 }
 
 // FUSED = called by the last workgroup of the ticketed error-norm launch (partials were published write-through inside it).
@@ -304,6 +348,15 @@ __device__ void control_block(xde_ctrl_t* c, const xde_ctrl_params_t& p, const N
   control_tail(c, p, seg_val, seg_nf, t_span, step_t, t_stage_out, mirror, flags, &zs, &pfs);
 }
 
+
+// XDE_CTRL_FLAGS: see publish_block (host side: one value per process — kernels and xde_ctrl_wait must agree on the publish protocol)
+inline int ctrl_flags() {
+  static int v = [] {
+    const char* e = getenv("XDE_CTRL_FLAGS");
+    return (e && *e) ? atoi(e) : 15;
+  }();
+  return v;
+}
 
 inline int check_params(const xde_ctrl_params_t* p, const char* who) {
   if (!p) return fail(XDE_EBADARG, std::string(who) + ": null params");

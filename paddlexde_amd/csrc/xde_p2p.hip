@@ -145,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void xde_p2p_control_kernel(xde_ctrl_t* c, 
   __shared__ double vec[kVec];  // [value(seg 0..15), nonfinite(seg 0..15)] — the layout of xde_norm_finalize's output
   __shared__ xde_ctrl_t zs;
   __shared__ TimePrefetch pfs;
-  control_prologue(c, p, t_span, step_t, mirror, flags, &zs, &pfs);
+  constexpr int kPubWave = 1;  // wave 0 runs the exchange: the mirror's invalidation and publish belong to another wave (publish_block)
+  control_prologue(c, p, t_span, step_t, mirror, flags, &zs, &pfs, kPubWave);
   if (threadIdx.x < kVec) vec[threadIdx.x] = 0.0;
   __syncthreads();
   if (flags & kCtrlSpecPartials)
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void xde_p2p_control_kernel(xde_ctrl_t* c, 
     reduce_partials<false>(slot, vec, vec + XDE_MAX_SEG);
   if (threadIdx.x < 64) p2p_exchange_wave(vec, local, peers, world, rank, p.norm_kind, spin_limit);
   __syncthreads();
-  control_tail(c, p, vec, vec + XDE_MAX_SEG, t_span, step_t, t_stage_out, mirror, flags, &zs, &pfs);
+  control_tail(c, p, vec, vec + XDE_MAX_SEG, t_span, step_t, t_stage_out, mirror, flags, &zs, &pfs, kPubWave);
 }
 
 }  // namespace
@@ -249,10 +250,7 @@ int xde_p2p_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const 
     peers.p[q] = static_cast<P2PMailbox*>(peer_mailboxes[q]);
   }
   if (peer_mailboxes[rank] != local_mailbox) return fail(XDE_EBADARG, "xde_p2p_rk_control: peer_mailboxes[rank] must be the local mailbox");
-  static const int flags = [] {
-    const char* e = getenv("XDE_CTRL_FLAGS");
-    return (e && *e) ? atoi(e) : 7;
-  }();
+  const int flags = ctrl_flags();
   int cap = norm_grid_cap() + XDE_MAX_SEG;
   if (cap > XDE_MAX_PARTIALS) cap = XDE_MAX_PARTIALS;
   hipStream_t st = static_cast<hipStream_t>(stream);

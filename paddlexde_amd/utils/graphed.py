@@ -71,8 +71,15 @@ class CapturedGraph:
         self.memsets_replaced = 0
 
     def capture(self, **kwargs):
-        """Context manager: ``with cg.capture(): ...`` records into the graph; call ``finish()`` afterwards."""
-        return torch.cuda.graph(self.graph, **kwargs)
+        """Context manager: ``with cg.capture(): ...`` records into the graph; call ``finish()`` afterwards.
+
+        Python's cyclic garbage collector is held off for the duration of the recording.  ``torch.cuda.graph`` collects once on entry,
+        but an automatic collection can still start at any allocation INSIDE the recorded body; if it reaps an object that owns
+        device resources — a dropped module's cached captures (``odeint_adjoint``'s per-module cache is keyed weakly: the entry dies
+        with the module), their graphs' private memory pools — those are released in the middle of an active stream capture, and the
+        process aborts (round 5: ``Fatal Python error: Aborted`` under ``weakref.remove`` inside a captured ``func``, one GPU run in
+        five).  Collection resumes, if it was on, when the recording ends."""
+        return _capture_without_gc(torch.cuda.graph(self.graph, **kwargs))
 
     def finish(self):
         if self._kept:
@@ -98,6 +105,32 @@ class CapturedGraph:
         self.graph.replay()
         if self.safe_mode:
             torch.cuda.current_stream().synchronize()
+
+
+class _capture_without_gc:
+    """``with torch.cuda.graph(...)`` with the cyclic garbage collector switched off between entry and exit (see
+    CapturedGraph.capture).  Entry first (it runs its own ``gc.collect()`` while that is still harmless), then ``gc.disable()``."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.was_enabled = False
+
+    def __enter__(self):
+        import gc
+
+        out = self.ctx.__enter__()
+        self.was_enabled = gc.isenabled()
+        gc.disable()
+        return out
+
+    def __exit__(self, *exc):
+        import gc
+
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was_enabled:
+                gc.enable()
 
 
 def _map(x, fn):

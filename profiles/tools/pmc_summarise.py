@@ -13,6 +13,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
@@ -20,12 +21,17 @@ def classify(name):
     if "xde_combine_pre_kernel" in name:
         return "combine_pre(partial sum in)"
     if "xde_combine_kernel" in name:
-        if "Lb1ELb1E" in name or "true, true" in name:
-            return "combine_last_stage(+partial error)"  # (since round 4 also the stage that emits the next stage's partial sum: both write two arrays)
-        if "Li1E" in name or ", 1," in name:
-            return "combine_fuse"
-        if "Li2E" in name or ", 2," in name:
-            return "combine_wfuse"
+        # xde_combine_kernel<T, MODE, VEC, OUT2, ...> (round 5 added the cache policy and the operand-count split behind OUT2)
+        m = re.search(r"xde_combine_kernel<([^>]*)>", name)
+        args = [a.strip() for a in m.group(1).split(",")] if m else []
+        if len(args) >= 4:
+            mode, out2 = args[1], args[3] == "true"
+            if mode == "1":
+                return "combine_fuse(+partial final sum)" if out2 else "combine_fuse"
+            if mode == "2":
+                return "combine_wfuse"
+            # (since round 4 "last stage" is also the stage that emits the next stage's partial sum: both write two arrays)
+            return "combine_last_stage(+partial error)" if out2 else "combine"
         return "combine"
     for key, tag in (("xde_errnorm_control", "errnorm+control"), ("xde_errnorm", "errnorm"), ("xde_control", "control"),
                      ("xde_dense", "dense"), ("xde_commit", "commit"), ("xde_finalize", "finalize"), ("xde_p2p", "p2p_exchange")):

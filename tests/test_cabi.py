@@ -299,3 +299,60 @@ def test_host_halves_run_up_to_the_launch_without_a_gpu():
     assert lib.xde_prof_enable(1) in (_hip.XDE_OK, _hip.XDE_EHIP)
     lib.xde_stage_combine(dev(1), dev(2), None, ks, None, coef, 2, 0, 1.0, 0.1, None, n, 0, None, None, 0.0, 0, None)
     assert lib.xde_prof_enable(0) in (_hip.XDE_OK, _hip.XDE_EHIP)
+
+
+def _ctrl_checksum(block):
+    """Python statement of the control block's checksum (csrc/xde_control_device.hpp: ctrl_chk_term / ctrl_mix64): the sum over every
+    8-byte word but `chk` of splitmix64's finaliser of (word + golden * (index + 1)), mod 2^64."""
+    M = (1 << 64) - 1
+
+    def mix(x):
+        x ^= x >> 30
+        x = (x * 0xBF58476D1CE4E5B9) & M
+        x ^= x >> 27
+        x = (x * 0x94D049BB133111EB) & M
+        x ^= x >> 31
+        return x
+
+    words = (C.c_uint64 * (C.sizeof(_hip.XdeCtrl) // 8)).from_buffer_copy(bytes(block))
+    chk_word = _hip.XdeCtrl.chk.offset // 8
+    return sum(mix((w + 0x9E3779B97F4A7C15 * (i + 1)) & M) for i, w in enumerate(words) if i != chk_word) & M
+
+
+def test_host_mirror_accepts_only_whole_blocks(monkeypatch):
+    """Round 5: the controller publishes its block to the pinned host mirror with ONE unordered store instruction; `xde_ctrl_wait`
+    accepts a copy of the slot only if its sequence number is the expected one AND its checksum holds.  Checked here on a mirror ring
+    in ordinary host memory (no GPU): a whole block is returned; a slot in which one payload word is still the previous occupant's (a
+    copy taken while the words were landing) is NOT accepted — the wait runs into its timeout instead of handing back a torn block;
+    a slot already taken by a later launch is reported as such."""
+    if "XDE_CTRL_FLAGS" in os.environ and not int(os.environ["XDE_CTRL_FLAGS"]) & 8:
+        pytest.skip("the seqlock protocol is selected")
+    lib = _hip.load_library()
+    ring = (_hip.XdeCtrl * _hip.XDE_MIRROR_SLOTS)()
+    seq = 21
+    new, old = _hip.XdeCtrl(), _hip.XdeCtrl()
+    for blk, s in ((old, seq - _hip.XDE_MIRROR_SLOTS), (new, seq)):
+        blk.t0, blk.t1, blk.dt, blk.ratio = 0.1 * s, 0.1 * s + 0.05, 0.05 + 1e-3 * s, 0.5
+        blk.n_steps, blk.n_accept, blk.accept, blk.seq = s, s - 2, 1, s
+        blk.chk = _ctrl_checksum(blk)
+    out = _hip.XdeCtrl()
+    slot = seq % _hip.XDE_MIRROR_SLOTS
+    ring[slot] = new
+    assert lib.xde_ctrl_wait(ring, seq, 50.0, C.byref(out)) == _hip.XDE_OK
+    assert (out.seq, out.dt, out.n_steps, out.chk) == (seq, new.dt, seq, new.chk)
+    # torn: every word of the new block has landed except `dt`, which is still the block's that held this slot 16 launches ago
+    torn = _hip.XdeCtrl.from_buffer_copy(bytes(new))
+    torn.dt = old.dt
+    ring[slot] = torn
+    assert lib.xde_ctrl_wait(ring, seq, 30.0, C.byref(out)) == _hip.XDE_ETIMEOUT
+    # ... and so is a slot whose sequence number has landed while the rest is still the old block
+    torn = _hip.XdeCtrl.from_buffer_copy(bytes(old))
+    torn.seq = seq
+    ring[slot] = torn
+    assert lib.xde_ctrl_wait(ring, seq, 30.0, C.byref(out)) == _hip.XDE_ETIMEOUT
+    # the slot belongs to a later launch already: the host lagged a whole ring behind
+    later = _hip.XdeCtrl.from_buffer_copy(bytes(new))
+    later.seq = seq + _hip.XDE_MIRROR_SLOTS
+    later.chk = _ctrl_checksum(later)
+    ring[slot] = later
+    assert lib.xde_ctrl_wait(ring, seq, 30.0, C.byref(out)) == _hip.XDE_EBADARG and b"overwritten" in lib.xde_last_error()

@@ -79,10 +79,10 @@ def test_dopri5_through_raw_c_abi():
 
     p = Params()
     # the binding states the layout it was written against; a stale mirror gets XDE_EBADARG from every entry point (first, prove it)
-    p.struct_size, p.abi_version = C.sizeof(Params) - 16, 5
+    p.struct_size, p.abi_version = C.sizeof(Params) - 16, 6
     assert lib.xde_ctrl_init(0x1000, C.byref(p), 0.0, 0.01, 3, 0x1000, None, 0x1000, 0, None, stream) == 1
     assert "layout mismatch" in lib.xde_last_error().decode()
-    p.struct_size, p.abi_version = C.sizeof(Params), 5
+    p.struct_size, p.abi_version = C.sizeof(Params), 6
     p.rtol, p.atol, p.min_step, p.max_step = float(np.float32(1e-5)), float(np.float32(1e-7)), 0.0, float("inf")
     p.safety, p.ifactor, p.dfactor, p.order = float(np.float32(0.9)), 10.0, float(np.float32(0.2)), 5.0
     p.max_num_steps = 2**31 - 1
