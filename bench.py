@@ -504,7 +504,7 @@ def dde_workload(args):
     fw = (time.perf_counter() - t0) / args.steps
     b3 = 2.0 * S * L * D * 4.0
     a3 = b3 * r3["launches"] / (r3["ms"] * 1e-3) / 1e9 if r3["ms"] > 0 else 0.0
-    extra["lag_grad"] = {"kernel": "xde_lag_grad_kernel<float, vec>", "avg_launch_us": 1e3 * r3["ms"] / max(r3["launches"], 1), "bytes_per_launch": b3,
+    extra["lag_grad"] = {"kernel": "xde_lag_grad_plane_kernel<float, vec>", "avg_launch_us": 1e3 * r3["ms"] / max(r3["launches"], 1), "bytes_per_launch": b3,
                          "achieved": a3, "frac": a3 / HBM_PEAK_GBS, "framework_multiply_plus_sum_us": 1e6 * fw}
     out["history_index"] = extra
     emit(out)
