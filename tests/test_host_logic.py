@@ -62,3 +62,42 @@ def test_bench_stage_watchdog_ends_a_rank_that_outlives_its_stage(tmp_path):
     assert r.returncode == 75 and "over its limit" in r.stderr
     r = subprocess.run([sys.executable, "-c", code.format(root=root, hook=", on_expire=lambda stage: 0")], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 70 and "over its limit" in r.stderr
+
+
+def test_garbage_collector_is_held_off_while_a_capture_records():
+    """Round 5: an automatic cyclic collection that starts INSIDE a stream capture can reap a dropped module's cached captures (the
+    per-module cache is keyed weakly) and release their graphs / memory pools in the middle of the recording — the process aborted
+    under `weakref.remove` inside a captured func (gpurun_out/r05f/suite.log).  Every recording now runs with the collector off and
+    restores it afterwards — also when the body raises, and without switching it ON for a caller who had it off."""
+    import gc
+
+    from paddlexde_amd.utils.graphed import _capture_without_gc
+
+    class Ctx:
+        def __init__(self):
+            self.events = []
+
+        def __enter__(self):
+            self.events.append(("enter", gc.isenabled()))  # (torch.cuda.graph collects on entry: the collector is still on then)
+            return "graph"
+
+        def __exit__(self, *exc):
+            self.events.append(("exit", gc.isenabled()))
+            return False
+
+    assert gc.isenabled()
+    c = Ctx()
+    with _capture_without_gc(c) as g:
+        assert g == "graph" and not gc.isenabled()
+    assert gc.isenabled() and c.events == [("enter", True), ("exit", False)]
+    with pytest.raises(RuntimeError):
+        with _capture_without_gc(Ctx()):
+            raise RuntimeError("func cannot be captured")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with _capture_without_gc(Ctx()):
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
