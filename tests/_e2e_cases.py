@@ -622,6 +622,36 @@ def test_adjoint_vjp_hook_on_foreign_tensors_reproduces_config3_gradients(dev, s
         assert torch.equal(a, b), (i, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("solver", ["dopri5", "rk4"])
+def test_adjoint_problem_time_gradients_equal_the_torch_route(dev, solver):
+    """`AdjointProblem.backward(..., t_requires_grad=True)`: dL/dt_span (functional/odeint_adjoint.py:130-141,161-162) through the
+    caller's hook — `f(t_i, y_i) . dL/dy_i` per output time and the integrated time adjoint for the first — equals the torch-autograd
+    route's `t.grad` bit for bit, and so do the parameter gradients of that run."""
+    from paddlexde_amd import AdjointProblem
+
+    dtype = torch.float64
+    S = {**FIXED, **ADAPTIVE}[solver]
+    m = ODEFunc(dtype).to(dev)
+    y0 = (torch.rand(64, 2, generator=torch.Generator().manual_seed(0), dtype=dtype) * 4 - 2).to(dev)
+    t = torch.linspace(0.0, 2.0, 5, dtype=dtype).to(dev)
+    tol = dict(rtol=1e-8, atol=1e-10)
+    opts = {"norm": _rms_norm} if solver == "rk4" else {"norm": _rms_norm, "dtype": dtype}
+    aopts = {"graph_func": False} if solver == "rk4" else {"graph_func": False, "dtype": dtype}
+    tg = t.clone().requires_grad_(True)
+    sol = odeint_adjoint(m, y0, tg, solver=S, options=opts, adjoint_options=dict(aopts), **tol)
+    sol.abs().mean().backward()
+    want_t, want_p = tg.grad.clone(), [p.grad.clone() for p in m.parameters()]
+    func, vjp, params = _mlp_foreign(m)
+    prob = AdjointProblem(func, vjp=vjp, adjoint_params=params, solver=S, options=opts, adjoint_options=dict(aopts), from_dlpack=P.Foreign.from_dlpack, **tol)
+    with torch.no_grad():
+        ans = prob.forward(P.Foreign(y0), P.Foreign(t))
+        grad_ans = P.Foreign(torch.sign(ans.raw) / ans.raw.numel())  # d mean|y| / dy: exactly what autograd forms
+        _, grad_t, grads = prob.backward(P.Foreign(t), ans, grad_ans, t_requires_grad=True)
+    assert isinstance(grad_t, P.Foreign) and torch.equal(grad_t.raw, want_t), float((grad_t.raw - want_t).abs().max())
+    assert all(torch.equal(g.raw, w) for g, w in zip(grads, want_p))
+    assert float(want_t.abs().max()) > 0
+
+
 def test_adjoint_vjp_hook_contract_is_checked(dev):
     """A hook that returns the wrong number of values, a wrong-shaped f, or is handed foreign tensors through the torch entry point is
     refused with a message that names the contract."""

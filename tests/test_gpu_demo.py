@@ -48,3 +48,16 @@ def test_sharded_demo_runs_with_two_ranks_on_one_gpu():
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("ranks")][0]
         assert "ranks {} ".format(n) in line and float(line.split()[-1]) < 1e-4, line
+
+
+@pytest.mark.parametrize("solver", ["rk4", "dopri5"])
+def test_foreign_framework_demo_trains_through_the_adjoint(solver):
+    """examples/foreign_adjoint_demo.py: the spiral MLP as a layer of ANOTHER framework (tensors that expose only DLPack, a hand-written
+    vjp, RMSprop on the caller's own storage) trained through `AdjointProblem` — no autograd of any framework anywhere; the loss falls as
+    it does for the torch demo ("for 'drops in under the existing Paddle models' the training path is the one that matters")."""
+    import foreign_adjoint_demo
+
+    steps = 120 if solver == "rk4" else 60
+    losses = foreign_adjoint_demo.train(max_steps=steps, solver=solver, log_every=0)
+    head, tail = sum(losses[:10]) / 10, sum(losses[-10:]) / 10
+    assert tail < 0.9 * head, (head, tail)
