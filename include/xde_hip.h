@@ -279,9 +279,9 @@ int xde_norm_result(const double* sums, const double* seg_count, int n_seg, int 
  *   t_stage_out: n_stage values of `state_dtype` on the device — times func() is called with in the
  *                next step;
  *   host_mirror: NULL, or a ring of XDE_MIRROR_SLOTS control blocks in pinned, device-mapped host memory
- *                (xde_host_alloc): the controller publishes the updated block to slot[seq % SLOTS] with a
- *                system-scope release, so the host learns accept/t/dt by polling (xde_ctrl_wait) — no copy
- *                command and no event packet on the stream.
+ *                (xde_host_alloc): the controller publishes the updated block to slot[seq % SLOTS] — all its
+ *                words, `seq` and `chk` included, with one unordered store instruction — so the host learns
+ *                accept/t/dt by polling (xde_ctrl_wait) — no copy command and no event packet on the stream.
  */
 int xde_rk_control(xde_ctrl_t* ctrl, const xde_ctrl_params_t* params, const void* ws,
                    const double* sums, const double* t_span_dev, const double* step_t_dev,
@@ -356,8 +356,12 @@ int xde_host_free(void* ptr);
 
 /*
  * Host side of the mirror: spin (no HIP call) until the controller launch number `seq` has published
- * its block, then copy it to host_out.  XDE_ETIMEOUT after timeout_ms; XDE_EBADARG if the slot was
- * already overwritten by launch seq + XDE_MIRROR_SLOTS.
+ * its block, then copy it to host_out.  The block's words reach the slot in no particular order (ABI 6): a copy
+ * is accepted only if its `seq` is the expected one AND its checksum holds — `chk` = the sum, mod 2^64, over
+ * every other 8-byte word w_i of the block of splitmix64's finaliser of (w_i + 0x9E3779B97F4A7C15 * (i + 1)) —
+ * so a copy taken while words were still landing is never handed back (it is taken again).  XDE_ETIMEOUT after
+ * timeout_ms; XDE_EBADARG if the slot was already overwritten by launch seq + XDE_MIRROR_SLOTS.
+ * (XDE_CTRL_FLAGS without bit 8 selects rounds 2-4's protocol: seq invalidated, payload, seq — three ordered writes.)
  */
 int xde_ctrl_wait(const xde_ctrl_t* host_mirror, int64_t seq, double timeout_ms, xde_ctrl_t* host_out);
 
