@@ -941,6 +941,8 @@ def main():
             out["cpu_baseline_fused"] = fused
     if rank == 0 and world == 1 and not sharded and not args.no_odeint and (B, D) == (65536, 128) and args.solver == "dopri5":
         wd.stage("whole odeint() calls", 300, on_expire=emit_main_line)
+        if os.environ.get("XDE_BENCH_TEST_HANG") == "extra":  # test hook: an EXTRA measurement that never returns
+            time.sleep(10 ** 6)
         try:
             out.update(odeint_calls(func, y0, args))
         except Exception as e:  # never lose the headline to the extra measurement

@@ -147,3 +147,18 @@ def test_bench_survives_a_peer_to_peer_probe_that_crashes():
     assert rep["p2p_probe"]["ok"] is False and "rank 1's probe exited with" in rep["p2p_probe"]["why"]
     assert rep["tried"] == [{"transport": "allreduce", "adopted": True}] and "all-reduce" in j["norm_exchange"]
     assert j["n_gpus"] == 2 and j["value"] > 0 and "p2p" not in j["exchange_ab"]
+
+
+def test_bench_extra_measurement_that_hangs_keeps_the_headline_and_exits_nonzero():
+    """a watchdog expiry during an EXTRA stage (here the whole-`odeint()` calls, made to hang by a test hook) used to
+    print the main line and exit 0 — a hang in the library's public path reported as success.  Now the line is still printed (the
+    headline is never lost to an extra), carries `watchdog_expired` = the stage that ran out, and the process exits 75."""
+    env = dict(os.environ, XDE_BENCH_TEST_HANG="extra", XDE_BENCH_STAGE_SCALE="0.05")  # (the extra stage gets 15 s, the timed region 30 s)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 75, (r.returncode, r.stderr[-1500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["watchdog_expired"] == "whole odeint() calls" and j["value"] > 0 and j["n_gpus"] == 1 and "odeint_ms_T2" not in j
+    assert "stage 'whole odeint() calls' has run for" in r.stderr
