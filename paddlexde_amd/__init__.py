@@ -6,5 +6,6 @@ Python over ctypes with torch-ROCm tensors as device buffers.  There is no CPU f
 __version__ = "0.1.0"
 
 from .functional import AdjointProblem, ddeint, ddeint_adjoint, odeint, odeint_adjoint  # noqa: F401
+from .interpolation import BezierSpline, CubicHermiteSpline, LinearInterpolation  # noqa: F401
 from .solver import *  # noqa: F401,F403
 from .xde import BaseDDE, BaseODE, BaseXDE  # noqa: F401

@@ -56,6 +56,30 @@ def test_history_gather_vs_oracle(dev, lead, uniform, dtype, D, method):
     assert P.rel_err(lg.grad.cpu().numpy(), g_ref) <= (5e-5 if dtype == np.float32 else 1e-11)
 
 
+@pytest.mark.parametrize("name", ["LinearInterpolation", "CubicHermiteSpline", "BezierSpline"])
+@pytest.mark.parametrize("kind", ["ramp", "sine"])
+def test_reference_interpolation_tests_as_written(dev, kind, name):
+    """tests/interpolation/test_interpolation.py:34-47,74-85, line for line on the product's spline classes (`paddlexde_amd.interpolation`,
+    the reference's `paddlexde.interpolation`): `interp = Cls(series, t); allclose(val_tgt, interp.evaluate(t_eval), rtol=...);
+    allclose(tgt_deri, interp.derivative(t_eval), rtol=...)` — and the objects agree with `HistoryIndex` bit for bit (same launch)."""
+    import paddlexde_amd.interpolation as I
+
+    series, t, t_eval, val_tgt, der_tgt = P.interpolation_fixture(kind)
+    method = {"LinearInterpolation": "linear", "CubicHermiteSpline": "cubic", "BezierSpline": "bez"}[name]
+    rtol_val, rtol_der = P.INTERPOLATION_TOLERANCES[kind][method]
+    interp = getattr(I, name)(torch.from_numpy(series).to(dev), torch.from_numpy(t).to(dev))
+    val, der = interp.evaluate(torch.from_numpy(t_eval).to(dev)), interp.derivative(torch.from_numpy(t_eval).to(dev))
+    assert val.shape == der.shape == (1, 1, 2)
+    assert P.paddle_allclose(val_tgt, val.cpu().numpy(), rtol=rtol_val)
+    assert P.paddle_allclose(der_tgt, der.cpu().numpy(), rtol=rtol_der)
+    y = HistoryIndex.apply(torch.from_numpy(t_eval).to(dev), torch.from_numpy(series).to(dev), torch.from_numpy(t).to(dev), method)
+    assert torch.equal(y, val)
+    assert torch.equal(interp.grid_points.cpu(), torch.from_numpy(t)) and interp.interval.shape == (2,)
+    # the default grid (t=None) is the unit grid: on the ramp series that is the fixture's own grid
+    if kind == "ramp":
+        assert torch.equal(getattr(I, name)(torch.from_numpy(series).to(dev)).evaluate(torch.from_numpy(t_eval).to(dev)), val)
+
+
 @pytest.mark.parametrize("method", ["linear", "cubic", "bez"])
 @pytest.mark.parametrize("kind", ["ramp", "sine"])
 def test_reference_interpolation_fixtures_on_the_history_kernels(dev, kind, method):

@@ -19,13 +19,14 @@ def test_exported_names_are_the_references():
         "paddlexde_amd.solver.fixed_solver": ["AdamsBashforthMoulton", "Euler", "Midpoint", "RK4"],
         "paddlexde_amd.solver.adaptive_solver": ["AdaptiveHeun", "Bosh3", "Dopri5", "Dopri8", "Fehlberg2"],
         "paddlexde_amd.xde": ["BaseDDE", "BaseODE", "BaseXDE"],
+        "paddlexde_amd.interpolation": ["BezierSpline", "CubicHermiteSpline", "LinearInterpolation"],  # interpolation/__init__.py:1
     }
     for mod, names in want.items():
         m = importlib.import_module(mod)
         for n in names:
             assert hasattr(m, n), (mod, n)
     top = importlib.import_module("paddlexde_amd")  # (`from .functional import *`, `from .solver import *`, `from .xde import *`: paddlexde/__init__.py:4-8)
-    for n in want["paddlexde_amd.functional"] + want["paddlexde_amd.solver"] + want["paddlexde_amd.xde"]:
+    for n in want["paddlexde_amd.functional"] + want["paddlexde_amd.solver"] + want["paddlexde_amd.xde"] + want["paddlexde_amd.interpolation"]:
         assert hasattr(top, n), n
     for n in ("sdeint", "sdeint_adjoint", "ScipyWrapperODESolver", "BaseSDE", "BaseCDE"):  # out of scope: absent, not stubbed
         assert not hasattr(top, n), n
