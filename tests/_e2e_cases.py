@@ -122,6 +122,28 @@ def test_adams_bashforth_moulton_vs_oracle(dev, implicit):
         assert np.array_equal(got.cpu().numpy(), ref), (implicit, max_order, float(np.abs(got.cpu().numpy() - ref).max()))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_step_interpolants_vs_oracle(dev, dtype):
+    """interpolation/functional/interp_fn.py:4-20 (`linear_interp`, `cubic_hermite_interp`) — off the hot path (the solvers only ever
+    evaluate them at t == t1, where both are y1), restated as framework ops in the reference's op order: bit-exact with the oracle's,
+    inside, at the ends of and beyond the step."""
+    from paddlexde_amd.interpolation.functional import cubic_hermite_interp, linear_interp
+
+    rng = np.random.RandomState(0)
+    y0, y1, d0, d1 = (rng.randn(5, 7).astype(dtype) for _ in range(4))
+    t0, t1 = dtype(0.25), dtype(1.5)
+    T = lambda x: torch.from_numpy(np.asarray(x)).to(dev)  # noqa: E731
+    for tq in (0.25, 1.5, 0.8, 1.4999, 2.0):
+        tq = dtype(tq)
+        want = O.linear_interp(t0, t1, y0, y1, tq)
+        got = linear_interp(T(t0), T(t1), T(y0), T(y1), T(tq))
+        assert np.array_equal(got.cpu().numpy(), want), tq
+        want = O.cubic_hermite_interp(t0, y0, d0, t1, y1, d1, tq)
+        got = cubic_hermite_interp(T(t0), T(y0), T(d0), T(t1), T(y1), T(d1), T(tq))
+        assert np.array_equal(got.cpu().numpy(), want), tq
+    assert np.array_equal(cubic_hermite_interp(T(t0), T(y0), T(d0), T(t1), T(y1), T(d1), T(t1)).cpu().numpy(), y1)  # what the solver relies on
+
+
 def test_fixed_layout_batched(dev):
     """y0 [B, L, D] -> [B, T*L, D] against the oracle."""
     rng = np.random.RandomState(0)
