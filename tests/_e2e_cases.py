@@ -388,6 +388,32 @@ def test_assertion_messages(dev):
             odeint(lambda t_, y: -y, torch.ones(4, 2), torch.tensor([0.0, 1.0]), solver=Dopri5)  # CPU tensors: no fallback
 
 
+def test_empty_batch_and_single_output_time(dev):
+    """Degenerate inputs.  Fixed solvers: as the reference (an empty batch gives an empty solution, one output time gives the
+    state back — oracle checked).  Adaptive solvers: the reference trips over itself there (the RMS norm of an empty state is NaN ->
+    "underflow in dt nan"; one output time -> IndexError on t_span[1], base_adaptive_solver.py) — here both are served: no launch
+    has a zero-sized grid (every C entry point returns XDE_OK for n == 0), the solution is the empty / one-row tensor."""
+    f = lambda t_, y: -y  # noqa: E731
+    t = torch.linspace(0.0, 1.0, 5, device=dev)
+    tn = t.cpu().numpy()
+    for name in ("euler", "rk4"):
+        got = odeint(f, torch.zeros(0, 3, device=dev), t, solver=FIXED[name])
+        want = O.odeint(f, np.zeros((0, 3), np.float32), tn, name)
+        assert tuple(got.shape) == want.shape == (0, 3)
+        got = odeint(f, torch.ones(2, 3, device=dev), t[:1], solver=FIXED[name])
+        want = O.odeint(f, np.ones((2, 3), np.float32), tn[:1], name)
+        assert np.array_equal(got.cpu().numpy(), want)
+    for pipeline in ("sync", "lag", "graph", "auto"):
+        opts = {"norm": _rms_norm, "pipeline": pipeline}
+        got = odeint(f, torch.zeros(0, 3, device=dev), t, solver=Dopri5, options=dict(opts))
+        assert tuple(got.shape) == (5, 0, 3) and got.dtype == torch.float32
+        y0 = torch.full((2, 3), 1.5, device=dev)
+        got = odeint(f, y0, t[:1], solver=Dopri5, options=dict(opts))
+        assert tuple(got.shape) == (1, 2, 3) and torch.equal(got[0], y0)
+    with pytest.raises(AssertionError, match="underflow in dt nan"):  # (what the reference does with the empty batch)
+        O.odeint(f, np.zeros((0, 3), np.float32), tn, "dopri5")
+
+
 # ----------------------------------------------------------------------------------------------
 # config 5: stiff Van der Pol, step-rejection stress
 # ----------------------------------------------------------------------------------------------
