@@ -650,6 +650,12 @@ def _sweep(plan, t_span, y_ans, grad_y, adjoint_params):
     """Integrate the augmented system from the last output time back to the first; returns ``(adj_y0, grad_t_span | None,
     [adj_theta ...])``."""
     n_times = len(t_span)
+    if y_ans.numel() == 0 and plan.options.get("process_group") is None:
+        # an empty batch (the forward pass served it: solver/base_adaptive_solver.py): nothing flows back — the reference's RMS norm of
+        # an empty segment is NaN and its solve ends in "underflow in dt nan"
+        zeros = [torch.zeros_like(p) for p in adjoint_params]
+        grad_t = torch.zeros(n_times, dtype=t_span.dtype, device=t_span.device) if plan.time_grad else None
+        return torch.zeros(plan.y0_shape, dtype=y_ans.dtype, device=y_ans.device), grad_t, zeros
     y_ans = _time_first(y_ans, plan.y0_shape, n_times, plan.forward_is_fixed)
     grad_y = _time_first(grad_y, plan.y0_shape, n_times, plan.forward_is_fixed)
     state = _AugmentedState(y_ans[-1], grad_y[-1], adjoint_params)

@@ -412,6 +412,15 @@ def test_empty_batch_and_single_output_time(dev):
         assert tuple(got.shape) == (1, 2, 3) and torch.equal(got[0], y0)
     with pytest.raises(AssertionError, match="underflow in dt nan"):  # (what the reference does with the empty batch)
         O.odeint(f, np.zeros((0, 3), np.float32), tn, "dopri5")
+    # ... and through the adjoint: nothing flows back from an empty batch or from the initial state alone
+    for solver, y_shape, tt in ((Dopri5, (0, 3), t), (Dopri5, (2, 3), t[:1]), (RK4, (0, 1, 3), t), (RK4, (2, 1, 3), t[:1])):
+        layer = nn.Linear(3, 3).to(dev)
+        y0 = torch.ones(y_shape, device=dev, requires_grad=True)
+        sol = odeint_adjoint(lambda t_, y: layer(y), y0, tt, solver=solver, adjoint_params=tuple(layer.parameters()), options={"norm": _rms_norm})
+        sol.sum().backward()
+        assert tuple(y0.grad.shape) == y_shape and all(float(p.grad.abs().sum()) == 0.0 for p in layer.parameters())
+        if 0 not in y_shape:
+            assert torch.equal(y0.grad, torch.ones_like(y0))  # d sum(y0) / d y0
 
 
 # ----------------------------------------------------------------------------------------------
