@@ -17,54 +17,38 @@ How it is organised here (not the reference's layout):
     2-point solves themselves: ONE re-armable solver serves every interval (and the next backward pass), the initial-step heuristic
     and the first attempted step of an interval are one graph replay (``_sweep_captured``; ``adjoint_options["interval_graph"]``);
   * a batch-sharded backward sums the row-summed adjoints over the process group where the step control looks at them.
+Files: this one holds the public entry points, the adjoint norms, the backward plan and the sweep; ``_adjoint_dynamics.py`` the augmented
+dynamics (torch autograd / the caller's vjp hook / the functional form a graph records); ``_adjoint_capture.py`` the captured dynamics,
+their per-module cache and the re-armable interval solvers.
 Deviations documented in SURVEY.md: D4 (tuple state flattened), D5 (reverse-time intervals run natively with a signed dt), D6 (the
 gradient w.r.t. ``y0`` is returned instead of ``None``)."""
-import os
-import threading
 import warnings
-import collections
-import weakref
 from typing import Any, NamedTuple, Optional
 
 import torch
 import torch.nn as nn
 
-from ..solver.base_fixed_solver import FixedSolver
 from ..utils.ode_utils import _rms_norm, native_norm_spec
-from .odeint import ScaledTuple, _odeint_packed, _pack, _segment_layout, odeint
+from .odeint import _odeint_packed, _pack, _segment_layout, odeint
 
-_N_LEADING = 3  # adj_t, y, adj_y come first in the augmented state; the parameter adjoints follow
-
-
-def _is_fixed(solver):
-    return isinstance(solver, type) and issubclass(solver, FixedSolver)
-
-
-def _time_first(x, y0_shape, n_times, fixed):
-    """View of a solution / its gradient with time on axis 0 (the fixed-step layout folds time into axis -2)."""
-    if not fixed:
-        return x
-    lead, rows, width = tuple(y0_shape[:-2]), y0_shape[-2], y0_shape[-1]
-    return x.reshape(lead + (n_times, rows, width)).movedim(len(lead), 0)
-
-
-def _group_sum(tensors, pg):
-    """Sum a list of small tensors over the batch-sharding process group with ONE all-reduce; returns new tensors."""
-    import torch.distributed as dist
-
-    group = None if pg is True else pg
-    tensors = [x.contiguous() for x in tensors]
-    flat = torch.cat([x.reshape(-1) for x in tensors]) if len(tensors) != 1 else tensors[0].reshape(-1).clone()
-    staged = flat.is_cuda and dist.get_backend(group) == "gloo"  # rehearsal transport: gloo reduces on the host
-    buf = flat.cpu() if staged else flat
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    if staged:
-        flat.copy_(buf)
-    outs, off = [], 0
-    for x in tensors:
-        outs.append(flat[off : off + x.numel()].view(x.shape))
-        off += x.numel()
-    return outs
+from ._adjoint_capture import (  # noqa: F401  (the cache and its markers are reached through this module by tests and tools)
+    _GRAPH_CACHE,
+    _IntervalSolver,
+    _NoGraph,
+    _NoIntervals,
+    _captured_dynamics,
+    _first_sweep_interval,
+    _interval_key,
+)
+from ._adjoint_dynamics import (  # noqa: F401
+    _N_LEADING,
+    _group_sum,
+    _is_fixed,
+    _make_augmented_dynamics,
+    _make_functional_dynamics,
+    _time_first,
+    _vjp_through_hook,
+)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -135,421 +119,6 @@ def _adjoint_parameters(func, given, norm_is_users):
             "excluded from the adjoint pass, and will not appear as a tensor in the adjoint norm."
         )
     return wanted
-
-
-# ----------------------------------------------------------------------------------------------------------------------
-# augmented dynamics                                                          (reference: odeint_adjoint.py:89-124)
-# ----------------------------------------------------------------------------------------------------------------------
-def _vjp_of(evaluate, t, y, wrt_params, cotangent, time_grad, retain):
-    """``f = evaluate(t, y)`` and ``cotangent^T df/d(t, y, params)``; missing gradients are zeros (:116-122)."""
-    with torch.enable_grad():
-        # fresh autograd leaves that ALIAS the inputs (the reference copies them, paddle.assign: two more launches per evaluation);
-        # nothing writes to either between here and the grad call below, and no graph outlives this function
-        t_const = t.detach()
-        t_var = t.detach().requires_grad_(True)
-        y_var = y.detach().requires_grad_(True)
-        # dL/dt is only resolved when asked for: func then sees a time it can be differentiated by
-        f = evaluate(t_var if time_grad else t_const, y_var)
-        grads = torch.autograd.grad(f, (t_var, y_var) + tuple(wrt_params), cotangent, allow_unused=True, retain_graph=retain)
-    filled = [_zeros_like(x) if g is None else g for x, g in zip((t_var, y_var) + tuple(wrt_params), grads)]
-    return f.detach(), filled[0], filled[1], filled[2:]
-
-
-def _vjp_through_hook(hook, t, y, wrt_params, cotangent):
-    """The same four results from the CALLER's vector-Jacobian product, ``adjoint_options["vjp"]``: ``hook(t, y, cotangent) -> (f,
-    vjp_t, vjp_y, *vjp_params)`` with ``vjp_* = cotangent^T df/d*`` (linear in the cotangent), one entry per adjoint parameter in
-    their order; ``None`` stands for a gradient that is identically zero (the time adjoint of an autonomous func).  This is where a
-    func of another framework is differentiated BY that framework (the reference's own arrangement: ``paddle.autograd.grad``,
-    :108-114) — or where a hand-written / fused vjp replaces ~30 autograd launches; nothing of torch's autograd runs."""
-    out = tuple(hook(t, y, cotangent))
-    if len(out) != _N_LEADING + len(wrt_params):
-        raise ValueError("adjoint_options['vjp'] must return (f, vjp_t, vjp_y, *vjp_params) with one entry per adjoint parameter: "
-                         "expected {} values, got {}".format(_N_LEADING + len(wrt_params), len(out)))
-    f, vjp_t, vjp_y, *vjp_params = out
-    if f is None or vjp_y is None:
-        raise ValueError("adjoint_options['vjp'] returned None for f or vjp_y")
-    if tuple(f.shape) != tuple(y.shape) or tuple(vjp_y.shape) != tuple(y.shape):
-        raise ValueError("adjoint_options['vjp']: f and vjp_y must have the state's shape {}, got {} and {}".format(
-            tuple(y.shape), tuple(f.shape), tuple(vjp_y.shape)))
-    for p, g in zip(wrt_params, vjp_params):
-        if g is not None and g.numel() != p.numel():
-            raise ValueError("adjoint_options['vjp']: a parameter vjp has {} elements, its parameter {}".format(g.numel(), p.numel()))
-    vjp_t = _zeros_like(t) if vjp_t is None else vjp_t.reshape(())
-    filled = [_zeros_like(p) if g is None else g.detach() for p, g in zip(wrt_params, vjp_params)]
-    return f.detach(), vjp_t.detach(), vjp_y.detach(), filled
-
-
-# (shape, dtype, device) -> a zero tensor that is only ever READ: the stand-in for a gradient autograd did not produce (the time
-# adjoint of an autonomous func, on every evaluation).  A bounded, least-recently-used cache (a handful of shapes per model; a
-# process that walks through many models or batch shapes does not keep every zero it ever needed).  A captured HIP graph bakes in
-# the raw ADDRESS of the zero it was recorded with: while a capture records, every zero handed out is also appended to that
-# capture's own keep-alive list (_ZERO_SINKS), so an entry evicted from this cache lives exactly as long as a graph that reads it.
-_ZEROS = collections.OrderedDict()
-_ZEROS_MAX = 32
-_ZERO_SINKS = []  # stack of keep-alive lists of the dynamics currently being evaluated for capture
-
-
-def _zeros_like(x):
-    key = (tuple(x.shape), x.dtype, x.device)
-    z = _ZEROS.get(key)
-    if z is None:
-        z = _ZEROS[key] = torch.zeros(key[0], dtype=x.dtype, device=x.device)
-        while len(_ZEROS) > _ZEROS_MAX:
-            _ZEROS.popitem(last=False)
-    else:
-        _ZEROS.move_to_end(key)
-    if _ZERO_SINKS and not any(z is k for k in _ZERO_SINKS[-1]):
-        _ZERO_SINKS[-1].append(z)
-    return z
-
-
-def _negated_vjp(vjp_t, f, vjp_y, vjp_params):
-    """The augmented dynamics' value ``(-vjp_t, f, -vjp_y, -vjp_theta...)`` where the vjp was taken with the cotangent ``+adj_y``:
-    the reference's ``-adj_y`` (:108-114) is a launch of its own, a vjp is linear in its cotangent (exactly: every operation of a
-    backward graph is sign-symmetric in IEEE arithmetic), and the pack that follows applies the sign for free."""
-    members = (vjp_t, f, vjp_y, *vjp_params)
-    return ScaledTuple.of(members, [-1.0, 1.0, -1.0] + [-1.0] * len(vjp_params))
-
-
-def _make_augmented_dynamics(func, adjoint_params, t_requires_grad, pg=None, reduce_params=False, vjp=None):
-    """``d/dt (adj_t, y, adj_y, adj_theta) = (vjp_t, f, vjp_y, vjp_theta)`` with the cotangent ``-adj_y`` (taken as ``+adj_y`` and
-    negated while the result is packed, see ``_negated_vjp``); only ``y`` and ``adj_y`` are read from the state.
-
-    Batch-sharded run (``pg``): ``f`` and ``vjp_y`` are per-row quantities of this rank's rows, ``vjp_t`` and ``vjp_theta`` are
-    sums over rows.  Where the step control looks at them — ``adj_t`` when time gradients are wanted, the parameter adjoints under
-    the default adjoint norm (``reduce_params``) — they are summed over the group here, so that every rank integrates the GLOBAL
-    ``adj_t`` / ``adj_theta`` and the all-reduced norm is exactly the unsharded one.
-
-    ``vjp``: the caller's vector-Jacobian product instead of torch autograd (``_vjp_through_hook``)."""
-
-    def augmented_dynamics(t, y_aug):
-        if vjp is not None:  # the caller's own vector-Jacobian product (adjoint_options["vjp"])
-            f, vjp_t, vjp_y, vjp_params = _vjp_through_hook(vjp, t, y_aug[1], adjoint_params, y_aug[2])
-        else:
-            f, vjp_t, vjp_y, vjp_params = _vjp_of(func, t, y_aug[1], adjoint_params, y_aug[2], t_requires_grad, retain=True)
-        if pg is not None:
-            shared = ([vjp_t] if t_requires_grad else []) + (list(vjp_params) if reduce_params else [])
-            if shared:
-                shared = _group_sum(shared, pg)
-                if t_requires_grad:
-                    vjp_t, shared = shared[0], shared[1:]
-                if reduce_params:
-                    vjp_params = shared
-        return _negated_vjp(vjp_t, f, vjp_y, vjp_params)
-
-    return augmented_dynamics
-
-
-def _make_functional_dynamics(func, adjoint_params, t_requires_grad):
-    """The augmented dynamics for HIP-graph capture: identical arithmetic, but the vjp is taken w.r.t. fresh detached aliases of
-    the parameters (substituted with torch.func.functional_call) instead of the parameter leaves themselves.  After a user's
-    loss.backward() the real leaves own AccumulateGrad nodes bound to the default stream, and differentiating w.r.t. them inside a
-    later stream capture makes the engine synchronise with the default stream — which crashes the capture.  Needs ``func`` to be an
-    nn.Module whose parameters are the adjoint parameters."""
-    names = {id(p): n for n, p in func.named_parameters()}
-    try:
-        order = [names[id(p)] for p in adjoint_params]
-    except KeyError:
-        raise NotImplementedError(
-            "adjoint_options['graph_func'] needs func to be an nn.Module and adjoint_params to be (a subset of) its parameters"
-        )
-    # the capture cache is keyed weakly by the module (_GRAPH_CACHE): what it stores must not keep the module alive
-    func_ref = weakref.ref(func)
-    del func
-
-    def augmented_dynamics(t, y_aug):
-        module = func_ref()
-        if module is None:
-            raise RuntimeError("the module this captured dynamics was built for no longer exists")
-        aliases = tuple(p.detach().requires_grad_(True) for p in adjoint_params)  # same storage, no copy
-        evaluate = lambda t_, y_: torch.func.functional_call(module, dict(zip(order, aliases)), (t_, y_))  # noqa: E731
-        f, vjp_t, vjp_y, vjp_params = _vjp_of(evaluate, t, y_aug[1], aliases, y_aug[2], t_requires_grad, retain=False)
-        return _negated_vjp(vjp_t, f, vjp_y, vjp_params)
-
-    return augmented_dynamics
-
-
-# ----------------------------------------------------------------------------------------------------------------------
-# captured dynamics (adjoint_options["graph_func"])
-# ----------------------------------------------------------------------------------------------------------------------
-_GRAPH_CACHE = weakref.WeakKeyDictionary()  # func module -> {signature: GraphedFunc}; captures are reused across calls
-
-MAX_GRAPHS_PER_MODULE = 8  # captured dynamics kept per module (each holds static buffers of the state's size)
-AUTO_GRAPH_FUNC_MAX_BYTES = 8 << 20  # "auto": states above this are bandwidth-bound, the launches are not the cost
-AUTO_GRAPH_FUNC_MIN_INTERVALS = 4  # "auto": output intervals needed to amortise a first capture
-
-
-class _NoGraph:
-    """Cache marker: capturing the dynamics of this module / signature failed once; it runs eagerly."""
-
-    refused = True
-
-
-def _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options):
-    """Whether adjoint_options["graph_func"] = "auto" captures the augmented dynamics for this call."""
-    if not (isinstance(func, nn.Module) and torch.is_tensor(y0) and y0.is_cuda):
-        return False
-    if threading.current_thread() is not threading.main_thread() or torch.cuda.is_current_stream_capturing():
-        return False
-    if adjoint_options.get("process_group") is not None:
-        return False
-    if y0.numel() * y0.element_size() > AUTO_GRAPH_FUNC_MAX_BYTES or len(adjoint_params) == 0:
-        return False
-    own = {id(p) for p in func.parameters()}
-    if any(id(p) not in own for p in adjoint_params):
-        return False
-    return len(t_span) - 1 >= AUTO_GRAPH_FUNC_MIN_INTERVALS or func in _GRAPH_CACHE
-
-
-def _graph_time_examples(adjoint_method, adjoint_options, t_span, y0):
-    """The time arguments (shape, dtype) the adjoint solver will hand to func, for pre-capturing its HIP graph."""
-    dev = y0.device
-    if _is_fixed(adjoint_method):
-        tt = t_span.dtype if t_span.dtype in (torch.float32, torch.float64) else torch.float32
-        return [torch.zeros(1, dtype=tt, device=dev)]
-    time_dtype = adjoint_options.get("dtype", torch.float32)
-    dtypes = {time_dtype, y0.dtype, torch.promote_types(time_dtype, y0.dtype)}
-    return [torch.zeros((), dtype=d, device=dev) for d in dtypes]
-
-
-# captured interval solves: the whole 2-point solve of one output interval (initial-step heuristic + first attempted step) as one
-# hipGraph on a solver that is kept across intervals and backward passes (solver/base_adaptive_solver_rk.py: intervals_prepare)
-_INTERVAL_OPTION_KEYS = ("norm", "dtype", "safety", "ifactor", "dfactor", "min_step", "max_step", "max_num_steps", "controller",
-                         "pi_beta", "pipeline", "process_group", "reuse_f0")
-_FIXED_INTERVAL_OPTION_KEYS = ("norm", "interp", "pipeline", "variant", "process_group")  # (a fixed grid: one STEP per interval)
-MAX_INTERVAL_SOLVERS = 4  # per captured dynamics (tolerances x solver x direction)
-
-
-class _NoIntervals:
-    """Cache entry: the interval solve could not be captured for this key (``reason`` says why); one ordinary solve per interval."""
-
-    def __init__(self, reason=""):
-        self.reason = reason
-
-
-class _IntervalSolver:
-    def __init__(self, solver):
-        self.solver = solver
-        self.lock = threading.Lock()  # one sweep at a time owns the static buffers (a second, concurrent one solves per interval)
-
-
-def _interval_key(solver, rtol, atol, options, direction, t_dtype=None):
-    """Cache key of the captured interval solve for these solver options, or None when they rule it out."""
-    if not isinstance(solver, type):
-        return None
-    if os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0":
-        return None
-    fixed = _is_fixed(solver)
-    items = []
-    for k, v in options.items():
-        if k not in (_FIXED_INTERVAL_OPTION_KEYS if fixed else _INTERVAL_OPTION_KEYS):
-            return None
-        if k == "norm":
-            if fixed:
-                continue  # (a fixed grid has no step control: the norm is never called)
-            v = native_norm_spec(v)
-            if v is None:
-                return None
-        elif k == "process_group":
-            if v is not None:
-                return None
-        elif k == "pipeline":
-            if v not in ("auto", "sync") and not (fixed and v == "graph"):  # (every attempt is resolved before the next: "sync")
-                return None
-            continue
-        elif k == "interp":
-            if v != "linear":
-                return None
-            continue
-        elif k == "reuse_f0":
-            if not v:
-                return None
-            continue
-        try:
-            hash(v)
-        except TypeError:
-            return None
-        items.append((k, v))
-    if fixed and t_dtype not in (torch.float32, torch.float64):
-        return None
-    if fixed:  # (one step per interval: its direction is in the data; its times are handed to func in the output times' dtype)
-        return (solver, "fixed", str(t_dtype), tuple(sorted(items, key=lambda kv: kv[0])))
-    return (solver, float(rtol), float(atol), int(direction), tuple(sorted(items, key=lambda kv: kv[0])))
-
-
-def _first_sweep_interval(t_host):
-    """The backward sweep's first interval that is not empty — ``(t[i], t[i-1])`` walking back from the end — or None when every
-    output time is the same.  Its direction is the sweep's: an output time repeated at the END (``t = [0, 1, 1]``) must not make a
-    backward sweep look like a forward one."""
-    times = t_host.tolist()
-    for i in range(len(times) - 1, 0, -1):
-        if times[i] != times[i - 1]:
-            return (times[i], times[i - 1])
-    return None
-
-
-def _prepare_intervals(graphed, flat_ex, segs, shapes, t_span, adjoint_solver, rtol, atol, adjoint_options):
-    """Build (once per key) the re-armable solver the backward sweep runs its intervals on.  Called where the dynamics is captured:
-    on the main thread, outside the autograd node."""
-    from ..solver._common import direction_of
-    from ..xde.base_ode import BaseODE
-
-    opts = {k: v for k, v in adjoint_options.items() if k not in ("_replay_intervals", "interval_graph")}
-    if adjoint_options.get("_replay_intervals") is not None or adjoint_options.get("interval_graph", True) is False:
-        return
-    if len(t_span) < 2 or _interval_key(adjoint_solver, rtol, atol, opts, 1, t_span.dtype) is None:
-        return
-    t_host = t_span.detach().to("cpu")
-    span = _first_sweep_interval(t_host)
-    if span is None:
-        return
-    key = _interval_key(adjoint_solver, rtol, atol, opts, direction_of(span), t_host.dtype)
-    cache = graphed.__dict__.setdefault("_intervals", {})
-    if key in cache:
-        return
-    try:
-        opts.pop("reuse_f0", None)
-        opts.pop("pipeline", None)
-        t_ex = torch.tensor(span, dtype=t_host.dtype)
-        if _is_fixed(adjoint_solver):
-            s = adjoint_solver(xde=BaseODE(graphed.func, y0=flat_ex, t_span=t_ex), y0=flat_ex, rtol=rtol, atol=atol, **opts)
-        else:
-            s = adjoint_solver(xde=BaseODE(graphed.func, y0=flat_ex, t_span=t_ex), y0=flat_ex, rtol=rtol, atol=atol, reuse_f0=True,
-                               _xde_segments=segs, _xde_segment_shapes=shapes, **opts)
-        if not (hasattr(s, "intervals_supported") and s.intervals_supported()):
-            cache[key] = _NoIntervals("the solver's options rule it out (intervals_supported)")
-            return
-        if _is_fixed(adjoint_solver):
-            s.intervals_prepare(span, t_host.dtype if t_host.dtype in (torch.float32, torch.float64) else torch.float32)
-        else:
-            s.intervals_prepare(span)
-        entry = _IntervalSolver(s)
-    except Exception as e:  # this solve cannot be captured: per-interval solves, and no second attempt for this key
-        entry = _NoIntervals("{}: {}".format(type(e).__name__, e))
-    while len(cache) >= MAX_INTERVAL_SOLVERS:
-        cache.pop(next(iter(cache)))
-    cache[key] = entry
-
-
-def _weak_hook(vjp):
-    """``vjp`` behind a weak reference, for a capture that is cached ON the hook's owner (what the cache stores must not keep its own
-    key alive); the backward plan holds the hook itself for as long as a backward pass can still run."""
-    inner = getattr(vjp, "__wrapped__", None)  # utils.interop.adapt_vjp(hook, importer): the user's hook is the thing to watch
-    importer = getattr(vjp, "_from_dlpack", None)
-    target = vjp if inner is None else inner
-    try:
-        ref = weakref.WeakMethod(target) if hasattr(target, "__self__") else weakref.ref(target)
-    except TypeError:
-        return vjp  # (not weakly referenceable: such an owner never enters the module-wide cache either)
-
-    def call(t, y, cotangent):
-        hook = ref()
-        if hook is None:
-            raise RuntimeError("the vjp hook this captured dynamics was built for no longer exists")
-        if inner is not None:
-            from ..utils.interop import adapt_vjp
-
-            hook = adapt_vjp(hook, importer)
-        return hook(t, y, cotangent)
-
-    return call
-
-
-def _graph_cache_owner(func, vjp):
-    """The object a module-wide capture cache hangs on (weakly): the module, or — with a vjp hook — the hook (its instance, for a bound
-    method: the method object itself is made anew on every attribute access)."""
-    if vjp is None:
-        return func
-    hook = getattr(vjp, "__wrapped__", vjp)
-    return getattr(hook, "__self__", hook)
-
-
-def _captured_dynamics(func, y0, t_span, adjoint_solver, adjoint_options, adjoint_params, rtol=None, atol=None, vjp=None):
-    """Resolve ``adjoint_options["graph_func"]`` and return the captured FLAT augmented dynamics, or None for the eager one.
-
-    The augmented dynamics (func forward + autograd vjp, ~30 eager launches) is captured into one HIP graph per time-argument
-    signature and replayed (config 3's backward: 105 -> 34 ms).  True (or a dict that caches captures across calls) forces it;
-    False switches it off; absent / "auto" (the default) uses it when it pays and is safe: a small state (launch-bound), an nn.Module
-    func whose parameters are the adjoint parameters, several output intervals to amortise the capture over (or a capture already
-    cached for this module), the main thread, no capture in progress, no per-evaluation all-reduce — and falls back to the eager
-    dynamics if the capture fails.  The capture has to happen in the caller of the autograd node — on the calling thread and outside
-    the node: capturing from the engine's worker thread (where backward runs), or inside its forward while the parameters are its
-    inputs, crashes the runtime.
-
-    With a vjp hook (``vjp``) the captured thing is the hook's own launches; "auto" then means OFF — whether another framework's
-    kernels land on the capturing stream, and survive a replay, is the caller's knowledge: ``graph_func=True`` states it."""
-    mode = adjoint_options.pop("graph_func", "auto")
-    forced = mode is True or isinstance(mode, dict)
-    if mode == "auto":
-        mode = vjp is None and _auto_graph_func(func, y0, t_span, adjoint_params, adjoint_options)
-    if not mode:
-        return None
-    from ..utils.graphed import GraphedFunc
-
-    if vjp is None and not isinstance(func, nn.Module):
-        raise NotImplementedError("adjoint_options['graph_func'] needs func to be an nn.Module (or a vjp hook)")
-    if isinstance(mode, dict):
-        cache = mode
-    else:
-        try:
-            cache = _GRAPH_CACHE.setdefault(_graph_cache_owner(func, vjp), {})
-        except TypeError:  # an owner that cannot be referenced weakly: captures live for this call only
-            cache = {}
-    time_grad = bool(t_span.requires_grad)
-    fixed = _is_fixed(adjoint_solver)
-    # (the captured kernels address the parameters' storage: a parameter whose storage was swapped — `p.data = ...` — needs a new
-    # capture, an in-place update such as an optimiser step does not)
-    key = ("aug-flat" if vjp is None else "aug-flat-hook", tuple(y0.shape), y0.dtype, str(y0.device), time_grad, fixed,
-           tuple((id(p), p.data_ptr()) for p in adjoint_params))
-    graphed = cache.get(key)
-    if isinstance(graphed, _NoGraph):
-        return None
-    # the augmented state in the flat, 16-byte-segment layout the backward will use
-    example = [torch.zeros([], dtype=y0.dtype, device=y0.device), y0.detach(), torch.zeros_like(y0)] + [torch.zeros_like(p) for p in adjoint_params]
-    adt, segs, total = _segment_layout(example)
-    if graphed is None:
-        if vjp is None:
-            dyn = _make_functional_dynamics(func, adjoint_params, time_grad)
-        else:
-            dyn = _make_augmented_dynamics(None, adjoint_params, time_grad, vjp=_weak_hook(vjp))
-        (s1, n1), (s2, n2) = segs[1], segs[2]
-        yshape, dev = tuple(y0.shape), y0.device
-
-        keep = []  # the shared zeros this dynamics reads (their addresses end up inside the captured graph): alive as long as it is
-
-        def flat_dynamics(t, yf):
-            # unpack views -> func + vjp -> pack, all inside ONE captured graph
-            v = yf[0] if fixed else yf
-            _ZERO_SINKS.append(keep)
-            try:
-                k = _pack(dyn(t, (None, v[s1 : s1 + n1].view(yshape), v[s2 : s2 + n2].view(yshape))), segs, total, adt, dev)
-            finally:
-                _ZERO_SINKS.pop()
-            return k[None, :] if fixed else k
-
-        graphed = GraphedFunc(flat_dynamics, clone_outputs=True)
-        graphed._keepalive = keep
-        while len(cache) >= MAX_GRAPHS_PER_MODULE:  # a loop over many batch shapes must not pile up captures (oldest first)
-            cache.pop(next(iter(cache)))
-        cache[key] = graphed
-    flat_ex = _pack(example, segs, total, adt, y0.device)
-    flat_ex = flat_ex[None, :] if fixed else flat_ex
-    try:
-        for t_ex in _graph_time_examples(adjoint_solver, adjoint_options, t_span, y0):
-            graphed.prepare(t_ex, flat_ex)
-    except Exception:
-        if forced:
-            raise
-        # "auto": this func cannot be captured (host synchronisation, unsupported op, ...): eager dynamics, and no second attempt
-        # for this module and signature
-        cache[key] = _NoGraph()
-        return None
-    if graphed.refused:
-        return None
-    if rtol is not None and not time_grad:
-        _prepare_intervals(graphed, flat_ex, segs, [tuple(x.shape) for x in example], t_span, adjoint_solver, rtol, atol,
-                           adjoint_options)
-    return graphed
 
 
 # ----------------------------------------------------------------------------------------------------------------------
