@@ -113,11 +113,11 @@ def test_bench_parent_stops_a_job_that_never_finishes():
     import time
 
     t0 = time.time()
-    r = _launch({"XDE_BENCH_REHEARSAL": "1", "XDE_BENCH_TIMEOUT": "40", "XDE_BENCH_TEST_HANG": "1"}, "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-n1", "--no-ab")
+    r = _launch({"XDE_BENCH_REHEARSAL": "1", "XDE_BENCH_TIMEOUT": "30", "XDE_BENCH_TEST_HANG": "1"}, "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-n1", "--no-ab")
     assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
     assert time.time() - t0 < 200
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert "still running after 40 s" in r.stderr and "rank 0: in stage" in r.stderr and "rank 1: in stage 'set-up + warm-up + timed region'" in r.stderr
+    assert "still running after 30 s" in r.stderr and "rank 0: in stage" in r.stderr and "rank 1: in stage 'set-up + warm-up + timed region'" in r.stderr
 
 
 def test_bench_n_rank_line_names_devices_transport_and_alternatives():
@@ -140,7 +140,9 @@ def test_bench_survives_a_peer_to_peer_probe_that_crashes():
     probe abort() (what a GPU fault inside the probe would look like to its parent): its peers' probes then run out of partners, every
     rank hears that the probe failed, the job moves on to the next transport together (rehearsal: the host-staged all-reduce) and the line
     says what happened."""
-    r = _launch({"XDE_BENCH_REHEARSAL": "1", "XDE_BENCH_TEST_PROBE_FAIL": "1"}, "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-n1")
+    # (XDE_BENCH_STAGE_SCALE: the surviving probe waits for its partner until its rendezvous stage — 45 s — runs out; half of that here)
+    r = _launch({"XDE_BENCH_REHEARSAL": "1", "XDE_BENCH_TEST_PROBE_FAIL": "1", "XDE_BENCH_STAGE_SCALE": "0.5"}, "--gpus", "2", "--steps", "5", "--warmup",
+                "2", "--no-n1")
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     rep = j["norm_exchange_report"]

@@ -382,8 +382,7 @@ def _p2p_worker(rank, world, port, out_dir, norm_name, pipeline):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm_name,pipeline,world", [("rms", "sync", 2), ("rms", "lag", 2), ("linf", "lag", 2), ("rms", "graph", 2),
-                                                      ("rms", "sync", 3), ("rms", "lag", 3), ("rms", "graph", 3),
-                                                      ("rms", "lag", 4), ("rms", "graph", 4)])
+                                                      ("rms", "graph", 3), ("rms", "lag", 4)])  # (three / four ranks: one pipeline each — a rank costs ~7 s of start-up)
 def test_peer_exchange_two_ranks_on_one_gpu(tmp_path, norm_name, pipeline, world):
     """The IPC-mapped mailboxes carry the per-attempt norm sums instead of an all-reduce: both ranks stay in lock-step and the
     run is BIT-identical to the all-reduce run (two summands: the rank-ordered sum is the all-reduce's sum; with four ranks
