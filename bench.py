@@ -319,7 +319,7 @@ def p2p_probe_child():
     return 0 if ok else 1
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed attempted steps (200 x 0.34 ms = 68 ms at the headline size)")
@@ -357,42 +357,12 @@ def main():
     ap.add_argument("--event-period", type=int, default=5,
                     help="time every p-th launch of each kernel inside the timed region (5 is coprime with the 6 "
                          "combines per step, so all stages are sampled evenly)")
-    args = ap.parse_args()
-    if args.gpus < 1:
-        raise SystemExit("--gpus must be >= 1")
-    if args.probe_p2p:
-        raise SystemExit(p2p_probe_child())
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` with no launcher: this process becomes the launcher.  Nothing here has touched the
-        # GPU (importing torch and counting devices do not initialise HIP), so starting children is safe.
-        raise SystemExit(self_launch(args))
-    # stdout carries ONE JSON line: whatever libraries print there meanwhile (RCCL's version banner, tuner notes) goes to
-    # stderr; the original stdout is restored just before the line is printed
-    sys.stdout.flush()
-    global _REAL_STDOUT
-    _REAL_STDOUT = os.dup(1)
-    os.dup2(2, 1)
-    args.tunable_op = not args.no_tunable_op  # (switched on below, after the transport probe: nothing may open the GPU before it)
+    return ap.parse_args()
 
-    c4_label = None
-    if args.workload in ("c4-shard", "c4-n1"):
-        # config 4's sizes on ONE GPU (VERDICT r02 #3): "c4-shard" = 65536 x 64, one rank's rows at N=8 (16 MiB operands, the whole
-        # working set Infinity-Cache resident); "c4-n1" = the GLOBAL 524288 x 64 on one rank, the N=1 point of the strong-scaling curve
-        args.batch, args.dim = (65536 if args.workload == "c4-shard" else 524288), 64
-        c4_label = ("BASELINE.json configs[3], one rank's shard at N=8 on one GPU" if args.workload == "c4-shard"
-                    else "BASELINE.json configs[3], the whole problem on one GPU (N=1 point of the strong-scaling curve)")
-        args.workload = "c2"
-    if args.workload != "c2":
-        args.tunable_op = enable_tunable_op(args.tunable_op)  # (single-process workloads: no probe to wait for)
-    if args.workload != "c2":  # the side workloads live in bench_side.py
-        import types
 
-        import bench_side
-
-        ctx = types.SimpleNamespace(emit=emit, make_problem=make_problem, HBM_PEAK_GBS=HBM_PEAK_GBS)
-        return {"rk4": bench_side.rk4_workload, "dense": bench_side.dense_workload, "dde": bench_side.dde_workload}.get(
-            args.workload, bench_side.side_workload)(args, ctx)
-
+def setup_ranks(args):
+    """This process's place in the job — rank, device, watchdog — and, for a sharded run, its groups: the gloo control group, the
+    peer-to-peer probe (in child processes, BEFORE this process opens its GPU), then the nccl (= RCCL) group.  Nothing is timed here."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -465,6 +435,47 @@ def main():
             print("bench.py[rank {}]: no usable nccl group ({}); continuing without one".format(rank, err or "failed on another rank"),
                   file=sys.stderr)
             nccl_pg = None
+    return (world, rank, local_rank, rehearsal, device, wd, dist, nccl_pg, rccl_ranks, p2p_probe, force_dist, sharded)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.probe_p2p:
+        raise SystemExit(p2p_probe_child())
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: this process becomes the launcher.  Nothing here has touched the
+        # GPU (importing torch and counting devices do not initialise HIP), so starting children is safe.
+        raise SystemExit(self_launch(args))
+    # stdout carries ONE JSON line: whatever libraries print there meanwhile (RCCL's version banner, tuner notes) goes to
+    # stderr; the original stdout is restored just before the line is printed
+    sys.stdout.flush()
+    global _REAL_STDOUT
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+    args.tunable_op = not args.no_tunable_op  # (switched on below, after the transport probe: nothing may open the GPU before it)
+
+    c4_label = None
+    if args.workload in ("c4-shard", "c4-n1"):
+        # config 4's sizes on ONE GPU (VERDICT r02 #3): "c4-shard" = 65536 x 64, one rank's rows at N=8 (16 MiB operands, the whole
+        # working set Infinity-Cache resident); "c4-n1" = the GLOBAL 524288 x 64 on one rank, the N=1 point of the strong-scaling curve
+        args.batch, args.dim = (65536 if args.workload == "c4-shard" else 524288), 64
+        c4_label = ("BASELINE.json configs[3], one rank's shard at N=8 on one GPU" if args.workload == "c4-shard"
+                    else "BASELINE.json configs[3], the whole problem on one GPU (N=1 point of the strong-scaling curve)")
+        args.workload = "c2"
+    if args.workload != "c2":
+        args.tunable_op = enable_tunable_op(args.tunable_op)  # (single-process workloads: no probe to wait for)
+    if args.workload != "c2":  # the side workloads live in bench_side.py
+        import types
+
+        import bench_side
+
+        ctx = types.SimpleNamespace(emit=emit, make_problem=make_problem, HBM_PEAK_GBS=HBM_PEAK_GBS)
+        return {"rk4": bench_side.rk4_workload, "dense": bench_side.dense_workload, "dde": bench_side.dde_workload}.get(
+            args.workload, bench_side.side_workload)(args, ctx)
+
+    world, rank, local_rank, rehearsal, device, wd, dist, nccl_pg, rccl_ranks, p2p_probe, force_dist, sharded = setup_ranks(args)
 
     import paddlexde_amd
     from paddlexde_amd import _hip
