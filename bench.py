@@ -52,7 +52,7 @@ import torch  # noqa: E402
 from bench_launch import Watchdog, _free_port, _stage_report, run_p2p_probe, self_launch  # noqa: E402,F401
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SETTLE_STEPS = 24  # untimed attempts of set-up before the W warm-up steps (timed_run)
+SETTLE_STEPS = int(os.environ.get("XDE_BENCH_SETTLE", "256"))  # untimed attempts of set-up before the W warm-up steps (timed_run)
 _REAL_STDOUT = None
 
 
@@ -355,9 +355,10 @@ def parse_args():
     ap.add_argument("--no-tunable-op", action="store_true",
                     help="leave PyTorch's TunableOp off (by default the framework tunes the GEMMs inside the user's func during "
                          "warm-up: same fp32 arithmetic, a better hipBLASLt/rocBLAS kernel for the shape)")
-    ap.add_argument("--event-period", type=int, default=5,
-                    help="time every p-th launch of each kernel inside the timed region (5 is coprime with the 6 "
-                         "combines per step, so all stages are sampled evenly)")
+    ap.add_argument("--event-period", type=int, default=11,
+                    help="time every p-th launch of each kernel inside the timed region (a dispatch-stamped launch costs the step ~5 us: "
+                         "every 5th one made the step 2.5 %% longer, every 11th ~1 %%; 11 is coprime with the 6 combines per step, so all "
+                         "stages are sampled evenly)")
     return ap.parse_args()
 
 
@@ -559,17 +560,19 @@ def main():
         if solver._auto_state == "graph" or pipeline == "graph":
             solver.advance(solver.GRAPH_ATTEMPTS + 1)  # both graphs a budgeted advance replays (4 attempts, 1 attempt) now exist
             settle += solver.GRAPH_ATTEMPTS + 1
-        # ... and whatever the pipeline, at least SETTLE_STEPS attempts of set-up (reported as `settle_steps`): the caching allocator's
-        # pool of state-sized blocks and the clocks reach their steady state here, so that a short `--warmup` (the driver's) does not
-        # leave the first hipMallocs of a solve inside the timed region (W = 5: first 20-step block 0.334 ms/step, the next two 0.324 /
-        # 0.321; W = 20: 0.3186 / 0.3180 / 0.3171)
+        # ... and whatever the pipeline, at least SETTLE_STEPS attempts of set-up (reported as `settle_steps`; 256 x 0.32 ms = 82 ms at the
+        # headline size): the chip needs tens of milliseconds of this load before a 20-step block (6 ms) reads what the next one reads —
+        # first block of three after 24 / 96 / 256 settle attempts + 5 warm-up steps: 0.3169 / 0.3135 / 0.3131 ms per step against
+        # 0.3108 / 0.3093 / 0.3122 for the blocks after it (profiles/r05_settle.txt).  The timed region stays EXACTLY K attempts.
         while settle < SETTLE_STEPS:
             solver.advance(4)
             settle += 4
+        if events:
+            be.prof_enable(args.event_period)  # (already during the warm-up steps: a stream's FIRST dispatch-stamped launches are not free)
         solver.advance(warmup)
         barrier()
         if events:
-            be.prof_enable(args.event_period)
+            be.prof_enable(args.event_period)  # counters and samples start from zero at the timed region
 
         def block():
             """EXACTLY `steps` attempted steps between barriers; this rank's clock stops after its stream has drained; MAX over ranks."""
