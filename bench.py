@@ -564,7 +564,7 @@ def main():
         # headline size): the chip needs tens of milliseconds of this load before a 20-step block (6 ms) reads what the next one reads —
         # first block of three after 24 / 96 / 256 settle attempts + 5 warm-up steps: 0.3169 / 0.3135 / 0.3131 ms per step against
         # 0.3108 / 0.3093 / 0.3122 for the blocks after it (profiles/r05_settle.txt).  The timed region stays EXACTLY K attempts.
-        while settle < SETTLE_STEPS:
+        while settle < (0 if rehearsal else SETTLE_STEPS):  # (a rehearsal — several ranks time-slicing ONE card — is not a measurement)
             solver.advance(4)
             settle += 4
         if events:
