@@ -129,10 +129,11 @@ def test_bench_n_rank_line_names_devices_transport_and_alternatives():
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert [d["rank"] for d in j["devices"]] == [0, 1] and all("device" in d and "name" in d for d in j["devices"])
     rep = j["norm_exchange_report"]
-    assert rep["asked"] == "auto" and rep["p2p_probe"]["ok"] is True and rep["tried"][0] == {"transport": "p2p", "adopted": True}
-    assert "xde_p2p_rk_control" in j["norm_exchange"]
+    said = (rep, r.stderr[-1500:])  # (a failure here must explain itself: what the negotiation reported, what the ranks wrote)
+    assert rep["asked"] == "auto" and rep["p2p_probe"]["ok"] is True and rep["tried"][0] == {"transport": "p2p", "adopted": True}, said
+    assert "xde_p2p_rk_control" in j["norm_exchange"], said
     ab = j["exchange_ab"]
-    assert ab["p2p"]["headline"] is True and ab["p2p"]["ms_per_step"] == j["ms_per_step"] and ab["allreduce"]["ms_per_step"] > 0
+    assert ab["p2p"]["headline"] is True and ab["p2p"]["ms_per_step"] == j["ms_per_step"] and ab["allreduce"]["ms_per_step"] > 0, (ab, said)
     assert "rccl_allreduce_ms_per_step" in j and j["rccl_allreduce_ms_per_step"] is None  # (gloo rehearsal: there is no RCCL group to time)
 
 
