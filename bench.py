@@ -52,7 +52,7 @@ import torch  # noqa: E402
 from bench_launch import Watchdog, _free_port, _stage_report, run_p2p_probe, self_launch  # noqa: E402,F401
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SETTLE_STEPS = int(os.environ.get("XDE_BENCH_SETTLE", "256"))  # untimed attempts of set-up before the W warm-up steps (timed_run)
+SETTLE_MS = float(os.environ.get("XDE_BENCH_SETTLE_MS", "100"))  # milliseconds of untimed attempts in set-up, before the W warm-up steps (timed_run)
 _REAL_STDOUT = None
 
 
@@ -560,13 +560,24 @@ def main():
         if solver._auto_state == "graph" or pipeline == "graph":
             solver.advance(solver.GRAPH_ATTEMPTS + 1)  # both graphs a budgeted advance replays (4 attempts, 1 attempt) now exist
             settle += solver.GRAPH_ATTEMPTS + 1
-        # ... and whatever the pipeline, at least SETTLE_STEPS attempts of set-up (reported as `settle_steps`; 256 x 0.32 ms = 82 ms at the
-        # headline size): the chip needs tens of milliseconds of this load before a 20-step block (6 ms) reads what the next one reads —
-        # first block of three after 24 / 96 / 256 settle attempts + 5 warm-up steps: 0.3169 / 0.3135 / 0.3131 ms per step against
-        # 0.3108 / 0.3093 / 0.3122 for the blocks after it (profiles/r05_settle.txt).  The timed region stays EXACTLY K attempts.
-        while settle < (0 if rehearsal else SETTLE_STEPS):  # (a rehearsal — several ranks time-slicing ONE card — is not a measurement)
-            solver.advance(4)
-            settle += 4
+        # ... and whatever the pipeline, SETTLE_MS (100 ms) of untimed attempts of set-up (their number is reported as `settle_steps`): the
+        # chip needs tens of milliseconds of this load before a 20-step block (6 ms) reads what the next one reads — first block of three
+        # after 24 / 96 / 256 settle attempts + 5 warm-up steps at the headline size: 0.3169 / 0.3135 / 0.3131 ms per step against
+        # 0.3108 / 0.3093 / 0.3122 for the blocks after it (profiles/r05_settle.txt); at the c4 shard 256 attempts (41 ms) still left the
+        # first block 2 % behind, hence a time, not a count.  The timed region stays EXACTLY K attempts.
+        if not rehearsal and SETTLE_MS > 0:  # (a rehearsal — several ranks time-slicing ONE card — is not a measurement)
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            solver.advance(32)
+            torch.cuda.synchronize()
+            per_step = (time.perf_counter() - t_s) / 32
+            more = min(4096, max(0, int(SETTLE_MS * 1e-3 / max(per_step, 1e-6)) - 32))
+            if dist is not None:  # (every rank takes the same number of attempts: the norm exchange is collective)
+                box = torch.tensor([more], dtype=torch.int64)
+                dist.all_reduce(box, op=dist.ReduceOp.MAX)
+                more = int(box.item())
+            solver.advance(more)
+            settle += 32 + more
         if events:
             be.prof_enable(args.event_period)  # (already during the warm-up steps: a stream's FIRST dispatch-stamped launches are not free)
         solver.advance(warmup)

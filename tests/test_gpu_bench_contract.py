@@ -33,7 +33,7 @@ def test_bench_json_contract():
     assert abs(j["value"] - 4096 * 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6  # value = states per step / step time
     # warmup + steps attempted, nothing skipped (+ the untimed settle attempts of set-up: the allocator's pool at its steady state, and —
     # pipeline="auto" — the graph captured)
-    assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"] and j["solver"]["settle_steps"] == 256
+    assert j["solver"]["n_steps"] == 8 + j["solver"]["settle_steps"] and j["solver"]["settle_steps"] >= 32
 
     # VERDICT r04 (next 6): the same K-step block three times in one run (the first is `ms_per_step`), and what of a step is inside no kernel
     assert len(j["ms_per_step_blocks"]) == 3 and j["ms_per_step_blocks"][0] == j["ms_per_step"] and all(b > 0 for b in j["ms_per_step_blocks"])
