@@ -565,7 +565,8 @@ def main():
         # after 24 / 96 / 256 settle attempts + 5 warm-up steps at the headline size: 0.3169 / 0.3135 / 0.3131 ms per step against
         # 0.3108 / 0.3093 / 0.3122 for the blocks after it (profiles/r05_settle.txt); at the c4 shard 256 attempts (41 ms) still left the
         # first block 2 % behind, hence a time, not a count.  The timed region stays EXACTLY K attempts.
-        if not rehearsal and SETTLE_MS > 0:  # (a rehearsal — several ranks time-slicing ONE card — is not a measurement)
+        # (a rehearsal — several ranks time-slicing ONE card — is not a measurement; XDE_BENCH_SETTLE_IN_REHEARSAL=1 settles there too: a soak)
+        if SETTLE_MS > 0 and (not rehearsal or os.environ.get("XDE_BENCH_SETTLE_IN_REHEARSAL") == "1"):
             torch.cuda.synchronize()
             t_s = time.perf_counter()
             solver.advance(32)
