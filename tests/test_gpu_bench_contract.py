@@ -119,6 +119,7 @@ def test_bench_parent_stops_a_job_that_never_finishes():
     assert time.time() - t0 < 200
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "still running after 30 s" in r.stderr and "rank 0: in stage" in r.stderr and "rank 1: in stage 'set-up + warm-up + timed region'" in r.stderr
+    time.sleep(3)  # (two processes that held the card were just KILLED: the next test's probe children should not meet their teardown)
 
 
 def test_bench_n_rank_line_names_devices_transport_and_alternatives():
