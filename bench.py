@@ -10,6 +10,10 @@ gloo), if the line does not say n_gpus == N, or — exit code 124, with the stag
 XDE_BENCH_TIMEOUT seconds.  Under a launcher (the driver's torch.distributed.run) it is one rank of the job.  Either way every rank
 runs each stage (rendezvous, transport probe, communicator, negotiation, timed region, extras, teardown) under a watchdog.
 
+Set-up (untimed, like the framework's GEMM tuning) ends with XDE_BENCH_SETTLE_MS (default 100) milliseconds of attempts — their number is
+`solver.settle_steps` on the line — so that a short timed block reads what the same block reads when repeated (profiles/r05_settle.txt);
+then W warm-up steps, then EXACTLY K timed attempts; the same K-step block is repeated twice more (`ms_per_step_blocks`).
+
 A "step" is ONE attempted Dopri5 step over the whole batch: 6 stage combines (xde_stage_combine), 6 calls
 of the user's func (a framework call: torch matmul ``y @ A^T``), one fused error-norm launch and the device
 controller — exactly what ``paddlexde_amd.odeint(..., solver=Dopri5)`` runs per attempt.
