@@ -211,6 +211,15 @@ def time_unsharded(B, D, dtype, pipeline, device, steps, warmup):
     s = Dopri5(xde=xde, y0=y0, rtol=1e-5, atol=1e-7, norm=_rms_norm, pipeline=pipeline)
     s.y0 = y0
     s._before_integrate(np.asarray([0.0, 1.0e9], dtype=np.float32))
+    settle = 0
+    if SETTLE_MS > 0 and os.environ.get("XDE_BENCH_REHEARSAL", "0") != "1":  # (the same settle phase as the main line's: timed_run)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        s.advance(32)
+        torch.cuda.synchronize()
+        more = min(4096, max(0, int(SETTLE_MS * 1e-3 * 32 / max(time.perf_counter() - t_s, 1e-6)) - 32))
+        s.advance(more)
+        settle = 32 + more
     s.advance(warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -218,7 +227,7 @@ def time_unsharded(B, D, dtype, pipeline, device, steps, warmup):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return {"value": B * D * steps / el, "unit": "states/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
-            "global_batch": B, "dim": D, "n_gpus": 1}
+            "settle_steps": settle, "global_batch": B, "dim": D, "n_gpus": 1}
 
 
 def pmc_traffic(B, D, dtype):
