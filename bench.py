@@ -249,6 +249,9 @@ def pmc_traffic(B, D, dtype):
         if rec.get("kernel_stamp") != now:
             src["stale"] = "the stage-combine kernel's sources changed after this counter pass was taken: not reported"
             return None, src
+        if rec.get("rocprofv3_avg_launch_us"):  # the same kernel's mean launch duration by rocprofv3 (kernel summary of the same profile run)
+            src["rocprofv3_avg_launch_us"] = rec["rocprofv3_avg_launch_us"]
+            src["rocprofv3_file"] = rec.get("rocprofv3_source")
         return rec.get("hbm_bytes_per_launch"), src
     except Exception as e:
         return None, "{}: {}".format(type(e).__name__, e)
@@ -707,6 +710,12 @@ def main():
             "bytes_per_launch": comb["bytes"] / max(comb["launches"], 1),
             "avg_launch_us": 1e3 * comb["ms"] / max(comb["launches"], 1),
         }
+        if isinstance(traffic_source, dict) and traffic_source.get("rocprofv3_avg_launch_us"):
+            # beside the live figure, the RECORDED one: rocprofv3's mean duration of the same launches (committed kernel summary, same
+            # stamp as the counter passes) — the events of a sampled launch read ~1 us longer than the profiler does
+            us = traffic_source.pop("rocprofv3_avg_launch_us")
+            out["roofline"]["rocprofv3"] = {"avg_launch_us": us, "frac": out["roofline"]["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                           "file": traffic_source.pop("rocprofv3_file", None), "kernel_stamp": traffic_source.get("kernel_stamp")}
         en = prof["errnorm"]
         if en["ms"] > 0:
             a2 = en["bytes"] / (en["ms"] * 1e-3) / 1e9

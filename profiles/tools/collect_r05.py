@@ -86,6 +86,21 @@ def main():
         by_size[key] = {"hbm_bytes_per_launch": mean, "errnorm_hbm_bytes_per_launch": en, "round": 5,
                         "kernel_stamp": kernel_stamp("combine"), "errnorm_kernel_stamp": kernel_stamp("errnorm"),
                         "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; mean over the step's six stage launches)" % dst}
+        # ... and rocprofv3's mean duration of the same six launches, from the kernel summary collected above (bench.py prints it beside
+        # its own event timing: roofline.rocprofv3)
+        stats = os.path.join(D, "r05_" + {"bench": "bench", "c4-shard": "c4_shard", "c4-n1": "c4_n1"}[name] + "_kernel_stats.csv")
+        if os.path.exists(stats):
+            tot = cnt = 0.0
+            for r in csv.DictReader(open(stats)):
+                n = r["Name"]
+                stage = ("xde_combine_kernel<" in n and ", 0, " in n.split("xde_combine_kernel<")[1][:12]) or "xde_combine_pre_kernel<" in n
+                if stage and int(r["Calls"]) >= 100:
+                    tot += float(r["TotalDurationNs"])
+                    cnt += int(r["Calls"])
+            if cnt:
+                by_size[key]["rocprofv3_avg_launch_us"] = tot / cnt / 1e3
+                by_size[key]["rocprofv3_source"] = ("profiles/%s (rocprofv3 --kernel-trace --stats; calls-weighted mean over the step's six stage launches)"
+                                                    % os.path.basename(stats))
     if by_size:
         json.dump({"by_size": by_size, "note": "written by profiles/tools/collect_r05.py; bench.py reports a figure only when kernel_stamp equals "
                    "csrc/build.py::kernel_stamp('combine') of the sources the library was built from"}, open(tpath, "w"), indent=1)
