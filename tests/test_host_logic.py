@@ -64,6 +64,27 @@ def test_bench_stage_watchdog_ends_a_rank_that_outlives_its_stage(tmp_path):
     assert r.returncode == 70 and "over its limit" in r.stderr
 
 
+def test_bench_recorded_measurements_are_tied_to_the_kernel_sources(monkeypatch):
+    """`roofline.traffic` (PMC counter passes) and `roofline.rocprofv3` (the committed kernel summary's mean stage-launch duration) are
+    RECORDED measurements: bench.py reports them only while the stamp of the stage-combine kernel's sources equals the stamp the record
+    was taken with, and says why when it does not."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from paddlexde_amd.csrc import build
+
+    traffic, src = bench.pmc_traffic(65536, 128, "f32")
+    assert traffic and abs(traffic / (31 * 65536 * 128 * 4 / 6) - 1) < 0.01  # (PMC bytes = the 31 N 4 B a step's six stage launches move)
+    assert src["kernel_stamp"] == src["current_kernel_stamp"] == build.kernel_stamp("combine")
+    assert 20 < src["rocprofv3_avg_launch_us"] < 35 and "kernel_stats.csv" in src["rocprofv3_file"]
+    monkeypatch.setattr(build, "kernel_stamp", lambda which: "0" * 12)  # (the kernel changed after the record was taken)
+    traffic, src = bench.pmc_traffic(65536, 128, "f32")
+    assert traffic is None and "stale" in src
+    assert bench.pmc_traffic(123, 7, "f32")[0] is None
+
+
 def test_garbage_collector_is_held_off_while_a_capture_records():
     """Round 5: an automatic cyclic collection that starts INSIDE a stream capture can reap a dropped module's cached captures (the
     per-module cache is keyed weakly) and release their graphs / memory pools in the middle of the recording — the process aborted
