@@ -7,11 +7,16 @@ reference's op order, for scripts that call them directly."""
 import torch
 
 
+def _same_time(a, b):
+    r = a == b  # (tensors on one device, or a tensor and a number: the reference's `if t == t0`)
+    return bool(r.all()) if torch.is_tensor(r) else bool(r)
+
+
 def linear_interp(t0, t1, y0, y1, t):
     """interp_fn.py:4-10"""
-    if torch.equal(torch.as_tensor(t), torch.as_tensor(t0)):
+    if _same_time(t, t0):
         return y0
-    if torch.equal(torch.as_tensor(t), torch.as_tensor(t1)):
+    if _same_time(t, t1):
         return y1
     slope = (t - t0) / (t1 - t0)
     return y0 + slope * (y1 - y0)
