@@ -98,6 +98,37 @@ def _stage_report(status_dir, n):
     return "\n".join(rows)
 
 
+def group_members(pgid):
+    """Live (non-zombie) processes whose process group or session is `pgid` — read from /proc, no signal is sent.  A zombie has
+    released everything it held (its GPU context included) and only waits for its parent's `wait`."""
+    out = []
+    for name in os.listdir("/proc"):
+        if not name.isdigit():
+            continue
+        try:
+            with open("/proc/{}/stat".format(name)) as fh:
+                stat = fh.read()
+        except OSError:
+            continue  # gone between the listing and the read
+        # pid (comm) state ppid pgrp session ...: comm may hold spaces and parentheses, so split after the LAST ')'
+        fields = stat[stat.rfind(")") + 2:].split()
+        if len(fields) < 4 or fields[0] == "Z":
+            continue
+        if int(fields[2]) == pgid or int(fields[3]) == pgid:
+            out.append(int(name))
+    return out
+
+
+def wait_for_group_exit(pgid, seconds):
+    """Poll until no live process of process group / session `pgid` is left, `seconds` at most.  -> the pids still alive ([] = none)."""
+    deadline = time.time() + seconds
+    while True:
+        left = group_members(pgid)
+        if not left or time.time() > deadline:
+            return left
+        time.sleep(0.05)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) invoked WITHOUT a launcher (the reference's own recipe is one command too,
     example/D3STN/README.md:53-59): start one rank per GPU with `python -m torch.distributed.run` as a CHILD process, relay rank 0's
@@ -120,6 +151,8 @@ def self_launch(args):
               "(XDE_BENCH_REHEARSAL=1 rehearses the N-rank invocation on one GPU over gloo)".format(n, have), file=sys.stderr)
         return 2
     if rehearsal and n > 6:
+        # (the GPU pool's process guard ends a job with more than 6 processes on one card; the world-8 geometry is rehearsed in ONE
+        # process instead: tests/test_gpu_world8.py — eight ranks as threads, real mailboxes, real kernels)
         print("bench.py: a rehearsal keeps to 6 ranks on one card", file=sys.stderr)
         return 2
     env = dict(os.environ)
@@ -146,6 +179,12 @@ def self_launch(args):
                 break
             except subprocess.TimeoutExpired:
                 continue
+        # `communicate` reaps the LAUNCHER only.  The ranks (and their probe children) are its children, not ours: killed, they may still
+        # be tearing their GPU contexts down when the launcher is gone — whoever runs next on this card (the next test's probe
+        # children, round 5's one red run) would meet that.  So: wait until nobody of that session is left before saying 124.
+        left = wait_for_group_exit(proc.pid, 30.0)
+        if left:
+            print("bench.py: processes of the stopped job still alive after 30 s: {}".format(left), file=sys.stderr, flush=True)
         return 124
     lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
     if proc.returncode != 0:

@@ -614,11 +614,22 @@ class HipBackend:
         def _recycle(self):
             host, ev, pool = self.host, self.ev, self.pool
             self.host = self.ev = self.pool = None
-            if host is not None and pool is not None and len(pool) < HipBackend.PEEK_POOL_MAX:
+            if host is None:
+                return
+            if pool is not None and len(pool) < HipBackend.PEEK_POOL_MAX:
                 pool.append((host, ev, self.device))
+            else:
+                # not kept: releasing a pinned buffer records an event on the stream its copy ran on — which may be recording a
+                # hipGraph right now (this runs from __del__, at any allocation): utils.graphed parks the pair until none is
+                from .utils.graphed import release_when_idle
+
+                release_when_idle((host, ev))
 
         def __del__(self):  # a handle nobody read (a solve that ended before its second attempt): the pair is reusable all the same —
-            self._recycle()  # copies are stream-ordered, a later peek's copy and event land after this one's
+            try:  # copies are stream-ordered, a later peek's copy and event land after this one's
+                self._recycle()
+            except Exception:  # interpreter shutdown
+                pass
 
     def ctrl_peek_async(self, ctrl):
         """Enqueue a copy of the control block AS IT IS AT THIS POINT OF THE STREAM into pinned host memory (a freshly constructed block

@@ -73,13 +73,21 @@ class CapturedGraph:
     def capture(self, **kwargs):
         """Context manager: ``with cg.capture(): ...`` records into the graph; call ``finish()`` afterwards.
 
-        Python's cyclic garbage collector is held off for the duration of the recording.  ``torch.cuda.graph`` collects once on entry,
-        but an automatic collection can still start at any allocation INSIDE the recorded body; if it reaps an object that owns
-        device resources — a dropped module's cached captures (``odeint_adjoint``'s per-module cache is keyed weakly: the entry dies
-        with the module), their graphs' private memory pools — those are released in the middle of an active stream capture, and the
-        process aborts (round 5: ``Fatal Python error: Aborted`` under ``weakref.remove`` inside a captured ``func``, one GPU run in
-        five).  Collection resumes, if it was on, when the recording ends."""
-        return _capture_without_gc(torch.cuda.graph(self.graph, **kwargs))
+        The recording is opened through ``recording()`` (below): while ANY thread of the process records, a captured graph whose last
+        reference dies — by a cyclic collection, by an explicit ``gc.collect()`` inside a user's func, or by a plain reference-count
+        drop — is parked on a process-wide list instead of being destroyed, and destroyed when the outermost recording has ended."""
+        return recording(torch.cuda.graph(self.graph, **kwargs))
+
+    def __del__(self):
+        # hipGraphExecDestroy / hipGraphDestroy / the release of the graph's private memory pool must not run in the middle of a stream
+        # capture (round 5, gpurun_out/r05f: `Fatal Python error: Aborted` under `weakref.remove` — a collection inside a captured func
+        # reaped a dropped module's entry of the per-module capture cache; the destructor's failed HIP call ends in std::terminate)
+        try:
+            g = self.__dict__.pop("graph", None)
+            if g is not None:
+                release_when_idle(g)
+        except Exception:  # interpreter shutdown: module globals may be gone
+            pass
 
     def finish(self):
         if self._kept:
@@ -107,30 +115,82 @@ class CapturedGraph:
             torch.cuda.current_stream().synchronize()
 
 
-class _capture_without_gc:
-    """``with torch.cuda.graph(...)`` with the cyclic garbage collector switched off between entry and exit (see
-    CapturedGraph.capture).  Entry first (it runs its own ``gc.collect()`` while that is still harmless), then ``gc.disable()``."""
+# ----------------------------------------------------------------------------------------------------------------------
+# Recordings open in the process, and what must not be released while one is
+# ----------------------------------------------------------------------------------------------------------------------
+# Re-entrant: a finalizer (release_when_idle) can run at any allocation, also on a thread that holds the lock
+_REC_LOCK = threading.RLock()
+_REC = {"depth": 0, "gc_was_enabled": False, "deferred_total": 0}
+_DEFERRED = []  # owners of device resources whose last reference died while a recording was open
+
+
+def recordings_open():
+    """Stream captures this package has open in the process (any thread)."""
+    return _REC["depth"]
+
+
+def release_when_idle(obj):
+    """For finalizers of objects that own device resources whose release issues HIP calls (a captured graph and its private pool;
+    pinned buffers, whose release records an event on the streams that used them).  While a recording is open in the process the
+    object is kept alive on a process-wide list, emptied when the outermost recording has ended, and True is returned; with no
+    recording open nothing is kept and the caller's reference is the last one."""
+    with _REC_LOCK:
+        if _REC["depth"] > 0:
+            _DEFERRED.append(obj)
+            _REC["deferred_total"] += 1
+            return True
+    return False
+
+
+class recording:
+    """``with recording(torch.cuda.graph(...))``: a stream capture during which nothing that owns a captured graph is released.
+
+    * The resources: ``CapturedGraph.__del__`` (every graph this package captures — ``GraphedFunc``'s captures in the per-module cache
+      of ``functional/_adjoint_capture.py``, the pipelines' and interval solvers' graphs of ``_hip.HipBackend.capture``, the fixed
+      solvers' captured step) and ``_hip._Peek`` (pinned buffers) go through ``release_when_idle``.  The list is emptied under the
+      lock when the depth returns to zero: a thread that wants to open the next recording waits for that.
+    * The belt: Python's cyclic collector is run once BEFORE the first recording opens (torch 2.10's ``torch.cuda.graph`` does not
+      collect on entry: ``torch.compiler.config.force_cudagraph_gc`` is False) and held off until the last one has closed — counted
+      across threads, because captures are opened ``capture_error_mode="thread_local"`` so that other threads keep working: the
+      first recording in remembers whether the collector was on, the last one out restores it.  The belt does not cover an explicit
+      ``gc.collect()`` in a user's func or a reference-count drop; the deferred release does."""
 
     def __init__(self, ctx):
         self.ctx = ctx
-        self.was_enabled = False
 
     def __enter__(self):
         import gc
 
-        out = self.ctx.__enter__()
-        self.was_enabled = gc.isenabled()
-        gc.disable()
-        return out
+        if _REC["depth"] == 0 and gc.isenabled():
+            gc.collect()  # dead cycles that own captures die here, while that is harmless
+        with _REC_LOCK:
+            if _REC["depth"] == 0:
+                _REC["gc_was_enabled"] = gc.isenabled()
+                gc.disable()
+            _REC["depth"] += 1
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            self._close()
+            raise
 
     def __exit__(self, *exc):
-        import gc
-
         try:
             return self.ctx.__exit__(*exc)
         finally:
-            if self.was_enabled:
-                gc.enable()
+            self._close()
+
+    @staticmethod
+    def _close():
+        import gc
+
+        with _REC_LOCK:
+            _REC["depth"] -= 1
+            if _REC["depth"] == 0:
+                while _DEFERRED:  # (a destructor run here cannot add to the list: the depth is zero)
+                    _DEFERRED.pop()
+                if _REC["gc_was_enabled"]:
+                    gc.enable()
 
 
 def _map(x, fn):

@@ -88,40 +88,157 @@ def test_bench_recorded_measurements_are_tied_to_the_kernel_sources(monkeypatch)
     assert bench.pmc_traffic(123, 7, "f32")[0] is None
 
 
+class _FakeCapture:
+    """Stands in for ``torch.cuda.graph(...)``: notes the collector's state at entry and exit."""
+
+    def __init__(self):
+        self.events = []
+
+    def __enter__(self):
+        import gc
+
+        self.events.append(("enter", gc.isenabled()))
+        return "graph"
+
+    def __exit__(self, *exc):
+        import gc
+
+        self.events.append(("exit", gc.isenabled()))
+        return False
+
+
 def test_garbage_collector_is_held_off_while_a_capture_records():
-    """Round 5: an automatic cyclic collection that starts INSIDE a stream capture can reap a dropped module's cached captures (the
-    per-module cache is keyed weakly) and release their graphs / memory pools in the middle of the recording — the process aborted
-    under `weakref.remove` inside a captured func (gpurun_out/r05f/suite.log).  Every recording now runs with the collector off and
-    restores it afterwards — also when the body raises, and without switching it ON for a caller who had it off."""
+    """Round 5: a cyclic collection that starts INSIDE a stream capture reaped a dropped module's cached captures (the per-module
+    cache is keyed weakly) and destroyed their graphs / memory pools in the middle of the recording — the process aborted under
+    `weakref.remove` inside a captured func (gpurun_out/r05f/suite.log).  The belt: every recording runs with the collector off (torch
+    2.10's `torch.cuda.graph` does NOT collect on entry — `force_cudagraph_gc` is False — so `recording` collects once itself, before the
+    capture opens) and restores it afterwards — also when the body raises, and without switching it ON for a caller who had it off."""
     import gc
 
-    from paddlexde_amd.utils.graphed import _capture_without_gc
+    from paddlexde_amd.utils.graphed import recording, recordings_open
 
-    class Ctx:
-        def __init__(self):
-            self.events = []
-
-        def __enter__(self):
-            self.events.append(("enter", gc.isenabled()))  # (torch.cuda.graph collects on entry: the collector is still on then)
-            return "graph"
-
-        def __exit__(self, *exc):
-            self.events.append(("exit", gc.isenabled()))
-            return False
-
-    assert gc.isenabled()
-    c = Ctx()
-    with _capture_without_gc(c) as g:
-        assert g == "graph" and not gc.isenabled()
-    assert gc.isenabled() and c.events == [("enter", True), ("exit", False)]
+    assert gc.isenabled() and recordings_open() == 0
+    c = _FakeCapture()
+    with recording(c) as g:
+        assert g == "graph" and not gc.isenabled() and recordings_open() == 1
+    assert gc.isenabled() and recordings_open() == 0 and c.events == [("enter", False), ("exit", False)]
     with pytest.raises(RuntimeError):
-        with _capture_without_gc(Ctx()):
+        with recording(_FakeCapture()):
             raise RuntimeError("func cannot be captured")
-    assert gc.isenabled()
+    assert gc.isenabled() and recordings_open() == 0
+
+    class Refuses(_FakeCapture):
+        def __enter__(self):
+            raise RuntimeError("capture_begin failed")
+
+    with pytest.raises(RuntimeError):
+        with recording(Refuses()):
+            pass
+    assert gc.isenabled() and recordings_open() == 0
     gc.disable()
     try:
-        with _capture_without_gc(Ctx()):
+        with recording(_FakeCapture()):
             pass
         assert not gc.isenabled()
     finally:
         gc.enable()
+
+
+def test_collector_guard_counts_recordings_across_threads():
+    """captures are opened `capture_error_mode="thread_local"` so that other threads keep working — two recordings can
+    overlap.  The guard is a process-wide depth counter under a lock: the first recording in switches the collector off, and only
+    the LAST one out switches it back on (a per-context `was_enabled` would re-enable it while the other thread still records)."""
+    import gc
+    import threading
+
+    from paddlexde_amd.utils.graphed import recording, recordings_open
+
+    a_inside, b_inside, a_may_leave, b_may_leave = (threading.Event() for _ in range(4))
+    seen = {}
+
+    def thread_a():
+        with recording(_FakeCapture()):
+            a_inside.set()
+            a_may_leave.wait(10)
+        seen["after_a"] = (gc.isenabled(), recordings_open())
+
+    def thread_b():
+        a_inside.wait(10)
+        with recording(_FakeCapture()):
+            seen["both"] = (gc.isenabled(), recordings_open())
+            b_inside.set()
+            b_may_leave.wait(10)
+        seen["after_b"] = (gc.isenabled(), recordings_open())
+
+    assert gc.isenabled()
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(), tb.start()
+    assert b_inside.wait(10)
+    a_may_leave.set()
+    ta.join(10)
+    assert seen["both"] == (False, 2)
+    assert seen["after_a"] == (False, 1), "the first recording to end must not switch the collector on under the other one"
+    b_may_leave.set()
+    tb.join(10)
+    assert seen["after_b"] == (True, 0) and gc.isenabled()
+    # nested on one thread (a func that is itself a GraphedFunc being prepared inside a recording body)
+    with recording(_FakeCapture()):
+        with recording(_FakeCapture()):
+            assert recordings_open() == 2 and not gc.isenabled()
+        assert recordings_open() == 1 and not gc.isenabled()
+    assert recordings_open() == 0 and gc.isenabled()
+
+
+def test_captured_graphs_that_die_during_a_recording_are_released_after_it():
+    """The fix proper: an owner of a captured graph that dies while ANY recording is open — through a cyclic
+    collection, an explicit `gc.collect()` in a user's func (which `gc.disable()` does not stop) or a plain reference-count drop —
+    hands the graph to a process-wide list; it is destroyed when the outermost recording has ended, never inside one."""
+    import gc
+    import threading
+
+    from paddlexde_amd.utils import graphed
+
+    backing = {}
+
+    def handle(name):
+        """Stands in for torch.cuda.CUDAGraph: an object of a C type whose DEALLOCATION is observable (a memoryview pins its
+        bytearray: the array cannot be resized while the view lives).  A Python `__del__` would not do: the collector calls it once
+        as soon as it finds the object in a dead cycle, resurrected or not — the C++ destructor of the real thing runs at deallocation."""
+        backing[name] = bytearray(8)
+        return memoryview(backing[name])
+
+    def alive(name):
+        try:
+            backing[name].append(0)
+            backing[name].pop()
+            return False
+        except BufferError:
+            return True
+
+    def owner(name, cyclic):
+        cg = graphed.CapturedGraph.__new__(graphed.CapturedGraph)  # (no GPU here: the attributes __init__ would set, by hand)
+        cg.graph = handle(name)
+        if cyclic:
+            cg.me = cg  # dies only when the collector runs, like a module whose hooks refer back to it
+        return cg
+
+    # no recording open: released at once, nothing parked
+    o = owner("idle", False)
+    assert alive("idle")
+    del o
+    assert not alive("idle") and not graphed._DEFERRED
+
+    o1, o2 = owner("refcount", False), owner("cycle", True)
+    o3 = owner("other-thread", False)
+    with graphed.recording(_FakeCapture()):
+        del o1  # reference-count drop inside the body
+        del o2
+        gc.collect()  # an explicit collection inside the user's func: gc.disable() does not prevent it
+        t = threading.Thread(target=lambda box: box.pop(), args=([o3],))
+        del o3
+        t.start(), t.join()  # the last reference dies on a thread that is not recording
+        with graphed.recording(_FakeCapture()):
+            pass  # an inner recording that ends does not empty the list: the outer one is still open
+        assert alive("refcount") and alive("cycle") and alive("other-thread") and len(graphed._DEFERRED) == 3
+    assert not (alive("refcount") or alive("cycle") or alive("other-thread")) and not graphed._DEFERRED
+    assert graphed.release_when_idle(object()) is False
