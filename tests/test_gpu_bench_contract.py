@@ -119,7 +119,8 @@ def test_bench_parent_stops_a_job_that_never_finishes():
     assert time.time() - t0 < 200
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "still running after 30 s" in r.stderr and "rank 0: in stage" in r.stderr and "rank 1: in stage 'set-up + warm-up + timed region'" in r.stderr
-    time.sleep(3)  # (two processes that held the card were just KILLED: the next test's probe children should not meet their teardown)
+    # (the parent returned 124 only after every process of the job's session was gone — bench_launch.wait_for_group_exit — so the next
+    #  test's probe children cannot meet a killed rank that is still tearing its GPU context down: no sleep here)
 
 
 def test_bench_n_rank_line_names_devices_transport_and_alternatives():
@@ -136,6 +137,22 @@ def test_bench_n_rank_line_names_devices_transport_and_alternatives():
     ab = j["exchange_ab"]
     assert ab["p2p"]["headline"] is True and ab["p2p"]["ms_per_step"] == j["ms_per_step"] and ab["allreduce"]["ms_per_step"] > 0, (ab, said)
     assert "rccl_allreduce_ms_per_step" in j and j["rccl_allreduce_ms_per_step"] is None  # (gloo rehearsal: there is no RCCL group to time)
+
+
+def test_bench_two_rank_rehearsal_takes_the_settle_phase_too():
+    """a real N-GPU run always takes the multi-rank settle path — the all-reduce(MAX) of the settle count, then
+    hundreds of collective mailbox exchanges before the timed region — while a one-card rehearsal skips it by default.  Once, in the
+    default suite, with the settle phase ON (a short one): the ranks agree on the number of attempts, the peer-to-peer transport is
+    adopted and survives them, and the line counts them."""
+    r = _launch({"XDE_BENCH_REHEARSAL": "1", "XDE_BENCH_SETTLE_IN_REHEARSAL": "1", "XDE_BENCH_SETTLE_MS": "30"}, "--gpus", "2", "--steps", "5",
+                "--warmup", "2", "--no-n1", "--no-ab")
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    rep = j["norm_exchange_report"]
+    said = (rep, r.stderr[-1500:])
+    assert rep["p2p_probe"]["ok"] is True and rep["tried"][0] == {"transport": "p2p", "adopted": True}, said
+    assert j["solver"]["settle_steps"] >= 32 and j["solver"]["n_steps"] == 7 + j["solver"]["settle_steps"], (j["solver"], said)
+    assert j["n_gpus"] == 2 and j["value"] > 0
 
 
 def test_bench_survives_a_peer_to_peer_probe_that_crashes():
