@@ -344,6 +344,26 @@ int xde_initial_step_fused(int phase, const void* a, const void* b, const void* 
                            int32_t n_out, const double* t_span_dev, const double* step_t_dev, void* t_stage_out, int64_t seq0,
                            void* stream);
 
+/*
+ * The same heuristic for states ABOVE the one-workgroup kernels' reach (added in round 6; ABI 6 still — nothing existing changed):
+ * 12 launches become 4 (+ the Euler probe's xde_stage_combine).
+ *   xde_scaled_norm2_partial: partials of d0 = norm(y0/scale) into slot 0 of `ws` and of d1 = norm(f0/scale) into slot 1 in ONE pass
+ *            over (y0, f0) — they share scale = atol + |y0| rtol (solver/base_adaptive_solver.py:50-53); record for record what two
+ *            xde_scaled_norm_partial launches (a = y0, slot 0; a = f0, slot 1) write.
+ *   xde_initial_step_tail, one workgroup per phase, everything that followed a norm pass as launches of its own:
+ *     phase 0: xde_norm_finalize + xde_norm_result of slots 0 and 1, then phase 0 of xde_initial_step (hs_dev[0..2] = {d0, d1, h0},
+ *              ctrl->dt = direction*h0, *t_probe_out = t_start + direction*h0);
+ *     phase 1: the same for slot 0 (filled by xde_scaled_norm_partial(a = f1, b = f0, slot 0)), phase 1 of xde_initial_step
+ *              (hs_dev[3] = the first step, hs_dev[4] = that norm) and xde_ctrl_init(first_step_dev = hs_dev + 3).
+ *   Norm kind, segment counts, dtypes come from params (one GPU, a native norm of <= XDE_MAX_SEG segments: a sharded run exchanges the
+ *   sums between finalize and result and keeps the separate calls).  t_start = NaN / seq0 < 0: as xde_initial_step_fused.  hs_dev: 5 doubles.
+ */
+int xde_scaled_norm2_partial(const void* f0, const void* y0, double rtol, double atol, const xde_segments_t* segs, int norm_kind,
+                             int dtype, void* ws, void* stream);
+int xde_initial_step_tail(int phase, const void* ws, double* hs_dev, const xde_ctrl_params_t* params, double t_start, void* t_probe_out,
+                          int probe_dtype, xde_ctrl_t* ctrl, int32_t n_out, const double* t_span_dev, const double* step_t_dev,
+                          void* t_stage_out, int64_t seq0, void* stream);
+
 /* Blocking device->host copy of the control block (hipMemcpyAsync + stream synchronise). */
 int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream);
 

@@ -49,6 +49,8 @@ SYMBOLS = (
     "xde_ctrl_retarget",
     "xde_initial_step",
     "xde_initial_step_fused",
+    "xde_scaled_norm2_partial",
+    "xde_initial_step_tail",
     "xde_ctrl_read",
     "xde_host_alloc",
     "xde_host_free",
@@ -234,6 +236,10 @@ def load_library():
         lib.xde_initial_step_fused.restype = i32
         lib.xde_initial_step_fused.argtypes = [i32, vp, vp, vp, C.POINTER(XdeSegments), i32, vp, C.POINTER(XdeCtrlParams), dbl, vp, i32, vp,
                                                C.c_int32, vp, vp, vp, i64, vp]
+        lib.xde_scaled_norm2_partial.restype = i32
+        lib.xde_scaled_norm2_partial.argtypes = [vp, vp, dbl, dbl, C.POINTER(XdeSegments), i32, i32, vp, vp]
+        lib.xde_initial_step_tail.restype = i32
+        lib.xde_initial_step_tail.argtypes = [i32, vp, vp, C.POINTER(XdeCtrlParams), dbl, vp, i32, vp, C.c_int32, vp, vp, vp, i64, vp]
         lib.xde_host_alloc.restype = i32
         lib.xde_host_alloc.argtypes = [i64, C.POINTER(C.c_void_p)]
         lib.xde_host_free.restype = i32
@@ -564,6 +570,28 @@ class HipBackend:
                                              dtype_code(t_probe.dtype) if t_probe is not None else XDE_F32, ctrl.data_ptr(), int(n_out),
                                              _ptr(t_span_dev), _ptr(step_t_dev), _ptr(t_stage), seq0, self._stream(y0))
         self._check(rc, "xde_initial_step_fused")
+        if m is not None:
+            m.seq0 = seq0
+
+    def scaled_norm2_partial(self, f0, y0, rtol, atol, segs, norm_kind, ws):
+        """Partials of norm(y0 / scale) (slot 0) and norm(f0 / scale) (slot 1) in one pass over (y0, f0)."""
+        self._require_device(f0, y0, ws)
+        rc = self.lib.xde_scaled_norm2_partial(f0.data_ptr(), y0.data_ptr(), float(rtol), float(atol), C.byref(segs), norm_kind,
+                                               dtype_code(y0.dtype), ws.data_ptr(), self._stream(y0))
+        self._check(rc, "xde_scaled_norm2_partial")
+
+    def initial_step_tail(self, phase, ws, hs, params, t_start, t_probe, ctrl, n_out=0, t_span_dev=None, step_t_dev=None, t_stage=None,
+                          keep_seq=False):
+        """What followed a norm pass of the initial-step heuristic as launches of its own — finalize, result, the scalar phase, and in
+        phase 1 the control block's construction — as ONE one-workgroup launch (states above initial_step_fused's reach).
+        ``t_start = nan`` / ``keep_seq``: as initial_step_fused."""
+        self._require_device(ws, hs, ctrl, t_probe, t_span_dev, t_stage)
+        m = self._mirrors.get(ctrl.data_ptr()) if (phase == 1 and not keep_seq) else None
+        seq0 = -1 if keep_seq else (m.seq if m is not None else 0)
+        rc = self.lib.xde_initial_step_tail(int(phase), ws.data_ptr(), hs.data_ptr(), C.byref(params), float(t_start), _ptr(t_probe),
+                                            dtype_code(t_probe.dtype) if t_probe is not None else XDE_F32, ctrl.data_ptr(), int(n_out),
+                                            _ptr(t_span_dev), _ptr(step_t_dev), _ptr(t_stage), seq0, self._stream(ctrl))
+        self._check(rc, "xde_initial_step_tail")
         if m is not None:
             m.seq0 = seq0
 

@@ -367,6 +367,54 @@ __global__ __launch_bounds__(kSingleBlock) void xde_initial_step_single_kernel(I
   }
 }
 
+// The same heuristic for states ABOVE the one-workgroup kernels' reach (round 6): the norm passes stay multi-workgroup launches
+// (xde_scaled_norm2_partial for phase 0's two norms in one pass, xde_scaled_norm_partial for phase 1's), and everything that came after
+// each of them as a launch of its own — xde_norm_finalize, xde_norm_result, xde_initial_step, and in phase 1 xde_ctrl_init — is ONE
+// one-workgroup launch per phase: 12 launches -> 4.  Same fixed-order reduction (reduce_partials), same norm_from_sums, same scalar
+// phases, same ctrl_init_body: same bits as the separate launches.
+struct InitTailArgs {
+  const NormSlot* slot_a;  // phase 0: partials of norm(y0/scale); phase 1: of norm((f1 - f0)/scale)
+  const NormSlot* slot_b;  // phase 0: partials of norm(f0/scale)
+  double* hs;
+  double t_start;
+  void* t_probe_out;
+  int probe_dtype;
+  int phase;
+  int32_t n_out;
+  const double* t_span;
+  const double* step_t;
+  void* t_stage_out;
+  int64_t seq0;
+};
+
+__global__ __launch_bounds__(kBlock) void xde_initial_step_tail_kernel(InitTailArgs g, xde_ctrl_params_t p, xde_ctrl_t* c) {
+  __shared__ double seg_val[2][XDE_MAX_SEG];
+  __shared__ double seg_nf[2][XDE_MAX_SEG];
+  __shared__ xde_ctrl_t z;
+  if (threadIdx.x < XDE_MAX_SEG) {
+    seg_val[0][threadIdx.x] = seg_val[1][threadIdx.x] = 0.0;
+    seg_nf[0][threadIdx.x] = seg_nf[1][threadIdx.x] = 0.0;
+  }
+  __syncthreads();
+  const bool diff = g.phase == 1;
+  reduce_partials(g.slot_a, seg_val[0], seg_nf[0]);
+  if (!diff) reduce_partials(g.slot_b, seg_val[1], seg_nf[1]);
+  if (threadIdx.x != 0) return;
+  double res[2];
+  res[0] = norm_from_sums(seg_val[0], p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, nullptr);
+  res[1] = diff ? 0.0 : norm_from_sums(seg_val[1], p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, nullptr);
+  // t_start = NaN: the start time is t_span_dev[0] (a launch recorded in a graph serves every interval it is replayed for)
+  const double t_start = (g.t_start != g.t_start && g.t_span) ? g.t_span[0] : g.t_start;
+  if (p.state_dtype == XDE_F32)
+    initial_step_phase<float>(g.phase, res, g.hs, p, t_start, g.t_probe_out, g.probe_dtype, c);
+  else
+    initial_step_phase<double>(g.phase, res, g.hs, p, t_start, g.t_probe_out, g.probe_dtype, c);
+  if (diff) {
+    g.hs[4] = res[0];  // (the third norm, for the parity tests)
+    ctrl_init_body(c, p, t_start, double(p.direction) * fabs(g.hs[3]), g.n_out, g.t_span, g.step_t, g.t_stage_out, g.seq0, z);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -568,6 +616,40 @@ int xde_initial_step_fused(int phase, const void* a, const void* b, const void* 
     else LAUNCH_IS(double, XDE_NORM_LINF);
   }
 #undef LAUNCH_IS
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_initial_step_tail(int phase, const void* ws, double* hs_dev, const xde_ctrl_params_t* params, double t_start, void* t_probe_out,
+                          int probe_dtype, xde_ctrl_t* ctrl, int32_t n_out, const double* t_span_dev, const double* step_t_dev,
+                          void* t_stage_out, int64_t seq0, void* stream) {
+  if (!ws || !hs_dev || !ctrl) return fail(XDE_EBADARG, "xde_initial_step_tail: null pointer");
+  if (phase != 0 && phase != 1) return fail(XDE_EBADARG, "xde_initial_step_tail: phase must be 0 or 1");
+  if (phase == 0 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step_tail: phase 0 needs t_probe_out");
+  if (phase == 1 && (!t_span_dev || !t_stage_out)) return fail(XDE_EBADARG, "xde_initial_step_tail: phase 1 needs t_span_dev and t_stage_out");
+  if (phase == 1 && n_out < 1) return fail(XDE_EBADARG, "xde_initial_step_tail: n_out must be >= 1");
+  if (t_start != t_start && !t_span_dev) return fail(XDE_EBADARG, "xde_initial_step_tail: t_start = NaN needs t_span_dev");
+  if (probe_dtype != XDE_F32 && probe_dtype != XDE_F64) return fail(XDE_EBADARG, "xde_initial_step_tail: bad probe dtype");
+  int rc = check_params(params, "xde_initial_step_tail");
+  if (rc != XDE_OK) return rc;
+  if (phase == 1 && params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_initial_step_tail: n_step_t > 0 without step_t_dev");
+  InitTailArgs g;
+  memset(&g, 0, sizeof(g));
+  g.slot_a = slot_ptr(ws, 0);
+  g.slot_b = slot_ptr(ws, 1);
+  g.hs = hs_dev;
+  g.t_start = t_start;
+  g.t_probe_out = t_probe_out;
+  g.probe_dtype = probe_dtype;
+  g.phase = phase;
+  g.n_out = n_out;
+  g.t_span = t_span_dev;
+  g.step_t = step_t_dev;
+  g.t_stage_out = t_stage_out;
+  g.seq0 = seq0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope prof(XDE_KID_FINALIZE, 0.0);
+  XDE_LAUNCH(xde_initial_step_tail_kernel, dim3(1), dim3(kBlock), st, prof, g, *params, ctrl);
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

@@ -144,6 +144,68 @@ __global__ __launch_bounds__(kBlock) void xde_scalednorm_kernel(ScaledArgs s) {
   block_reduce_store<NORM>(NORM == XDE_NORM_RMS ? acc64 + double(acc) : double(acc), double(nf), s.slot, seg);
 }
 
+// norm(y0 / scale) and norm(f0 / scale) of the heuristic's first phase (base_adaptive_solver.py:50-53) in ONE pass over (y0, f0): they share
+// `scale`, so the second pass over y0 (and its launch) is saved — SURVEY A6's "scaled-norm of two vectors in one pass".  Each norm's
+// partial records go to a slot of their own (d0 -> slot, d1 -> slot_b), element for element what two xde_scalednorm_kernel launches
+// on the same grid write: same per-lane order, same fp64 flush period, same workgroup reduction — same bits.
+template <typename T, int NORM, bool VEC>
+__global__ __launch_bounds__(kBlock) void xde_scalednorm2_kernel(ScaledArgs s, NormSlot* slot_b) {
+  using P = Pack<T, VEC>;
+  constexpr int W = P::W;
+  const T* __restrict__ f0 = static_cast<const T*>(s.a);
+  const T* __restrict__ y0 = static_cast<const T*>(s.y0);
+  const int seg = find_segment(s.map, blockIdx.x);
+  const int lb = blockIdx.x - s.map.seg_blk[seg];
+  const int nb = s.map.seg_blk[seg + 1] - s.map.seg_blk[seg];
+  const T rtol = T(s.rtol), atol = T(s.atol);
+  const int64_t start = s.map.seg_start[seg];
+  const int64_t len = s.map.seg_len[seg];
+  const int64_t nvec = len / W;
+  const int64_t vbase = start / W;
+  const int64_t stride = int64_t(nb) * kBlock;
+  T acc0 = T(0), acc1 = T(0);
+  double acc64_0 = 0.0, acc64_1 = 0.0;  // (see errnorm_body)
+  int it = 0;
+  int nf = 0;
+  auto one = [&](T fv, T yv) {
+    const T scale = atol + abs_(yv) * rtol;
+    const T r0 = abs_(yv / scale);
+    const T r1 = abs_(fv / scale);
+    if (NORM == XDE_NORM_RMS) {
+      acc0 = acc0 + r0 * r0;
+      acc1 = acc1 + r1 * r1;
+    } else {
+      acc0 = (r0 != r0 || acc0 != acc0) ? (r0 != r0 ? r0 : acc0) : (r0 > acc0 ? r0 : acc0);
+      acc1 = (r1 != r1 || acc1 != acc1) ? (r1 != r1 ? r1 : acc1) : (r1 > acc1 ? r1 : acc1);
+    }
+    nf += finite_(yv) ? 0 : 1;
+  };
+  for (int64_t i = int64_t(lb) * kBlock + threadIdx.x; i < nvec; i += stride) {
+    P fv = P::load(f0, vbase + i);
+    P yv = P::load(y0, vbase + i);
+#pragma unroll
+    for (int w = 0; w < W; ++w) one(fv.v[w], yv.v[w]);
+    if (NORM == XDE_NORM_RMS && (++it & 63) == 0) {
+      acc64_0 += double(acc0);
+      acc64_1 += double(acc1);
+      acc0 = T(0);
+      acc1 = T(0);
+    }
+  }
+  if (VEC && lb == 0) {
+    const int64_t i = start + nvec * W + threadIdx.x;
+    if (i < start + len) one(f0[i], y0[i]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    s.slot->nblocks = slot_b->nblocks = gridDim.x;
+    s.slot->n_seg = slot_b->n_seg = s.map.n_seg;
+    s.slot->norm_kind = slot_b->norm_kind = NORM;
+  }
+  block_reduce_store<NORM>(NORM == XDE_NORM_RMS ? acc64_0 + double(acc0) : double(acc0), double(nf), s.slot, seg);
+  __syncthreads();  // (the reduction's LDS staging is shared by the two calls)
+  block_reduce_store<NORM>(NORM == XDE_NORM_RMS ? acc64_1 + double(acc1) : double(acc1), double(nf), slot_b, seg);
+}
+
 __global__ __launch_bounds__(kBlock) void xde_finalize_kernel(const NormSlot* slot, double* sums_out) {
   __shared__ double seg_val[XDE_MAX_SEG];
   __shared__ double seg_nf[XDE_MAX_SEG];
@@ -376,6 +438,49 @@ int xde_scaled_norm_partial(const void* av, const void* bv, const void* y0, doub
   }
 #undef LAUNCH_SC2
 #undef LAUNCH_SC
+  HIP_TRY(hipGetLastError());
+  return XDE_OK;
+}
+
+int xde_scaled_norm2_partial(const void* f0, const void* y0, double rtol, double atol, const xde_segments_t* segs, int norm_kind,
+                             int dtype, void* ws, void* stream) {
+  if (!f0 || !y0 || !ws || !segs) return fail(XDE_EBADARG, "xde_scaled_norm2_partial: null pointer");
+  if (int rc0 = check_segments(segs)) return rc0;
+  if (dtype != XDE_F32 && dtype != XDE_F64) return fail(XDE_EBADARG, "xde_scaled_norm2_partial: bad dtype");
+  if (norm_kind != XDE_NORM_RMS && norm_kind != XDE_NORM_LINF) return fail(XDE_EBADARG, "xde_scaled_norm2_partial: bad norm");
+  ScaledArgs s;
+  memset(&s, 0, sizeof(s));
+  s.a = f0;
+  s.y0 = y0;
+  s.rtol = rtol;
+  s.atol = atol;
+  s.slot = slot_ptr(ws, 0);
+  NormSlot* slot_b = slot_ptr(ws, 1);
+  const int width = dtype == XDE_F32 ? 4 : 2;
+  const bool vec = aligned16(f0) && aligned16(y0) && segs_vec_ok(segs, width);
+  int nblocks = 0;
+  int rc = build_segmap(segs, vec ? width : 1, vec, &s.map, &nblocks);  // (the grid xde_scaled_norm_partial takes for these segments)
+  if (rc != XDE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double total = 0;
+  for (int i = 0; i < segs->n_seg; ++i) total += double(segs->seg_len[i]);
+  ProfScope prof(XDE_KID_SCALEDNORM, 2.0 * total * (dtype == XDE_F32 ? 4.0 : 8.0));
+  dim3 g(nblocks), b(kBlock);
+#define LAUNCH_SC2(T, NORM)                                                                \
+  do {                                                                                     \
+    if (vec)                                                                               \
+      XDE_LAUNCH((xde_scalednorm2_kernel<T, NORM, true>), g, b, st, prof, s, slot_b);      \
+    else                                                                                   \
+      XDE_LAUNCH((xde_scalednorm2_kernel<T, NORM, false>), g, b, st, prof, s, slot_b);     \
+  } while (0)
+  if (dtype == XDE_F32) {
+    if (norm_kind == XDE_NORM_RMS) LAUNCH_SC2(float, XDE_NORM_RMS);
+    else LAUNCH_SC2(float, XDE_NORM_LINF);
+  } else {
+    if (norm_kind == XDE_NORM_RMS) LAUNCH_SC2(double, XDE_NORM_RMS);
+    else LAUNCH_SC2(double, XDE_NORM_LINF);
+  }
+#undef LAUNCH_SC2
   HIP_TRY(hipGetLastError());
   return XDE_OK;
 }

@@ -98,6 +98,14 @@ class IntervalSolves:
             f1 = s._eval(self.tprobe, self.y1)
             be.initial_step_fused(1, f1, f0, y0, s._xsegs, self.hs, s._params, nan, None, s._ctrl, 2, s._t_span_dev, s._step_t_dev,
                                   s._t_stage, keep_seq=True)
+        elif s._tail_first_step():  # a larger state: the norm passes as launches of their own, one one-workgroup launch after each
+            be.scaled_norm2_partial(f0, y0, s.rtol, s.atol, s._xsegs, s._norm_kind, s._ws)
+            be.initial_step_tail(0, s._ws, self.hs, s._params, nan, self.tprobe, s._ctrl, t_span_dev=s._t_span_dev, keep_seq=True)
+            be.stage_combine(self.y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=s._ctrl)  # fuse(f0, h0, y0)
+            f1 = s._eval(self.tprobe, self.y1)
+            be.scaled_norm_partial(f1, f0, y0, float(s.rtol), float(s.atol), s._xsegs, s._norm_kind, s._ws, 0)
+            be.initial_step_tail(1, s._ws, self.hs, s._params, nan, None, s._ctrl, 2, s._t_span_dev, s._step_t_dev, s._t_stage,
+                                 keep_seq=True)
         else:  # the separate launches of _select_initial_step_device, the start time read on the device
             res, hs = self.res, self.hs
             s._scaled_norm_into(y0, None, y0, s.rtol, s.atol, res[0:1])

@@ -383,6 +383,13 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         return (self._small_state and self._chunks is None and self.process_group is None and not self._replay
                 and hasattr(self.backend, "initial_step_fused") and self._fused_first)
 
+    def _tail_first_step(self):
+        """The heuristic of a state above the one-workgroup kernels' reach in 4 launches instead of 12 (xde_scaled_norm2_partial,
+        xde_initial_step_tail): a native norm in one launch's worth of segments, one GPU (a sharded run exchanges the sums between
+        finalize and result), no prescribed step sequence.  (``_fused_first`` = False keeps the separate launches: same results.)"""
+        return (not self._custom_norm and self._chunks is None and self.process_group is None and not self._replay
+                and hasattr(self.backend, "initial_step_tail") and self._fused_first)
+
     def _select_initial_step_device(self, t0, y0, f0=None):
         """``select_initial_step`` (base_adaptive_solver.py:33-72) with its scalar arithmetic on the device: the three
         norms feed two one-thread launches (xde_initial_step) instead of two blocking reads; the first step never visits
@@ -404,6 +411,21 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
             f1 = self._eval(t_probe, y1)
             be.initial_step_fused(1, f1, f0, y0, self._xsegs, hs, self._params, float(t0h), None, self._ctrl, len(self._t_host),
                                   self._t_span_dev, self._step_t_dev, self._t_stage)
+            self._first_step_dbg = (hs[4:5], hs)
+            self._ctrl_ready = True
+            return hs[3:4]
+        if self._tail_first_step():
+            # d0 and d1 in ONE pass over (y0, f0); finalize + result + the scalars (+ the control block's construction) folded into
+            # one one-workgroup launch per phase: 12 launches -> 4; _before_integrate skips its ctrl_init
+            hs = torch.zeros(5, dtype=torch.float64, device=dev)
+            be.scaled_norm2_partial(f0, y0, self.rtol, self.atol, self._xsegs, self._norm_kind, self._ws)
+            be.initial_step_tail(0, self._ws, hs, self._params, float(t0h), t_probe, self._ctrl)
+            y1 = torch.empty_like(y0)
+            be.stage_combine(y1, y0, [f0], [1.0], _hip.COMBINE_FUSE, ctrl=self._ctrl)  # fuse(f0, h0, y0)
+            f1 = self._eval(t_probe, y1)
+            be.scaled_norm_partial(f1, f0, y0, float(self.rtol), float(self.atol), self._xsegs, self._norm_kind, self._ws, 0)
+            be.initial_step_tail(1, self._ws, hs, self._params, float(t0h), None, self._ctrl, len(self._t_host), self._t_span_dev,
+                                 self._step_t_dev, self._t_stage)
             self._first_step_dbg = (hs[4:5], hs)
             self._ctrl_ready = True
             return hs[3:4]

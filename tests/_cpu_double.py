@@ -332,6 +332,35 @@ class NumpyDoubleBackend:
             hs[4] = res[0]
             self.ctrl_init(ctrl, params, t_start, 0.0, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=hs[3:4])
 
+    def scaled_norm2_partial(self, f0, y0, rtol, atol, segs, norm_kind, ws):
+        """Contract of xde_scaled_norm2_partial: the two separate passes, slot 0 <- norm(y0/scale), slot 1 <- norm(f0/scale)."""
+        self.scaled_norm_partial(y0, None, y0, rtol, atol, segs, norm_kind, ws, 0)
+        self.scaled_norm_partial(f0, None, y0, rtol, atol, segs, norm_kind, ws, 1)
+        self.launches.pop()  # (one launch)
+
+    def initial_step_tail(self, phase, ws, hs, params, t_start, t_probe, ctrl, n_out=0, t_span_dev=None, step_t_dev=None, t_stage=None,
+                          keep_seq=False):
+        """Contract of xde_initial_step_tail: finalize + result (+ the scalar phase, + ctrl_init), composed."""
+        import torch
+
+        if t_start != t_start:  # NaN: the start time is the first output time
+            t_start = float(t_span_dev.numpy()[0])
+        sums = self.new_sums(None)
+        counts = [params.seg_count[i] for i in range(params.n_seg)]
+        res = torch.zeros(2, dtype=torch.float64)
+        n0 = len(self.launches)
+        for slot in ((0, 1) if phase == 0 else (0,)):
+            self.norm_finalize(ws, slot, sums)
+            self.norm_result(sums, counts, params.norm_kind, params.state_dtype, res[slot : slot + 1])
+        del self.launches[n0:]
+        self.launches.append("initial_step_tail")
+        if phase == 0:
+            self.initial_step(0, res, hs, params, t_start, t_probe, ctrl)
+        else:
+            self.initial_step(1, res, hs, params, t_start, None, ctrl)
+            hs[4] = res[0]
+            self.ctrl_init(ctrl, params, t_start, 0.0, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=hs[3:4])
+
     def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None, keep_seq=False):
         c = self._c(ctrl)
         seq = c.seq

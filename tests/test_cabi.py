@@ -113,6 +113,8 @@ def test_every_entry_point_rejects_null_arguments():
         "xde_initial_step": lambda: lib.xde_initial_step(0, None, None, C.byref(P), 0.0, None, 0, None, None),
         "xde_initial_step_fused": lambda: lib.xde_initial_step_fused(0, None, None, None, C.byref(S), 0, None, C.byref(P), 0.0, None, 0, None, 2, None,
                                                                     None, None, 0, None),
+        "xde_scaled_norm2_partial": lambda: lib.xde_scaled_norm2_partial(None, None, 1e-3, 1e-6, C.byref(S), 0, 0, None, None),
+        "xde_initial_step_tail": lambda: lib.xde_initial_step_tail(0, None, None, C.byref(P), 0.0, None, 0, None, 2, None, None, None, 0, None),
         "xde_ctrl_read": lambda: lib.xde_ctrl_read(None, None, None),
         "xde_host_alloc": lambda: lib.xde_host_alloc(0, None),
         "xde_ctrl_wait": lambda: lib.xde_ctrl_wait(None, 0, 1.0, None),

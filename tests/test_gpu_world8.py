@@ -1,0 +1,36 @@
+"""World 8 on one card before hardware does it on eight: eight ranks as threads of ONE child process — the GPU
+pool allows at most 6 processes on a card, so bench.py's one-card rehearsal (one process per rank) stops at 6 — with real mailboxes,
+seven peers per rank, the real kernels, and BASELINE configs[3]'s exact shape: 8 x (65536 x 64).  See tests/_world8_child.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _child(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_world8_child.py"), *args], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT)
+    assert r.returncode == 0, "exit code {}\n--- stdout\n{}\n--- stderr\n{}".format(r.returncode, r.stdout[-3000:], r.stderr[-6000:])
+    return r.stdout.strip().splitlines()[-1]
+
+
+def test_world8_exchange_known_vectors():
+    """xde_p2p_exchange with world = 8: 8 mailbox rows, 7 peers per rank, 100 rounds (sum, and max-and-sum) of known vectors, every
+    rank's result exact."""
+    assert _child("exchange").startswith("OK exchange world=8")
+
+
+@pytest.mark.parametrize("pipeline", ["sync", "lag"])
+def test_world8_config4_sharded_vs_golden(pipeline):
+    """Config 4 as north_star shards it — 524288 x 64 over 8 ranks of 65536 rows — through xde_p2p_rk_control: eight controllers in
+    lock-step bit for bit, the fixture's global accept / reject sequence and counts, sampled rows at 1e-5 max|ref| (the bar of
+    test_config4_sharded_two_ranks_on_one_gpu_vs_golden)."""
+    line = json.loads(_child("solve", pipeline))
+    assert line["ok"] and line["world"] == 8 and line["rows_per_rank"] == 65536 and line["dim"] == 64
+    assert line["worst_abs_err_rows"] <= line["bar"]

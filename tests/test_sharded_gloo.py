@@ -64,9 +64,11 @@ def _worker(rank, world, port, out_dir, norm_name, pipeline, device="cpu"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("norm_name,pipeline,world", [("rms", "sync", 2), ("rms", "lag", 2), ("linf", "sync", 2), ("rms", "lag", 3)])
+@pytest.mark.parametrize("norm_name,pipeline,world", [("rms", "sync", 2), ("rms", "lag", 2), ("linf", "sync", 2), ("rms", "lag", 3),
+                                                      ("rms", "sync", 8), ("rms", "lag", 8), ("linf", "lag", 8)])
 def test_two_rank_sharded_equals_unsharded(tmp_path, cpu_double, norm_name, pipeline, world):
-    """world 3 splits the 64 rows 21 / 21 / 22: uneven shards (the global element count is itself all-reduced)."""
+    """world 3 splits the 64 rows 21 / 21 / 22: uneven shards (the global element count is itself all-reduced).  world 8 (64 rows ->
+    8 x 8) is north_star's geometry — "the 8 GPUs of one node" — executed before hardware does."""
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), norm_name, pipeline), nprocs=world, join=True)
     rs = [np.load(tmp_path / "rank{}.npz".format(r)) for r in range(world)]
@@ -179,7 +181,7 @@ def _adjoint_worker(rank, world, port, out_dir, norm, t_grad):
 
 
 @pytest.mark.parametrize("norm,t_grad,world", [("seminorm", False, 2), ("default", False, 2), ("default", True, 2), ("seminorm", True, 2),
-                                              ("default", False, 3)])
+                                              ("default", False, 3), ("seminorm", False, 8), ("default", False, 8), ("default", True, 8)])
 def test_sharded_adjoint_equals_unsharded(tmp_path, cpu_double, norm, t_grad, world):
     """Forward AND adjoint backward batch-sharded over the ranks, under the default adjoint norm (odeint_adjoint.py:284-287: it
     looks at every parameter adjoint, which is a sum over ALL rows) and under "seminorm": every rank takes the unsharded run's
@@ -382,7 +384,9 @@ def _p2p_worker(rank, world, port, out_dir, norm_name, pipeline):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("norm_name,pipeline,world", [("rms", "sync", 2), ("rms", "lag", 2), ("linf", "lag", 2), ("rms", "graph", 2),
-                                                      ("rms", "graph", 3), ("rms", "lag", 4)])  # (three / four ranks: one pipeline each — a rank costs ~7 s of start-up)
+                                                      ("rms", "graph", 3), ("rms", "lag", 3), ("rms", "lag", 4), ("rms", "graph", 4)])
+# (every pipeline that goes through xde_p2p_control_kernel's publish wave meets MORE THAN ONE peer — lag and graph at three
+#  and at four ranks; a rank costs ~7 s of start-up.  Four ranks + the test process = 5 processes on the card: the pool allows 6)
 def test_peer_exchange_two_ranks_on_one_gpu(tmp_path, norm_name, pipeline, world):
     """The IPC-mapped mailboxes carry the per-attempt norm sums instead of an all-reduce: both ranks stay in lock-step and the
     run is BIT-identical to the all-reduce run (two summands: the rank-ordered sum is the all-reduce's sum; with four ranks
