@@ -291,11 +291,11 @@ extern bool g_prof_on;
 extern int g_prof_period;
 extern int64_t g_prof_launches[XDE_KID_COUNT];
 extern std::vector<ProfRec> g_prof_recs;
-extern std::vector<hipEvent_t> g_event_pool;
 extern double g_prof_bytes[XDE_KID_COUNT];
 extern int64_t g_prof_counts[XDE_KID_COUNT];
 extern double g_prof_ms[XDE_KID_COUNT];
-hipEvent_t get_event();
+hipEvent_t get_event();          // an idle event of the CURRENT device's pool (created when the pool is empty); g_prof_mu held
+void put_event(hipEvent_t e);    // back to the pool of the device it was created on; g_prof_mu held
 
 // When profiling is on, the start/stop events are handed to hipExtLaunchKernelGGL, which stamps them with
 // the kernel dispatch's own begin/end timestamps (no extra marker packets on the stream).

@@ -447,11 +447,8 @@ int xde_error_norm_control(const void* const* k, const void* k0_alt, const doubl
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_ERRNORM, bytes);
   {
-    // small state: one workgroup does everything (XDE_SINGLE_ELEMS elements or fewer; 0 switches the path off)
-    static const int64_t single_max = [] {
-      const char* e = getenv("XDE_SINGLE_ELEMS");
-      return (e && *e) ? atoll(e) : int64_t(1) << 16;
-    }();
+    // small state: one workgroup does everything (65536 elements or fewer: configs 3 and 5, launch-latency-bound)
+    constexpr int64_t single_max = int64_t(1) << 16;
     int64_t total = 0;
     for (int s2 = 0; s2 < segs->n_seg; ++s2) total += segs->seg_len[s2];
     if (total <= single_max) {
@@ -697,8 +694,14 @@ int xde_ctrl_wait(const xde_ctrl_t* host_mirror, int64_t seq, double timeout_ms,
     if (cur == seq) {
       if (!checksummed) break;
       // the block's words arrive in no particular order: the copy counts only if it is one whole block (else: words still landing)
-      memcpy(host_out, slot, sizeof(xde_ctrl_t));
-      if (host_out->seq == seq && ctrl_copy_holds(*host_out)) return XDE_OK;
+      // (into a local block first: the caller's host_out is written only with a copy that holds — after a timeout or a refusal it
+      //  still has what the caller left in it, include/xde_hip.h: "such a copy is never handed back")
+      xde_ctrl_t cand;
+      memcpy(&cand, slot, sizeof(xde_ctrl_t));
+      if (cand.seq == seq && ctrl_copy_holds(cand)) {
+        memcpy(host_out, &cand, sizeof(xde_ctrl_t));
+        return XDE_OK;
+      }
     } else if (cur > seq && (!checksummed || cur - seq >= XDE_MIRROR_SLOTS)) {
       // (checksummed: a sequence number ahead of ours can only be a LATER launch's word in this slot, i.e. seq + k * SLOTS)
       return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot already overwritten by a later launch");
@@ -717,10 +720,12 @@ int xde_ctrl_wait(const xde_ctrl_t* host_mirror, int64_t seq, double timeout_ms,
     __builtin_ia32_pause();
 #endif
   }
-  memcpy(host_out, slot, sizeof(xde_ctrl_t));
+  xde_ctrl_t cand;
+  memcpy(&cand, slot, sizeof(xde_ctrl_t));
   // the slot may have been overwritten while copying (only if the host lags >= SLOTS launches behind)
   if (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != seq)
     return fail(XDE_EBADARG, "xde_ctrl_wait: mirror slot overwritten while reading");
+  memcpy(host_out, &cand, sizeof(xde_ctrl_t));
   return XDE_OK;
 }
 

@@ -316,7 +316,7 @@ inline void lag_plane_shape(int64_t outer, int plane, int DV, int* R_out, int* n
   if (R < 1) R = 1;
   if (int64_t(R) > outer) R = int(outer > 0 ? outer : 1);
   const int64_t passes = (outer + R - 1) / R;  // one pass per workgroup at most ...
-  static const int cap = env_int("XDE_LAG_GRID", 512);  // ... and 512 workgroups (256 / 384 / 512 / 768: 14.7 / 13.5 / 12.2 / 13.5 us at the D3STN size, profiles/r05_combine_ab.txt)
+  constexpr int cap = 512;  // ... and 512 workgroups (256 / 384 / 512 / 768: 14.7 / 13.5 / 12.2 / 13.5 us at the D3STN size, profiles/r05_combine_ab.txt)
   int64_t nb = passes < cap ? passes : cap;
   if (nb > kLagMaxBlocksPerLag) nb = kLagMaxBlocksPerLag;
   if (nb < 1) nb = 1;

@@ -12,6 +12,9 @@
 //
 // Library state: last error, launch-sampling records, ABI housekeeping.
 
+#include <map>
+#include <unordered_map>
+
 #include "xde_common.hpp"
 
 namespace xde {
@@ -29,20 +32,45 @@ bool g_prof_on = false;
 int g_prof_period = 1;
 int64_t g_prof_launches[XDE_KID_COUNT] = {0};
 std::vector<ProfRec> g_prof_recs;
-std::vector<hipEvent_t> g_event_pool;
+// Idle events, per DEVICE: an event is bound to the device that was current when it was created, and recording it on another
+// device's stream fails — a process that times launches on more than one device (the binding allows it) must never be handed a
+// foreign one.  `g_event_home` remembers where each event was created.
+static std::map<int, std::vector<hipEvent_t>> g_event_pools;
+static std::unordered_map<hipEvent_t, int> g_event_home;
 double g_prof_bytes[XDE_KID_COUNT] = {0};
 int64_t g_prof_counts[XDE_KID_COUNT] = {0};
 double g_prof_ms[XDE_KID_COUNT] = {0};
 
+static int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;  // (no device: events cannot be created either)
+  }
+  return dev;
+}
+
 hipEvent_t get_event() {
-  if (!g_event_pool.empty()) {
-    hipEvent_t e = g_event_pool.back();
-    g_event_pool.pop_back();
+  const int dev = current_device();
+  auto& pool = g_event_pools[dev];
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
     return e;
   }
-  hipEvent_t e;
-  (void)hipEventCreate(&e);
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  g_event_home[e] = dev;
   return e;
+}
+
+void put_event(hipEvent_t e) {
+  if (!e) return;
+  auto it = g_event_home.find(e);
+  g_event_pools[it == g_event_home.end() ? -1 : it->second].push_back(e);
 }
 
 
@@ -142,21 +170,26 @@ int xde_prof_enable(int on) {
       g_prof_ms[i] = 0;
     }
     for (auto& r : g_prof_recs) {
-      g_event_pool.push_back(r.start);
-      g_event_pool.push_back(r.stop);
+      put_event(r.start);
+      put_event(r.stop);
     }
     g_prof_recs.clear();
     // The events sampled launches will be stamped with exist BEFORE the first of them is taken: hipEventCreate costs 1-2 us, and created
     // on demand the first timed block of a benchmark paid for ~100 of them (bench.py's first 20-step block read 7 us per step longer
     // than the two blocks after it).  On a box without a device nothing can be created: the pool stays empty and launches fail anyway.
+    // (the pool warmed is the CURRENT device's: the one whose launches the caller is about to time; another device's pool fills on
+    // demand)
     constexpr size_t kWarmEvents = 512;
-    while (g_event_pool.size() < kWarmEvents) {
+    const int dev = current_device();
+    auto& pool = g_event_pools[dev];
+    while (dev >= 0 && pool.size() < kWarmEvents) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) {
         (void)hipGetLastError();
         break;
       }
-      g_event_pool.push_back(e);
+      g_event_home[e] = dev;
+      pool.push_back(e);
     }
   }
   return XDE_OK;
@@ -176,8 +209,8 @@ int xde_prof_collect(int64_t* counts_out, double* ms_out, double* bytes_out) {
     } else {
       (void)hipGetLastError();
     }
-    g_event_pool.push_back(r.start);
-    g_event_pool.push_back(r.stop);
+    put_event(r.start);
+    put_event(r.stop);
   }
   g_prof_recs.clear();
   for (int i = 0; i < XDE_KID_COUNT; ++i) {

@@ -2,7 +2,6 @@
 a replayed hipGraph per time-argument signature, cached on the module (or on the vjp hook's owner), and the re-armable interval
 solvers built on it.  Everything here runs in the CALLER of the autograd node — main thread, outside the node (see
 ``_captured_dynamics``)."""
-import os
 import threading
 import weakref
 
@@ -80,8 +79,6 @@ class _IntervalSolver:
 def _interval_key(solver, rtol, atol, options, direction, t_dtype=None):
     """Cache key of the captured interval solve for these solver options, or None when they rule it out."""
     if not isinstance(solver, type):
-        return None
-    if os.environ.get("XDE_INTERVAL_GRAPH", "1") == "0":
         return None
     fixed = _is_fixed(solver)
     items = []

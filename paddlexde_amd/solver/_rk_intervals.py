@@ -7,7 +7,7 @@ state lives in a static buffer (``state``), the two output times are uploaded in
 the control block on the device (xde_initial_step_fused with t_start = NaN and seq0 < 0), runs the heuristic's two evaluations and
 the first attempt, writes the output row and hands the state over (xde_dense_commit).  A second graph holds one more attempt for the
 intervals that need it.  Same kernels, same operands, same order as the eager solve: bit-identical results
-(tests/_e2e_cases.py::test_adjoint_captured_interval_solves).
+(tests/_adjoint_cases.py::test_adjoint_captured_interval_solves).
 """
 import numpy as np
 import torch

@@ -21,7 +21,6 @@ interval solves odeint_adjoint's backward runs on are ``_rk_intervals.py``.
 """
 import bisect
 import collections
-import os
 
 import numpy as np
 import torch
@@ -53,6 +52,7 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
     order: int
     tableau: _ButcherTableau
     mid: list
+    SINGLE_MAX_ELEMS = 1 << 16  # largest state (elements) served by the one-workgroup norm + controller / initial-step kernels
 
     def __init__(
         self,
@@ -144,7 +144,7 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         # odeint_adjoint's backward runs one solve per output interval, most of them a single attempted step long: the speculative
         # pipeline then waits for the verdict of a solve's FIRST attempt (whose step size the host never saw) before it enqueues a
         # second one, instead of discarding a whole attempt per interval
-        self._short_solves = bool(_short_solves) and os.environ.get("XDE_SHORT_SOLVES", "1") != "0"  # (0: for measuring it)
+        self._short_solves = bool(_short_solves)
         # options["stats_out"] = {}: a dict of the caller's that receives the solve's counters (attempts, accepted, rejected, func
         # evaluations, final time and step) when it ends — `odeint()` returns the solution only, as the reference's does
         self._stats_out = stats_out
@@ -175,9 +175,9 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
             self.pipeline = pipeline = "sync"
         # SMALL states (configs 3 and 5: launch-latency-bound): xde_error_norm_control runs as ONE workgroup that walks the segments
         # and goes straight on to the controller — no partial records, no tickets, one launch and one hipGraph node less per
-        # attempt.  XDE_SINGLE_ELEMS = largest state (elements) served that way; 0 = off.  (At large sizes one ticketed launch for
+        # attempt.  SINGLE_MAX_ELEMS = largest state (elements) served that way.  (At large sizes one ticketed launch for
         # norm + controller was measured no faster than two — 36.4 us vs 23.1 + 12 us on config 2 — and is not offered.)
-        self._single_max = int(os.environ.get("XDE_SINGLE_ELEMS", str(1 << 16)))
+        self._single_max = self.SINGLE_MAX_ELEMS
 
         self.backend = _hip.get_backend()
         self.nfe = 0  # calls func has received
@@ -300,7 +300,7 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         # constructed — on the device when the heuristic chose the step): a copy of the block is enqueued here, behind the
         # heuristic's kernels and ahead of the first attempt's, and read when the second attempt is about to be enqueued
         self._init_peek = None
-        if (hasattr(be, "ctrl_peek_async") and os.environ.get("XDE_SHORT_SOLVES", "1") != "0"
+        if (hasattr(be, "ctrl_peek_async")
                 and (self.pipeline == "lag" or (self.pipeline == "auto" and self._auto.pick() == "lag"))):
             self._init_peek = be.ctrl_peek_async(self._ctrl)
 

@@ -20,7 +20,7 @@ own tensors (`adapt_vjp` below), and `functional.AdjointProblem` is the framewor
 caller's framework wraps (INTEGRATION.md section B shows the 10-line `paddle.autograd.grad` hook and the PyLayer around it).
 Paddle itself is not installed in the build image; the adapters are exercised with a protocol-level stand-in (a class that exposes
 nothing but `__dlpack__` / `__dlpack_device__` / `shape` / `dtype`): tests/test_gpu_kernels.py::test_foreign_tensors_through_dlpack,
-tests/_e2e_cases.py::test_adjoint_vjp_hook_on_foreign_tensors_reproduces_config3_gradients.
+tests/_adjoint_cases.py::test_adjoint_vjp_hook_on_foreign_tensors_reproduces_config3_gradients.
 
 Stream contract (both adapters): the caller's framework must enqueue its kernels on the stream this package runs on (torch's current
 stream: share it, or make the framework's current stream that one) — DLPack's `stream` argument orders the hand-over of each tensor,

@@ -326,8 +326,7 @@ def test_fused_initial_step_equals_the_separate_launches_and_the_oracle(dev, dty
                    norm=_rms_norm if norm_name == "rms" else _linf_norm, dtype=tdt, step_t=torch.tensor([direction * 0.2500001, direction * 2.0]))
         s.y0 = y0d
         s._before_integrate(tsp)
-        if not s._small_state:
-            pytest.skip("XDE_SINGLE_ELEMS=0: the one-workgroup device path of the heuristic is switched off")
+        assert s._small_state
         assert s._fused_first_step() == fused and s._ctrl_ready == fused
         res, hs = s._first_step_dbg
         return s, float(res.cpu().numpy()[0]), hs.cpu().numpy()[:4].copy(), be.ctrl_read(s._ctrl), s._t_stage.cpu().numpy().copy()
@@ -352,3 +351,67 @@ def test_fused_initial_step_equals_the_separate_launches_and_the_oracle(dev, dty
     so = O.AdaptiveRKSolver(f_or, y0, rtol, atol, method="dopri5", norm=O._rms_norm if norm_name == "rms" else O._linf_norm, dtype=dtype)
     first_ref = so.select_initial_step(so.tt(0.25), y0, so.order - 1, so.rtol, so.atol)
     assert hf[3] == pytest.approx(float(first_ref), rel=1e-4 if dtype == np.float32 else 1e-9)
+
+
+@pytest.mark.parametrize("direction", [1, -1])
+@pytest.mark.parametrize("norm_name", ["rms", "linf"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_large_state_initial_step_in_four_launches_equals_the_twelve(dev, dtype, norm_name, direction):
+    """VERDICT r05 (next 5): states above the one-workgroup kernels' reach paid 12 launches for select_initial_step
+    (solver/base_adaptive_solver.py:33-72): 3 x (xde_scaled_norm_partial + xde_norm_finalize + xde_norm_result) + 2 x xde_initial_step +
+    xde_ctrl_init.  Now 4: d0 and d1 in ONE pass over (y0, f0) (xde_scaled_norm2_partial — SURVEY A6's "two norms in one pass"), and
+    everything that followed a norm pass as ONE one-workgroup launch per phase (xde_initial_step_tail).  Same grid, same per-lane order,
+    same fixed-order reduction, same scalar code: d0, d1, h0, the third norm, the first step, the constructed control block and the
+    stage times are BIT-identical to the twelve launches' — and so to what test_initial_step_vs_oracle_select_initial_step holds to
+    the oracle.  (2^17 + 3) x 2 elements: not a multiple of the vector width, several workgroups."""
+    from paddlexde_amd import Dopri5 as Solver
+    from paddlexde_amd.utils import _linf_norm, _rms_norm
+    from paddlexde_amd.xde import BaseODE
+
+    be = _hip.get_backend()
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.RandomState(6)
+    y0 = rng.uniform(-2, 2, size=((1 << 17) + 3, 2)).astype(dtype)
+    f_t = P.vdp_torch(3.0)
+    y0d = torch.from_numpy(y0).to(dev)
+    t_span = np.asarray([direction * 0.25, direction * 1.0, direction * 5.0])
+    tsp = t_span.astype(np.float32 if dtype == np.float32 else np.float64)
+    heuristic = ("scaled_norm_partial", "scaled_norm2_partial", "norm_finalize", "norm_result", "initial_step", "initial_step_tail", "ctrl_init")
+
+    def run(folded):
+        counts, depth = {}, [0]
+        s = Solver(xde=BaseODE(f_t, y0=y0d, t_span=torch.from_numpy(t_span)), y0=y0d, rtol=1e-5, atol=1e-7, _fused_first_step=folded,
+                   norm=_rms_norm if norm_name == "rms" else _linf_norm, dtype=tdt, step_t=torch.tensor([direction * 0.2500001, direction * 2.0]))
+        s.y0 = y0d
+        originals = {name: getattr(be, name) for name in heuristic}
+        try:
+            for name, fn in originals.items():
+                def counted(*a, _fn=fn, _name=name, **k):
+                    if not depth[0]:  # (the CPU double composes its folded calls from the separate ones: the solver's own calls count)
+                        counts[_name] = counts.get(_name, 0) + 1
+                    depth[0] += 1
+                    try:
+                        return _fn(*a, **k)
+                    finally:
+                        depth[0] -= 1
+
+                setattr(be, name, counted)
+            s._before_integrate(tsp)
+        finally:
+            for name in heuristic:
+                delattr(be, name)  # (the instance attributes set above: the class's methods show through again)
+        assert not s._small_state and s._tail_first_step() == folded and s._ctrl_ready == folded
+        res, hs = s._first_step_dbg
+        return s, counts, float(res.cpu().numpy()[0]), hs.cpu().numpy()[:4].copy(), be.ctrl_read(s._ctrl), s._t_stage.cpu().numpy().copy()
+
+    sf, nf, n3f, hf, cf, tf = run(True)
+    su, nu, n3u, hu, cu, tu = run(False)
+    assert nf == {"scaled_norm2_partial": 1, "scaled_norm_partial": 1, "initial_step_tail": 2}, nf  # 4 launches
+    assert nu == {"scaled_norm_partial": 3, "norm_finalize": 3, "norm_result": 3, "initial_step": 2, "ctrl_init": 1}, nu  # 12
+    assert sf.nfe == su.nfe == 3  # f0, f0 again (as the reference counts it), f1
+    assert np.array_equal(hf, hu) and n3f == n3u, (hf, hu, n3f, n3u)  # d0, d1, h0, first step; the third norm: bit for bit
+    for name in ("t0", "t1", "dt", "t_plan", "n_out", "next_out", "out_begin", "out_end", "done", "next_step_index", "on_step_t", "n_steps",
+                 "accept", "status", "dt_last", "ratio", "n_accept", "n_reject", "steps_in_interval"):
+        assert getattr(cf, name) == getattr(cu, name), name
+    assert cf.next_out == 1 and cf.dt * direction > 0
+    assert np.array_equal(tf[:6], tu[:6])

@@ -22,7 +22,7 @@ from paddlexde_amd.utils import _rms_norm
 from paddlexde_amd.xde import BaseODE
 
 from . import problems as P
-from ._e2e_cases import ODEFunc, _mlp_numpy
+from ._e2e_common import ODEFunc, _mlp_numpy
 
 
 def _oracle_run(f_np, y0, t, *, rtol, atol, options=None):

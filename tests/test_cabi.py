@@ -192,6 +192,7 @@ def test_a_stale_params_mirror_gets_ebadarg_not_a_read_past_its_end(stale):
         "xde_rk_control": lambda: lib.xde_rk_control(dummy, ref, dummy, None, dummy, None, dummy, None, None),
         "xde_ctrl_retarget": lambda: lib.xde_ctrl_retarget(dummy, ref, dummy, 1, None, None),
         "xde_initial_step": lambda: lib.xde_initial_step(1, dummy, dummy, ref, 0.0, None, 0, dummy, None),
+        "xde_initial_step_tail": lambda: lib.xde_initial_step_tail(1, dummy, dummy, ref, 0.0, None, 0, dummy, 2, dummy, None, dummy, 0, None),
         "xde_error_norm_control": lambda: lib.xde_error_norm_control(kk, None, ce, 1, dummy, None, dummy, C.byref(S), 0, dummy, None, dummy,
                                                                     ref, dummy, None, dummy, None, None),
     }
@@ -278,6 +279,8 @@ def test_host_halves_run_up_to_the_launch_without_a_gpu():
         "error_norm_control": lambda: lib.xde_error_norm_control(ks, None, coef, 1, dev(2), None, dev(8), C.byref(segs), 0, dev(9), dev(6), dev(5), C.byref(P),
                                                                 dev(20), None, dev(21), None, None),
         "scaled_norm_partial": lambda: lib.xde_scaled_norm_partial(dev(1), dev(2), dev(3), 1e-5, 1e-7, C.byref(segs), 0, 0, dev(9), 1, None),
+        "scaled_norm2_partial": lambda: lib.xde_scaled_norm2_partial(dev(1), dev(2), 1e-5, 1e-7, C.byref(segs), 0, 0, dev(9), None),
+        "initial_step_tail": lambda: lib.xde_initial_step_tail(1, dev(9), dev(23), C.byref(P), 0.0, None, 0, dev(5), 2, dev(20), None, dev(21), 0, None),
         "norm_finalize": lambda: lib.xde_norm_finalize(dev(9), 0, dev(22), None),
         "rk_control": lambda: lib.xde_rk_control(dev(5), C.byref(P), dev(9), None, dev(20), None, dev(21), None, None),
         "ctrl_init": lambda: lib.xde_ctrl_init(dev(5), C.byref(P), 0.0, 0.1, 2, dev(20), None, dev(21), 0, None, None),
@@ -347,6 +350,8 @@ def test_host_mirror_accepts_only_whole_blocks(monkeypatch):
     torn.dt = old.dt
     ring[slot] = torn
     assert lib.xde_ctrl_wait(ring, seq, 30.0, C.byref(out)) == _hip.XDE_ETIMEOUT
+    # (a rejected candidate never reaches the caller's buffer — it still holds the block of the last successful wait)
+    assert bytes(out) == bytes(new)
     # ... and so is a slot whose sequence number has landed while the rest is still the old block
     torn = _hip.XdeCtrl.from_buffer_copy(bytes(old))
     torn.seq = seq
@@ -358,3 +363,4 @@ def test_host_mirror_accepts_only_whole_blocks(monkeypatch):
     later.chk = _ctrl_checksum(later)
     ring[slot] = later
     assert lib.xde_ctrl_wait(ring, seq, 30.0, C.byref(out)) == _hip.XDE_EBADARG and b"overwritten" in lib.xde_last_error()
+    assert bytes(out) == bytes(new)

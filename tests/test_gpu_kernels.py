@@ -13,7 +13,7 @@ import os
 
 from ._cpu_double import NumpyDoubleBackend
 
-SINGLE_MAX = int(os.environ.get("XDE_SINGLE_ELEMS", str(1 << 16)))  # largest state served by the one-workgroup norm + control
+SINGLE_MAX = 1 << 16  # largest state served by the one-workgroup norm + control (AdaptiveRKSolver.SINGLE_MAX_ELEMS)
 
 pytestmark = pytest.mark.gpu
 
@@ -445,6 +445,67 @@ def test_initial_step_fused_over_many_segments(be, dbl, dtype, norm):
             np.testing.assert_allclose(hg[[0, 1, 4]], hr[[0, 1, 4]], rtol=tol, atol=0, equal_nan=True, err_msg=str((li, aligned)))
             np.testing.assert_allclose(hg[3], hr[3], rtol=10 * tol, atol=0, equal_nan=True, err_msg=str((li, aligned)))
             np.testing.assert_allclose(fg, fr, rtol=10 * tol, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("norm", ["rms", "linf"])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_two_norms_in_one_pass_write_the_two_separate_passes_records(be, dtype, norm):
+    """xde_scaled_norm2_partial: norm(y0/scale) and norm(f0/scale) of the initial-step heuristic (solver/base_adaptive_solver.py:50-53) in
+    ONE pass over (y0, f0).  Its two slots of block-partial records must be — byte for byte — what two xde_scaled_norm_partial launches
+    (a = y0 -> slot 0, a = f0 -> slot 1) write: same grid, same per-lane order, same fp64 flush period.  Tuple layouts, aligned and
+    unaligned (the scalar path), a NaN, a non-finite y0 element; then xde_initial_step_tail on those slots against finalize + result +
+    the scalar launch."""
+    dev = torch.device("cuda:0")
+    dt = DT[dtype]
+    w = 4 if dtype == "f32" else 2
+    rng = np.random.RandomState(12)
+    nk = _hip.NORM_RMS if norm == "rms" else _hip.NORM_LINF
+    layouts = [[(1 << 20) + 3], [1, 16384, 70001, 100, 2], [5, 7, 9, 4099, 2, 1, 64, 63, 65, 1024, 3, 8191, 6, 2, 1, 400000], [3]]
+    for li, lens in enumerate(layouts):
+        for aligned in (True, False):
+            segs, pos = [], 0
+            for n in lens:
+                segs.append((pos, n))
+                pos += ((n + w - 1) // w * w) if aligned else n
+            y0 = torch.from_numpy(rng.uniform(-2, 2, pos)).to(dt)
+            f0 = torch.from_numpy(rng.uniform(-3, 3, pos)).to(dt)
+            if li == 1:
+                f0[segs[2][0] + 5] = float("nan")
+                y0[segs[1][0] + 9] = float("inf")
+            y0, f0 = y0.to(dev), f0.to(dev)
+            xs = _hip.make_segments(segs)
+            ws_a, ws_b = be.new_workspace(dev), be.new_workspace(dev)
+            be.scaled_norm_partial(y0, None, y0, 1e-3, 1e-5, xs, nk, ws_a, 0)
+            be.scaled_norm_partial(f0, None, y0, 1e-3, 1e-5, xs, nk, ws_a, 1)
+            be.scaled_norm2_partial(f0, y0, 1e-3, 1e-5, xs, nk, ws_b)
+            torch.cuda.synchronize()
+            assert torch.equal(ws_a.cpu(), ws_b.cpu()), (li, aligned)
+            # the one-workgroup tail on those records == finalize + result (x2) + the scalar launch
+            p = _hip.XdeCtrlParams()
+            p.rtol, p.atol, p.min_step, p.max_step = 1e-3, 1e-5, 0.0, float("inf")
+            p.safety, p.ifactor, p.dfactor, p.order = 0.9, 10.0, 0.2, 5.0
+            p.max_num_steps = 2**31 - 1
+            p.time_dtype = p.state_dtype = _hip.dtype_code(dt)
+            p.norm_kind, p.n_stage, p.n_seg, p.direction = nk, 6, len(segs), -1
+            counts = [float(n) for _, n in segs]
+            for i, c in enumerate(counts):
+                p.seg_count[i] = c
+            ctrl_a, ctrl_b = be.new_ctrl(dev), be.new_ctrl(dev)
+            res = torch.zeros(2, dtype=torch.float64, device=dev)
+            sums = be.new_sums(dev)
+            hs_a, hs_b = torch.zeros(5, dtype=torch.float64, device=dev), torch.zeros(5, dtype=torch.float64, device=dev)
+            tp_a, tp_b = torch.zeros((), dtype=dt, device=dev), torch.zeros((), dtype=dt, device=dev)
+            for slot in (0, 1):
+                be.norm_finalize(ws_a, slot, sums)
+                be.norm_result(sums, counts, nk, _hip.dtype_code(dt), res[slot : slot + 1])
+            be.initial_step(0, res, hs_a, p, 0.25, tp_a, ctrl_a)
+            be.initial_step_tail(0, ws_b, hs_b, p, 0.25, tp_b, ctrl_b)
+            torch.cuda.synchronize()
+            ha, hb = hs_a.cpu().numpy(), hs_b.cpu().numpy()
+            assert np.array_equal(ha[:3], hb[:3], equal_nan=True), (li, aligned, ha, hb)
+            assert np.array_equal(tp_a.cpu().numpy(), tp_b.cpu().numpy(), equal_nan=True)
+            da, db = be.ctrl_read(ctrl_a).dt, be.ctrl_read(ctrl_b).dt
+            assert da == db or (da != da and db != db)
 
 
 def test_stage_combine_and_error_norm_beyond_2_31_elements(be):
