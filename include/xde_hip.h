@@ -355,6 +355,9 @@ int xde_initial_step_fused(int phase, const void* a, const void* b, const void* 
  *              ctrl->dt = direction*h0, *t_probe_out = t_start + direction*h0);
  *     phase 1: the same for slot 0 (filled by xde_scaled_norm_partial(a = f1, b = f0, slot 0)), phase 1 of xde_initial_step
  *              (hs_dev[3] = the first step, hs_dev[4] = that norm) and xde_ctrl_init(first_step_dev = hs_dev + 3).
+ *   host_mirror (phase 1, seq0 >= 0; or NULL): the constructed block is also published to slot seq0 % XDE_MIRROR_SLOTS of the host mirror
+ *   the way xde_rk_control publishes (checksummed protocol only), so that xde_ctrl_wait(host_mirror, seq0, ...) hands the host the
+ *   block — where the first attempt lands, `t_plan` — without a copy command; the caller passes a seq0 no earlier launch published.
  *   Norm kind, segment counts, dtypes come from params (one GPU, a native norm of <= XDE_MAX_SEG segments: a sharded run exchanges the
  *   sums between finalize and result and keeps the separate calls).  t_start = NaN / seq0 < 0: as xde_initial_step_fused.  hs_dev: 5 doubles.
  */
@@ -362,7 +365,7 @@ int xde_scaled_norm2_partial(const void* f0, const void* y0, double rtol, double
                              int dtype, void* ws, void* stream);
 int xde_initial_step_tail(int phase, const void* ws, double* hs_dev, const xde_ctrl_params_t* params, double t_start, void* t_probe_out,
                           int probe_dtype, xde_ctrl_t* ctrl, int32_t n_out, const double* t_span_dev, const double* step_t_dev,
-                          void* t_stage_out, int64_t seq0, void* stream);
+                          void* t_stage_out, int64_t seq0, xde_ctrl_t* host_mirror, void* stream);
 
 /* Blocking device->host copy of the control block (hipMemcpyAsync + stream synchronise). */
 int xde_ctrl_read(const xde_ctrl_t* ctrl_dev, xde_ctrl_t* host_out, void* stream);

@@ -171,7 +171,7 @@ class XdeError(RuntimeError):
 class _Work:
     """The small per-solve device buffers of an adaptive solver."""
 
-    __slots__ = ("key", "ctrl", "ws", "sums", "t_stage")
+    __slots__ = ("key", "ctrl", "ws", "sums", "t_stage", "t_views")
 
 
 # torch's C-level accessor of the current stream handle: ~0.3 us against ~4 us for torch.cuda.current_stream().cuda_stream
@@ -239,7 +239,7 @@ def load_library():
         lib.xde_scaled_norm2_partial.restype = i32
         lib.xde_scaled_norm2_partial.argtypes = [vp, vp, dbl, dbl, C.POINTER(XdeSegments), i32, i32, vp, vp]
         lib.xde_initial_step_tail.restype = i32
-        lib.xde_initial_step_tail.argtypes = [i32, vp, vp, C.POINTER(XdeCtrlParams), dbl, vp, i32, vp, C.c_int32, vp, vp, vp, i64, vp]
+        lib.xde_initial_step_tail.argtypes = [i32, vp, vp, C.POINTER(XdeCtrlParams), dbl, vp, i32, vp, C.c_int32, vp, vp, vp, i64, vp, vp]
         lib.xde_host_alloc.restype = i32
         lib.xde_host_alloc.argtypes = [i64, C.POINTER(C.c_void_p)]
         lib.xde_host_free.restype = i32
@@ -351,19 +351,23 @@ class HipBackend:
         self._work_pool = {}  # (device, state dtype, stream) -> free _Work sets
         self._lag_ws = {}  # (device, L, stream) -> workspace of xde_lag_grad (zeroed once; every launch leaves it re-armed)
         self._tls = threading.local()  # .capturing: this THREAD is recording a hipGraph (its launches do not execute)
+        # (the init block can ride the mirror only under the checksummed publish protocol, XDE_CTRL_FLAGS bit 8 — the default)
+        self._mirror_takes_init = (int(os.environ.get("XDE_CTRL_FLAGS", "15")) & 8) != 0
 
     # -- host mirror ring of the control block (see xde_rk_control / xde_ctrl_wait) -------------
     class _Mirror:
-        __slots__ = ("ptr", "seq", "seq0", "peek")
+        __slots__ = ("ptr", "seq", "seq0", "peek", "init_published")
 
         def __init__(self, ptr):
             self.ptr, self.seq, self.seq0 = ptr, 0, 0
+            self.init_published = False  # the block the solve started from is in slot seq0 of the ring (initial_step_tail)
             self.peek = None  # ctrl_peek_async's pool of idle (pinned buffer, event, device) triples
 
     def _acquire_mirror(self):
         if self._mirror_pool:
             m = self._mirror_pool.pop()
             m.seq0 = m.seq  # nothing published for the new owner yet: ctrl_read falls back to a device copy
+            m.init_published = False
             return m
         ptr = C.c_void_p()
         self._check(self.lib.xde_host_alloc(XDE_MIRROR_SLOTS * C.sizeof(XdeCtrl), C.byref(ptr)), "xde_host_alloc")
@@ -427,6 +431,7 @@ class HipBackend:
         w.ws = self.new_workspace(device)
         w.sums = self.new_sums(device)
         w.t_stage = torch.zeros(XDE_MAX_STAGE, dtype=state_dtype, device=device)
+        w.t_views = [w.t_stage[i] for i in range(XDE_MAX_STAGE)]  # the 0-dim stage times handed to func (made once per work set)
         return w
 
     def release_work(self, w):
@@ -572,6 +577,7 @@ class HipBackend:
         self._check(rc, "xde_initial_step_fused")
         if m is not None:
             m.seq0 = seq0
+            m.init_published = False
 
     def scaled_norm2_partial(self, f0, y0, rtol, atol, segs, norm_kind, ws):
         """Partials of norm(y0 / scale) (slot 0) and norm(f0 / scale) (slot 1) in one pass over (y0, f0)."""
@@ -584,16 +590,32 @@ class HipBackend:
                           keep_seq=False):
         """What followed a norm pass of the initial-step heuristic as launches of its own — finalize, result, the scalar phase, and in
         phase 1 the control block's construction — as ONE one-workgroup launch (states above initial_step_fused's reach).
-        ``t_start = nan`` / ``keep_seq``: as initial_step_fused."""
+        ``t_start = nan`` / ``keep_seq``: as initial_step_fused.  Phase 1 (not ``keep_seq``) also publishes the constructed block to the
+        control block's host mirror: ``ctrl_init_handle(ctrl)`` is then the handle ``ctrl_wait`` takes — where the first attempt lands,
+        without a copy command on the stream (the publication takes a sequence number of its own: the slot it lands in may still
+        hold the previous owner's last block under the old number)."""
         self._require_device(ws, hs, ctrl, t_probe, t_span_dev, t_stage)
         m = self._mirrors.get(ctrl.data_ptr()) if (phase == 1 and not keep_seq) else None
+        publish = m is not None and not self._is_capturing() and self._mirror_takes_init
+        if publish:
+            m.seq += 1
         seq0 = -1 if keep_seq else (m.seq if m is not None else 0)
         rc = self.lib.xde_initial_step_tail(int(phase), ws.data_ptr(), hs.data_ptr(), C.byref(params), float(t_start), _ptr(t_probe),
                                             dtype_code(t_probe.dtype) if t_probe is not None else XDE_F32, ctrl.data_ptr(), int(n_out),
-                                            _ptr(t_span_dev), _ptr(step_t_dev), _ptr(t_stage), seq0, self._stream(ctrl))
+                                            _ptr(t_span_dev), _ptr(step_t_dev), _ptr(t_stage), seq0, m.ptr if publish else None,
+                                            self._stream(ctrl))
         self._check(rc, "xde_initial_step_tail")
         if m is not None:
             m.seq0 = seq0
+            m.init_published = publish
+
+    def ctrl_init_handle(self, ctrl):
+        """Handle (for ``ctrl_wait``) of the freshly constructed block when the launch that constructed it published it to the host
+        mirror (initial_step_tail); else None — ``ctrl_peek_async`` enqueues a copy instead."""
+        m = self._mirrors.get(ctrl.data_ptr())
+        if m is not None and m.init_published and m.seq == m.seq0:
+            return (m, m.seq0)
+        return None
 
     def ctrl_init(self, ctrl, params, t_start, first_step, n_out, t_span_dev, step_t_dev, t_stage, first_step_dev=None, keep_seq=False):
         """``t_start = nan``: the start time is ``t_span_dev[0]``; ``keep_seq``: the block goes on counting its controller launches
@@ -607,6 +629,7 @@ class HipBackend:
         self._check(rc, "xde_ctrl_init")
         if m is not None:
             m.seq0 = seq0
+            m.init_published = False
 
     def ctrl_retarget(self, ctrl, params, t_span_dev, n_out):
         """New output list for a running solve (the device side of AdaptiveRKSolver.step(next_t))."""
@@ -686,6 +709,8 @@ class HipBackend:
         return HipBackend._Peek(host, ev, ctrl.device, pool)
 
     def ctrl_peek_result(self, handle) -> XdeCtrl:
+        if isinstance(handle, tuple):  # ctrl_init_handle: the block is in the mirror ring
+            return self.ctrl_wait(handle)
         if handle.host is None:
             raise XdeError("ctrl_peek_result: this handle has been consumed already")
         handle.ev.synchronize()

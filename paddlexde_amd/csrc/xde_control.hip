@@ -385,6 +385,8 @@ struct InitTailArgs {
   const double* step_t;
   void* t_stage_out;
   int64_t seq0;
+  xde_ctrl_t* mirror;  // phase 1: the constructed block is also published to the host mirror (slot seq0 % SLOTS), or NULL
+  int flags;
 };
 
 __global__ __launch_bounds__(kBlock) void xde_initial_step_tail_kernel(InitTailArgs g, xde_ctrl_params_t p, xde_ctrl_t* c) {
@@ -399,20 +401,26 @@ __global__ __launch_bounds__(kBlock) void xde_initial_step_tail_kernel(InitTailA
   const bool diff = g.phase == 1;
   reduce_partials(g.slot_a, seg_val[0], seg_nf[0]);
   if (!diff) reduce_partials(g.slot_b, seg_val[1], seg_nf[1]);
-  if (threadIdx.x != 0) return;
-  double res[2];
-  res[0] = norm_from_sums(seg_val[0], p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, nullptr);
-  res[1] = diff ? 0.0 : norm_from_sums(seg_val[1], p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, nullptr);
-  // t_start = NaN: the start time is t_span_dev[0] (a launch recorded in a graph serves every interval it is replayed for)
-  const double t_start = (g.t_start != g.t_start && g.t_span) ? g.t_span[0] : g.t_start;
-  if (p.state_dtype == XDE_F32)
-    initial_step_phase<float>(g.phase, res, g.hs, p, t_start, g.t_probe_out, g.probe_dtype, c);
-  else
-    initial_step_phase<double>(g.phase, res, g.hs, p, t_start, g.t_probe_out, g.probe_dtype, c);
-  if (diff) {
-    g.hs[4] = res[0];  // (the third norm, for the parity tests)
-    ctrl_init_body(c, p, t_start, double(p.direction) * fabs(g.hs[3]), g.n_out, g.t_span, g.step_t, g.t_stage_out, g.seq0, z);
+  if (threadIdx.x == 0) {
+    double res[2];
+    res[0] = norm_from_sums(seg_val[0], p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, nullptr);
+    res[1] = diff ? 0.0 : norm_from_sums(seg_val[1], p.seg_count, p.n_seg, p.norm_kind, p.state_dtype, nullptr);
+    // t_start = NaN: the start time is t_span_dev[0] (a launch recorded in a graph serves every interval it is replayed for)
+    const double t_start = (g.t_start != g.t_start && g.t_span) ? g.t_span[0] : g.t_start;
+    if (p.state_dtype == XDE_F32)
+      initial_step_phase<float>(g.phase, res, g.hs, p, t_start, g.t_probe_out, g.probe_dtype, c);
+    else
+      initial_step_phase<double>(g.phase, res, g.hs, p, t_start, g.t_probe_out, g.probe_dtype, c);
+    if (diff) {
+      g.hs[4] = res[0];  // (the third norm, for the parity tests)
+      ctrl_init_body(c, p, t_start, double(p.direction) * fabs(g.hs[3]), g.n_out, g.t_span, g.step_t, g.t_stage_out, g.seq0, z);
+    }
   }
+  if (!diff || !g.mirror) return;  // (block-uniform)
+  // The speculative pipeline wants to know where the FIRST attempt lands (`t_plan` of the block just constructed) before it
+  // enqueues a second one: the block goes to the host mirror the way every controller launch's does — no copy command, no event
+  __syncthreads();
+  publish_block(c, z, g.mirror, g.flags | kCtrlChecksum);
 }
 
 }  // namespace
@@ -619,7 +627,7 @@ int xde_initial_step_fused(int phase, const void* a, const void* b, const void* 
 
 int xde_initial_step_tail(int phase, const void* ws, double* hs_dev, const xde_ctrl_params_t* params, double t_start, void* t_probe_out,
                           int probe_dtype, xde_ctrl_t* ctrl, int32_t n_out, const double* t_span_dev, const double* step_t_dev,
-                          void* t_stage_out, int64_t seq0, void* stream) {
+                          void* t_stage_out, int64_t seq0, xde_ctrl_t* host_mirror, void* stream) {
   if (!ws || !hs_dev || !ctrl) return fail(XDE_EBADARG, "xde_initial_step_tail: null pointer");
   if (phase != 0 && phase != 1) return fail(XDE_EBADARG, "xde_initial_step_tail: phase must be 0 or 1");
   if (phase == 0 && !t_probe_out) return fail(XDE_EBADARG, "xde_initial_step_tail: phase 0 needs t_probe_out");
@@ -630,6 +638,9 @@ int xde_initial_step_tail(int phase, const void* ws, double* hs_dev, const xde_c
   int rc = check_params(params, "xde_initial_step_tail");
   if (rc != XDE_OK) return rc;
   if (phase == 1 && params->n_step_t > 0 && !step_t_dev) return fail(XDE_EBADARG, "xde_initial_step_tail: n_step_t > 0 without step_t_dev");
+  if (host_mirror && (phase != 1 || seq0 < 0)) return fail(XDE_EBADARG, "xde_initial_step_tail: host_mirror goes with phase 1 and seq0 >= 0");
+  if (host_mirror && !(ctrl_flags() & kCtrlChecksum))
+    return fail(XDE_EBADARG, "xde_initial_step_tail: host_mirror needs the checksummed publish protocol (XDE_CTRL_FLAGS bit 8)");
   InitTailArgs g;
   memset(&g, 0, sizeof(g));
   g.slot_a = slot_ptr(ws, 0);
@@ -644,6 +655,8 @@ int xde_initial_step_tail(int phase, const void* ws, double* hs_dev, const xde_c
   g.step_t = step_t_dev;
   g.t_stage_out = t_stage_out;
   g.seq0 = seq0;
+  g.mirror = host_mirror;
+  g.flags = ctrl_flags();
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope prof(XDE_KID_FINALIZE, 0.0);
   XDE_LAUNCH(xde_initial_step_tail_kernel, dim3(1), dim3(kBlock), st, prof, g, *params, ctrl);

@@ -10,7 +10,10 @@ namespace xde {
 // K3: controller
 // ------------------------------------------------------------------------------------------
 template <typename TT> __device__ inline TT pow_(TT a, TT b);
-template <> __device__ inline float pow_<float>(float a, float b) { return powf(a, b); }
+// fp32: a double-precision pow rounded once — the correctly rounded fp32 power in all but ~1e-9 of the cases, i.e. what the host's libm
+// powf returns (the reference's CPU path: `error_ratio ** exponent` on fp32 tensors, utils/ode_utils.py:96) except where libm itself
+// misrounds.  The device's own powf is 1-2 ulp off; one thread calls this once per attempt, so the cost is nil.
+template <> __device__ inline float pow_<float>(float a, float b) { return float(pow(double(a), double(b))); }
 template <> __device__ inline double pow_<double>(double a, double b) { return pow(a, b); }
 template <typename TT> __device__ inline TT fmin__(TT a, TT b);
 template <> __device__ inline float fmin__<float>(float a, float b) { return fminf(a, b); }

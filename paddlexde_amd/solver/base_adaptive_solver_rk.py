@@ -278,7 +278,8 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         be, p, d, y0 = self.backend, self._params, self._direction, self.y0
 
         # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
-        f0 = self._eval(self._scalar_t(t_span[0], self.dtype), y0)
+        self._t0_dev = self._scalar_t(t_span[0], self.dtype)
+        f0 = self._eval(self._t0_dev, y0)
         first_dev = None
         self._ctrl_ready = False
         if self.first_step is None:
@@ -302,7 +303,9 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         self._init_peek = None
         if (hasattr(be, "ctrl_peek_async")
                 and (self.pipeline == "lag" or (self.pipeline == "auto" and self._auto.pick() == "lag"))):
-            self._init_peek = be.ctrl_peek_async(self._ctrl)
+            # (the large-state heuristic's last launch has published that block to the host mirror already: nothing to enqueue)
+            h = be.ctrl_init_handle(self._ctrl) if hasattr(be, "ctrl_init_handle") else None
+            self._init_peek = h if h is not None else be.ctrl_peek_async(self._ctrl)
 
     def _setup(self, t_span):
         """Buffers, output times and controller parameters of a solve over ``t_span`` (everything before the first evaluation)."""
@@ -322,7 +325,7 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         self._t_span_dev = upload(t_span.astype(np.float64), dev)
         self._work = w = be.acquire_work(dev, y0.dtype)  # recycled by integrate() when the solve has ended
         self._t_stage, self._ctrl, self._ws, self._sums = w.t_stage, w.ctrl, w.ws, w.sums
-        self._t_views = [self._t_stage[i] for i in range(self._n_stage)]  # the 0-dim stage times handed to func
+        self._t_views = getattr(w, "t_views", None) or [self._t_stage[i] for i in range(self._n_stage)]  # the 0-dim stage times handed to func
         self._seg_count = self._global_counts()
         self._csums = be.new_sums(dev) if self._chunks is not None else None  # the controller's input in chunked mode
         self._scratch = torch.empty_like(y0)
@@ -399,7 +402,9 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         sdt = _hip.dtype_code(y0.dtype)
         t0h = np_dtype(self.dtype)(t0)
         if f0 is None:
-            f0 = self._eval(self._scalar_t(t0h, self.dtype), y0)
+            # (the reference's second evaluation at the start time gets the start time's tensor of the first one: same value)
+            t0_dev = getattr(self, "_t0_dev", None)
+            f0 = self._eval(t0_dev if t0_dev is not None else self._scalar_t(t0h, self.dtype), y0)
         t_probe = torch.empty((), dtype=torch.promote_types(self.dtype, y0.dtype), device=dev)
         if self._fused_first_step():
             # small state: the three norms, the scalar arithmetic and the control block's construction in TWO one-workgroup launches
@@ -417,7 +422,7 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         if self._tail_first_step():
             # d0 and d1 in ONE pass over (y0, f0); finalize + result + the scalars (+ the control block's construction) folded into
             # one one-workgroup launch per phase: 12 launches -> 4; _before_integrate skips its ctrl_init
-            hs = torch.zeros(5, dtype=torch.float64, device=dev)
+            hs = torch.empty(5, dtype=torch.float64, device=dev)  # (every entry is written by the two tail launches)
             be.scaled_norm2_partial(f0, y0, self.rtol, self.atol, self._xsegs, self._norm_kind, self._ws)
             be.initial_step_tail(0, self._ws, hs, self._params, float(t0h), t_probe, self._ctrl)
             y1 = torch.empty_like(y0)

@@ -71,6 +71,9 @@ def run(calls, plain):
         st = {}
         del marks[:]
         torch.cuda.synchronize()
+        if plain:
+            torch.cuda._sleep(1)  # a launch of its own name (spin_kernel) in front of every call: the trace reduction splits on it
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         if not plain:
             mark("entry>")
@@ -110,16 +113,19 @@ def trace(directory, calls):
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    # a call = the kernels between two gaps of > 0.4 ms (torch.cuda.synchronize + the host's set-up between calls)
-    groups, cur = [], [rows[0]]
-    for prev, row in zip(rows, rows[1:]):
-        if row[0] - prev[1] > 400_000:
-            groups.append(cur)
+    # a call = the launches after one marker launch (spin_kernel, enqueued by run(plain=True) in front of every call) up to the next
+    groups, cur = [], None
+    for row in rows:
+        if "spin_kernel" in row[2]:
+            if cur:
+                groups.append(cur)
             cur = []
-        cur.append(row)
-    groups.append(cur)
-    groups = [g for g in groups if len(g) > 60][-calls:]
-    print("# kernels of the last {} odeint() calls in {} (a call: the launches between two idle gaps > 0.4 ms)".format(len(groups), path))
+        elif cur is not None:
+            cur.append(row)
+    if cur:
+        groups.append(cur)
+    groups = groups[-calls:]
+    print("# kernels of the last {} odeint() calls in {} (a call: the launches between two marker launches)".format(len(groups), path))
     for gi, g in enumerate(groups):
         span = (g[-1][1] - g[0][0]) / 1e3
         busy = sum(e - s for s, e, _ in g) / 1e3
@@ -133,7 +139,7 @@ def trace(directory, calls):
         return n.split("(")[0][:90]
 
     first_ctrl = next(i for i, n in enumerate(names) if "xde_control_kernel" in n or "xde_errnorm" in n)
-    head_end = max(i for i in range(first_ctrl) if "xde_initial_step" in names[i] or "ctrl_init" in names[i]) + 1
+    head_end = max(i for i in range(first_ctrl) if "xde_initial_step" in names[i] or "ctrl_init" in names[i]) + 1  # first launch of attempt 1
     t_first = g[0][0]
     for i in range(head_end + 1):
         s, e, n = g[i]
@@ -152,13 +158,59 @@ def trace(directory, calls):
         print("    {:3d} x {}".format(v, k))
 
 
+def host_profile(calls):
+    """The HOST's share of a call: a state just above the one-workgroup kernels' reach (1024 x 128: the same code path as config 2,
+    no GPU time to speak of) over an interval of ONE attempted step, under cProfile."""
+    import cProfile
+    import pstats
+
+    import torch
+
+    from paddlexde_amd import Dopri5, odeint
+    from paddlexde_amd.utils import _rms_norm
+    from tests import problems as P
+
+    A = P.skew_matrix(128).float().cuda()
+    y0 = torch.randn(1024, 128, generator=torch.Generator().manual_seed(0)).cuda()
+    func = lambda t, y: y @ A.T  # noqa: E731
+    t = torch.tensor([0.0, 1e-3])
+
+    def one():
+        st = {}
+        with torch.no_grad():
+            odeint(func, y0, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm, "pipeline": "lag", "stats_out": st})
+        return st
+
+    for _ in range(20):
+        st = one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        one()
+    host = (time.perf_counter() - t0) / calls
+    torch.cuda.synchronize()
+    print("# host time of a whole odeint() call of {} attempt(s), {} func evaluations (1024 x 128 state, lag pipeline): {:.1f} us".format(
+        st["n_steps"], st["nfe"], 1e6 * host))
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(calls):
+        one()
+    pr.disable()
+    torch.cuda.synchronize()
+    ps = pstats.Stats(pr, stream=sys.stdout)
+    ps.sort_stats("cumulative").print_stats(45)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--calls", type=int, default=9)
     ap.add_argument("--plain", action="store_true", help="no phase marks (for a rocprofv3 run, and for the unmarked total)")
     ap.add_argument("--trace", default=None, help="directory of a rocprofv3 --kernel-trace run of this script: reduce it")
+    ap.add_argument("--host-profile", action="store_true")
     a = ap.parse_args()
-    if a.trace:
+    if a.host_profile:
+        host_profile(200)
+    elif a.trace:
         trace(a.trace, min(a.calls, 3))
     else:
         run(a.calls, a.plain)

@@ -114,7 +114,7 @@ def test_every_entry_point_rejects_null_arguments():
         "xde_initial_step_fused": lambda: lib.xde_initial_step_fused(0, None, None, None, C.byref(S), 0, None, C.byref(P), 0.0, None, 0, None, 2, None,
                                                                     None, None, 0, None),
         "xde_scaled_norm2_partial": lambda: lib.xde_scaled_norm2_partial(None, None, 1e-3, 1e-6, C.byref(S), 0, 0, None, None),
-        "xde_initial_step_tail": lambda: lib.xde_initial_step_tail(0, None, None, C.byref(P), 0.0, None, 0, None, 2, None, None, None, 0, None),
+        "xde_initial_step_tail": lambda: lib.xde_initial_step_tail(0, None, None, C.byref(P), 0.0, None, 0, None, 2, None, None, None, 0, None, None),
         "xde_ctrl_read": lambda: lib.xde_ctrl_read(None, None, None),
         "xde_host_alloc": lambda: lib.xde_host_alloc(0, None),
         "xde_ctrl_wait": lambda: lib.xde_ctrl_wait(None, 0, 1.0, None),
@@ -192,7 +192,7 @@ def test_a_stale_params_mirror_gets_ebadarg_not_a_read_past_its_end(stale):
         "xde_rk_control": lambda: lib.xde_rk_control(dummy, ref, dummy, None, dummy, None, dummy, None, None),
         "xde_ctrl_retarget": lambda: lib.xde_ctrl_retarget(dummy, ref, dummy, 1, None, None),
         "xde_initial_step": lambda: lib.xde_initial_step(1, dummy, dummy, ref, 0.0, None, 0, dummy, None),
-        "xde_initial_step_tail": lambda: lib.xde_initial_step_tail(1, dummy, dummy, ref, 0.0, None, 0, dummy, 2, dummy, None, dummy, 0, None),
+        "xde_initial_step_tail": lambda: lib.xde_initial_step_tail(1, dummy, dummy, ref, 0.0, None, 0, dummy, 2, dummy, None, dummy, 0, None, None),
         "xde_error_norm_control": lambda: lib.xde_error_norm_control(kk, None, ce, 1, dummy, None, dummy, C.byref(S), 0, dummy, None, dummy,
                                                                     ref, dummy, None, dummy, None, None),
     }
@@ -280,7 +280,7 @@ def test_host_halves_run_up_to_the_launch_without_a_gpu():
                                                                 dev(20), None, dev(21), None, None),
         "scaled_norm_partial": lambda: lib.xde_scaled_norm_partial(dev(1), dev(2), dev(3), 1e-5, 1e-7, C.byref(segs), 0, 0, dev(9), 1, None),
         "scaled_norm2_partial": lambda: lib.xde_scaled_norm2_partial(dev(1), dev(2), 1e-5, 1e-7, C.byref(segs), 0, 0, dev(9), None),
-        "initial_step_tail": lambda: lib.xde_initial_step_tail(1, dev(9), dev(23), C.byref(P), 0.0, None, 0, dev(5), 2, dev(20), None, dev(21), 0, None),
+        "initial_step_tail": lambda: lib.xde_initial_step_tail(1, dev(9), dev(23), C.byref(P), 0.0, None, 0, dev(5), 2, dev(20), None, dev(21), 0, None, None),
         "norm_finalize": lambda: lib.xde_norm_finalize(dev(9), 0, dev(22), None),
         "rk_control": lambda: lib.xde_rk_control(dev(5), C.byref(P), dev(9), None, dev(20), None, dev(21), None, None),
         "ctrl_init": lambda: lib.xde_ctrl_init(dev(5), C.byref(P), 0.0, 0.1, 2, dev(20), None, dev(21), 0, None, None),
