@@ -274,18 +274,28 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
     # base_adaptive_solver_rk.py:81-114
     # ------------------------------------------------------------------------------------------
     def _before_integrate(self, t_span):
-        t_span = self._setup(t_span)
-        be, p, d, y0 = self.backend, self._params, self._direction, self.y0
-
+        # The evaluations at the start time need nothing of the set-up below, so they are enqueued FIRST: the GPU works through them
+        # while the host builds the solve's buffers, uploads and parameter block (a whole `odeint()` call at config 2 is host-bound
+        # up to its first attempt: profiles/r06_odeint_tail.txt).  Same evaluations, same order as the reference's.
+        tt = np_dtype(self.dtype)
+        if not isinstance(t_span, np.ndarray) or t_span.dtype != tt:
+            t_span = t_span_to_host(t_span, tt)
+        self.y0 = y0 = as_operand(self.y0.detach())
+        self.backend.require_device(y0)
         # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
         self._t0_dev = self._scalar_t(t_span[0], self.dtype)
         f0 = self._eval(self._t0_dev, y0)
+        f0_dup = None
+        if self.first_step is None and not self._reuse_f0 and not self._custom_norm:
+            # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
+            f0_dup = self._eval(self._t0_dev, y0, live=(storage_ptr(f0),))
+        t_span = self._setup(t_span)
+        be, p, d, y0 = self.backend, self._params, self._direction, self.y0
         first_dev = None
         self._ctrl_ready = False
         if self.first_step is None:
-            # f0 is recomputed inside select_initial_step (f0=None), as in the reference         :84-87
-            f0_again = f0 if self._reuse_f0 else None
-            if f0_again is not None:
+            f0_again = f0 if self._reuse_f0 else f0_dup
+            if self._reuse_f0:
                 self._nfe_skipped += 1  # (the call the reference makes here and this solve does not)
             if self._custom_norm:  # (a user's norm callable runs as framework ops: the heuristic's scalars go through the host)
                 first_step = self.select_initial_step(t_span[0], y0, self.order - 1, self.rtol, self.atol, f0=f0_again)

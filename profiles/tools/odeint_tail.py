@@ -201,14 +201,89 @@ def host_profile(calls):
     ps.sort_stats("cumulative").print_stats(45)
 
 
+def host_sections(calls):
+    """Host time (perf_counter, inclusive) of the pieces of a call's set-up — everything before the first attempted step — at config 2's
+    size, where allocations are 32 MiB blocks and the GPU is busy: wrappers around the functions, no profiler."""
+    import torch
+
+    from paddlexde_amd import Dopri5, _hip, odeint
+    from paddlexde_amd.solver import _common
+    from paddlexde_amd.solver.base_adaptive_solver import AdaptiveSolver
+    from paddlexde_amd.solver.base_adaptive_solver_rk import AdaptiveRKSolver
+    from paddlexde_amd.utils import _rms_norm
+    from paddlexde_amd.xde import BaseODE
+
+    A, y0 = problem()
+    func = lambda t, y: y @ A.T  # noqa: E731
+    t = torch.linspace(0.0, 1.0, 2)
+    acc = collections.defaultdict(float)
+    cnt = collections.Counter()
+    state = {"on": False}
+
+    def timed(owner, name, label=None):
+        fn = getattr(owner, name)
+        label = label or name
+
+        def wrapper(*a, **k):
+            if not state["on"]:
+                return fn(*a, **k)
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                acc[label] += time.perf_counter() - t0
+                cnt[label] += 1
+
+        setattr(owner, name, wrapper)
+
+    be = _hip.get_backend()
+    for name in ("_setup", "_eval", "_select_initial_step_device", "_before_integrate", "__init__"):
+        timed(AdaptiveRKSolver, name, "solver." + name)
+    timed(AdaptiveSolver, "integrate", "solver.integrate (whole)")
+    timed(BaseODE, "__init__", "BaseODE.__init__")
+    for name in ("scaled_norm2_partial", "initial_step_tail", "stage_combine", "scaled_norm_partial", "acquire_work"):
+        timed(be, name, "backend." + name)
+    timed(_common, "upload", "upload")
+    import paddlexde_amd.solver.base_adaptive_solver_rk as M
+
+    timed(M, "upload", "upload")
+    timed(M, "scalar", "scalar (torch.full)")
+    run_ = AdaptiveRKSolver._run
+
+    def _run(self, solution):
+        state["on"] = False  # the attempts are not part of the set-up
+        return run_(self, solution)
+
+    AdaptiveRKSolver._run = _run
+    totals = []
+    for call in range(calls + 3):
+        torch.cuda.synchronize()
+        state["on"] = call >= 3
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            odeint(func, y0, t, solver=Dopri5, rtol=1e-5, atol=1e-7, options={"norm": _rms_norm})
+        state["on"] = False
+        torch.cuda.synchronize()
+        if call >= 3:
+            totals.append(time.perf_counter() - t0)
+    print("# host time per call of the pieces of the set-up of odeint() at config 2 (65536 x 128), {} calls; the wrappers cost ~0.3 us each".format(calls))
+    for k in sorted(acc, key=lambda k: -acc[k]):
+        print("{:42s} {:8.1f} us   ({:.0f} x per call)".format(k, 1e6 * acc[k] / calls, cnt[k] / calls))
+    totals.sort()
+    print("whole call, median {:.3f} ms".format(1e3 * totals[len(totals) // 2]))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--calls", type=int, default=9)
     ap.add_argument("--plain", action="store_true", help="no phase marks (for a rocprofv3 run, and for the unmarked total)")
     ap.add_argument("--trace", default=None, help="directory of a rocprofv3 --kernel-trace run of this script: reduce it")
     ap.add_argument("--host-profile", action="store_true")
+    ap.add_argument("--host-sections", action="store_true")
     a = ap.parse_args()
-    if a.host_profile:
+    if a.host_sections:
+        host_sections(20)
+    elif a.host_profile:
         host_profile(200)
     elif a.trace:
         trace(a.trace, min(a.calls, 3))

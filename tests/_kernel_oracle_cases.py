@@ -415,3 +415,11 @@ def test_large_state_initial_step_in_four_launches_equals_the_twelve(dev, dtype,
         assert getattr(cf, name) == getattr(cu, name), name
     assert cf.next_out == 1 and cf.dt * direction > 0
     assert np.array_equal(tf[:6], tu[:6])
+    if hasattr(be, "ctrl_init_handle"):
+        # the folded heuristic's last launch also PUBLISHED the constructed block to the host mirror (the speculative pipeline reads where
+        # the first attempt lands from there: no copy command on the stream); the separate launches leave that to ctrl_peek_async
+        h = be.ctrl_init_handle(sf._ctrl)
+        assert h is not None and be.ctrl_init_handle(su._ctrl) is None
+        pub = be.ctrl_wait(h)
+        for name in ("t0", "t1", "dt", "t_plan", "n_out", "next_out", "done", "seq", "n_steps", "status"):
+            assert getattr(pub, name) == getattr(cf, name), name
