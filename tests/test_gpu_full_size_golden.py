@@ -236,7 +236,7 @@ def _oracle_run(label, f_np, B, D):
     return _ORACLE_RUNS[label]
 
 
-def _free_run_on_the_device(pipeline, first_step=None):
+def _free_run_on_the_device(pipeline, first_step=None, problem="dense_linear"):
     """Config 2's dense linear func (128-term sums in a stated order on both sides) on the device, NOT replayed, against the oracle's
     free run of the same problem: -> (device trace, oracle trace, worst row deviation as a fraction of `1e-7 + 1e-5 |ref|`, max-norm
     row deviation over max|ref|, the solver, the oracle's solver)."""
@@ -245,8 +245,13 @@ def _free_run_on_the_device(pipeline, first_step=None):
     from paddlexde_amd.xde import BaseODE
 
     rows = int(os.environ.get("XDE_DENSE_LINEAR_ROWS", "65536"))
-    f_np, f_torch = _dense_linear_summed_in_order(128)
-    y0, t, ref, so, _ = _oracle_run("dense_linear/{}".format(rows), f_np, rows, 128)
+    if problem == "dense_linear":
+        f_np, f_torch = _dense_linear_summed_in_order(128)
+        y0, t, ref, so, _ = _oracle_run("dense_linear/{}".format(rows), f_np, rows, 128)
+    else:  # 64 weakly non-linear oscillators per row (+, -, * only): the replay test's other bit-reproducible func
+        rows = 65536
+        f_np, f_torch = _oscillators(128)
+        y0, t, ref, so, _ = _oracle_run("config2_size_replay_unmodified_bar", f_np, rows, 128)
     dev = "cuda:0"
     y0d, tt = torch.from_numpy(y0).to(dev), torch.from_numpy(t)
     extra = {} if first_step is None else {"first_step": first_step(so)}
@@ -262,23 +267,25 @@ def _ulps(mine, theirs):
     return np.abs(mine - theirs) / np.spacing(np.abs(theirs).astype(np.float32)).astype(np.float64)
 
 
+@pytest.mark.parametrize("problem", ["dense_linear", "oscillators"])
 @pytest.mark.parametrize("pipeline", ["sync", "lag"])
-def test_config2_dense_linear_func_free_running_controller_at_the_unmodified_bar(pipeline):
+def test_config2_dense_linear_func_free_running_controller_at_the_unmodified_bar(pipeline, problem):
     """VERDICT r05 (next 4): north_star's bar UNMODIFIED and NOT replayed on config 2's own problem.  The reference decides every step
     from one global error ratio (utils/ode_utils.py:80-97; solver/base_adaptive_solver_rk.py:183-284).  Here the device's own controller
-    runs free from the reference's own `first_step` option (`:40`, set to the step the oracle's heuristic chose): it must take the
+    runs free from the reference's own `first_step` option (`:40`, set to the step the oracle's heuristic chose; also on the replay test's second bit-reproducible func,
+    the non-linear oscillators): it must take the
     oracle's decisions (identical accept / reject sequence, counts, NFE less the heuristic's two evaluations), EVERY step size within
     ONE fp32 ulp of the oracle's (the controller's `pow`: a double-precision pow rounded to fp32 against libm's powf; the ratio's
     reduction order over 8.4 M squares), and every emitted row within `1e-7 + 1e-5 |ref|` ELEMENT-WISE on all 8 388 608 elements.
     (Why `first_step`: see the fully free-running twin below — the heuristic's step is defined through fp32 norms whose last bit is
     the summation order's, and the reference's FIRST error estimate amplifies that bit to percents.)"""
-    mine, theirs, worst_rows, maxnorm, s, so, rows = _free_run_on_the_device(pipeline, first_step=lambda so_: float(so_.trace[0].dt))
+    mine, theirs, worst_rows, maxnorm, s, so, rows = _free_run_on_the_device(pipeline, first_step=lambda so_: float(so_.trace[0].dt), problem=problem)
     assert mine.shape == theirs.shape, (mine.shape, theirs.shape)
     assert np.array_equal(mine[:, 3], theirs[:, 3])  # the same decisions
     assert (s.stats["n_accept"], s.stats["n_reject"], s.stats["nfe"]) == (so.n_accept, so.n_reject, so.nfe - 2)
     dt_ulps = _ulps(mine[:, 1], theirs[:, 1])
     ratio_rel = float((np.abs(mine[:, 2] - theirs[:, 2]) / np.abs(theirs[:, 2])).max())
-    P.report("config2_dense_linear_free_controller_unmodified_bar/{}/{}".format(rows, pipeline),
+    P.report("config2_{}_free_controller_unmodified_bar/{}/{}".format(problem, rows, pipeline),
              {"attempts": len(theirs), "elements": rows * 128, "dt_ulps": [float(x) for x in dt_ulps], "t0_ulps_max": float(_ulps(mine[1:, 0], theirs[1:, 0]).max()),
               "ratio_rel_max": ratio_rel, "rows_bar_fraction": worst_rows, "rows_maxnorm_rel": maxnorm, "dt_bit_equal": int((dt_ulps == 0).sum())})
     assert dt_ulps[0] == 0.0 and dt_ulps.max() <= 1.0, dt_ulps  # every step size within one fp32 ulp of the oracle's
