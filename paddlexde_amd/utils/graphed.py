@@ -149,11 +149,13 @@ class recording:
       of ``functional/_adjoint_capture.py``, the pipelines' and interval solvers' graphs of ``_hip.HipBackend.capture``, the fixed
       solvers' captured step) and ``_hip._Peek`` (pinned buffers) go through ``release_when_idle``.  The list is emptied under the
       lock when the depth returns to zero: a thread that wants to open the next recording waits for that.
-    * The belt: Python's cyclic collector is run once BEFORE the first recording opens (torch 2.10's ``torch.cuda.graph`` does not
-      collect on entry: ``torch.compiler.config.force_cudagraph_gc`` is False) and held off until the last one has closed — counted
+    * The belt: Python's cyclic collector is held off from the first recording's entry until the last one has closed — counted
       across threads, because captures are opened ``capture_error_mode="thread_local"`` so that other threads keep working: the
       first recording in remembers whether the collector was on, the last one out restores it.  The belt does not cover an explicit
-      ``gc.collect()`` in a user's func or a reference-count drop; the deferred release does."""
+      ``gc.collect()`` in a user's func or a reference-count drop; the deferred release does.  (No collection is forced on entry:
+      torch 2.10's ``torch.cuda.graph`` does not collect there either — ``torch.compiler.config.force_cudagraph_gc`` is False — because
+      a full collection costs tens of milliseconds, and a solve that switches to its captured pipeline records a graph per call.
+      Dead cycles that own captures may therefore be alive when a recording starts: that is what the deferred release is for.)"""
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -161,8 +163,6 @@ class recording:
     def __enter__(self):
         import gc
 
-        if _REC["depth"] == 0 and gc.isenabled():
-            gc.collect()  # dead cycles that own captures die here, while that is harmless
         with _REC_LOCK:
             if _REC["depth"] == 0:
                 _REC["gc_was_enabled"] = gc.isenabled()

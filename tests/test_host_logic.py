@@ -113,9 +113,9 @@ class _FakeCapture:
 def test_garbage_collector_is_held_off_while_a_capture_records():
     """Round 5: a cyclic collection that starts INSIDE a stream capture reaped a dropped module's cached captures (the per-module
     cache is keyed weakly) and destroyed their graphs / memory pools in the middle of the recording — the process aborted under
-    `weakref.remove` inside a captured func (gpurun_out/r05f/suite.log).  The belt: every recording runs with the collector off (torch
-    2.10's `torch.cuda.graph` does NOT collect on entry — `force_cudagraph_gc` is False — so `recording` collects once itself, before the
-    capture opens) and restores it afterwards — also when the body raises, and without switching it ON for a caller who had it off."""
+    `weakref.remove` inside a captured func (gpurun_out/r05f/suite.log).  The belt: every recording runs with the collector off (neither
+    torch 2.10's `torch.cuda.graph` — `force_cudagraph_gc` is False — nor `recording` forces a collection on entry: tens of milliseconds
+    per capture) and restores it afterwards — also when the body raises, and without switching it ON for a caller who had it off."""
     import gc
 
     from paddlexde_amd.utils.graphed import recording, recordings_open
