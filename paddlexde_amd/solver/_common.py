@@ -1,4 +1,6 @@
 """Host-side helpers shared by the solvers: operand hygiene and time tables."""
+import collections
+
 import numpy as np
 import torch
 
@@ -48,6 +50,28 @@ def upload(arr, device):
     if device.type != "cuda":
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)
+
+
+_CONST_TABLES = collections.OrderedDict()  # (dtype, bytes, device, stream) -> device tensor; see upload_const
+_CONST_TABLES_MAX = 16
+
+
+def upload_const(arr, device, stream_key=None):
+    """``upload`` for a small table the kernels only READ (a solve's output times): the device copy of an identical table uploaded
+    before on the same device and stream is handed out again — a training loop that integrates over the same output times every
+    iteration pays the pinned staging and the copy (~25 us of host time, profiles/r06_odeint_tail.txt) once.  The caller must not
+    write into the result.  Nothing is cached while a stream capture is in progress (such a tensor would live in the graph's pool)."""
+    if device.type != "cuda" or arr.nbytes > 512 or torch.cuda.is_current_stream_capturing():
+        return upload(arr, device)
+    key = (arr.dtype.str, arr.shape, arr.tobytes(), device.index, stream_key)
+    t = _CONST_TABLES.get(key)
+    if t is None:
+        t = _CONST_TABLES[key] = upload(arr, device)
+        while len(_CONST_TABLES) > _CONST_TABLES_MAX:
+            _CONST_TABLES.popitem(last=False)
+    else:
+        _CONST_TABLES.move_to_end(key)
+    return t
 
 
 def scalar(value, dtype, device):

@@ -27,7 +27,7 @@ import torch
 
 from .. import _hip
 from ..utils.ode_utils import native_norm_spec
-from ._common import as_operand, direction_of, np_dtype, scalar, storage_ptr, t_span_to_host, upload
+from ._common import as_operand, direction_of, np_dtype, scalar, storage_ptr, t_span_to_host, upload, upload_const
 from ._rk_intervals import IntervalSolves
 from ._rk_norms import NormReductions
 from ._rk_pipelines import AutoPipeline, GraphPipeline, LagPipeline, SyncPipeline
@@ -332,8 +332,9 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         self._graph_pl.reset()
         self._direction = direction_of(t_span)
         self._t_host = t_span
-        self._t_span_dev = upload(t_span.astype(np.float64), dev)
         self._work = w = be.acquire_work(dev, y0.dtype)  # recycled by integrate() when the solve has ended
+        # (read-only for every kernel; keyed by the work set's stream: the copy is ordered before this solve's launches)
+        self._t_span_dev = upload_const(t_span.astype(np.float64), dev, getattr(w, "key", None))
         self._t_stage, self._ctrl, self._ws, self._sums = w.t_stage, w.ctrl, w.ws, w.sums
         self._t_views = getattr(w, "t_views", None) or [self._t_stage[i] for i in range(self._n_stage)]  # the 0-dim stage times handed to func
         self._seg_count = self._global_counts()
