@@ -74,6 +74,23 @@ def upload_const(arr, device, stream_key=None):
     return t
 
 
+def scalar_const(value, dtype, device, stream_key=None):
+    """``scalar`` for a value func only READS (a solve's start time): the 0-dim tensor made for the same value, dtype, device and
+    stream before is handed out again (a fill launch and ~10 us of host time per solve otherwise).  As with the reference, which hands
+    func views of the caller's own ``t_span``, a func must not write into its time argument."""
+    if torch.device(device).type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return scalar(value, dtype, device)
+    key = ("scalar", float(value), dtype, torch.device(device).index, stream_key)
+    t = _CONST_TABLES.get(key)
+    if t is None:
+        t = _CONST_TABLES[key] = scalar(value, dtype, device)
+        while len(_CONST_TABLES) > _CONST_TABLES_MAX:
+            _CONST_TABLES.popitem(last=False)
+    else:
+        _CONST_TABLES.move_to_end(key)
+    return t
+
+
 def scalar(value, dtype, device):
     """0-dim device tensor holding ``value``: a fill kernel with the value as argument (no host-to-device copy)."""
     return torch.full((), float(value), dtype=dtype, device=device)

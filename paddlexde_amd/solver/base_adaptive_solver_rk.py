@@ -27,7 +27,7 @@ import torch
 
 from .. import _hip
 from ..utils.ode_utils import native_norm_spec
-from ._common import as_operand, direction_of, np_dtype, scalar, storage_ptr, t_span_to_host, upload, upload_const
+from ._common import as_operand, direction_of, np_dtype, scalar, scalar_const, storage_ptr, t_span_to_host, upload, upload_const
 from ._rk_intervals import IntervalSolves
 from ._rk_norms import NormReductions
 from ._rk_pipelines import AutoPipeline, GraphPipeline, LagPipeline, SyncPipeline
@@ -283,7 +283,7 @@ class AdaptiveRKSolver(NormReductions, AdaptiveSolver):
         self.y0 = y0 = as_operand(self.y0.detach())
         self.backend.require_device(y0)
         # f0 = move(t_span[0], t_span[1] - t_span[0], y0)                                          :83
-        self._t0_dev = self._scalar_t(t_span[0], self.dtype)
+        self._t0_dev = scalar_const(t_span[0], self.dtype, y0.device, self.backend._stream_of(y0.device) if hasattr(self.backend, "_stream_of") else None)
         f0 = self._eval(self._t0_dev, y0)
         f0_dup = None
         if self.first_step is None and not self._reuse_f0 and not self._custom_norm:

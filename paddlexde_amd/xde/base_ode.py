@@ -11,7 +11,7 @@ class BaseODE(BaseXDE):
         self.init_y0(y0)
 
     def init_y0(self, y0):
-        self.y0 = y0
+        self.__dict__["y0"] = y0  # (a plain attribute: see BaseXDE.__init__)
 
     def handle(self, h, ts):
         pass

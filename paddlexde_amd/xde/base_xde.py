@@ -13,10 +13,13 @@ import torch.nn as nn
 class BaseXDE(ABC, nn.Module):
     def __init__(self, name, var_nums, y0, t_span):
         super().__init__()
-        self.name = name
-        self.var_nums = var_nums
-        self.t_span = t_span
-        self.pred_len = t_span.shape
+        # (plain attributes, set past nn.Module.__setattr__'s parameter / buffer / submodule bookkeeping: a wrapper is built per
+        # odeint() call, and that bookkeeping was 15 of a call's ~100 us of host set-up, profiles/r06_odeint_tail.txt)
+        d = self.__dict__
+        d["name"] = name
+        d["var_nums"] = var_nums
+        d["t_span"] = t_span
+        d["pred_len"] = t_span.shape
 
     def method(self):
         print(f"current method is {self.name}.")
