@@ -11,8 +11,9 @@ with 2-4 real processes on the card.
 
 A rank's controller launch spins (bounded) until its seven peers have posted: every rank's stream therefore needs a hardware queue
 of its own — a launch queued BEHIND a spinning one on the same queue would never start.  GPU_MAX_HW_QUEUES (4 by default) is raised
-before the runtime starts; if two ranks end up sharing a queue all the same, the bounded wait runs out and the run fails with a
-diagnosis, it does not hang.
+before the runtime starts, and a short co-residency probe runs first on the very streams the solve will use: if two ranks share a queue
+all the same, the probe's bounded wait runs out and the run ends as a SKIP (exit code 77: a fact about the box, not about the library);
+nothing hangs.
 
     python tests/_world8_child.py exchange     # known vectors through xde_p2p_exchange, 8 ranks, sum and max, 50 rounds
     python tests/_world8_child.py solve sync   # config 4 at full size, 8 shards, against tests/golden/config4_full.npz
@@ -76,10 +77,21 @@ def mailboxes():
     return lib, out
 
 
+_STREAMS = []
+
+
+def rank_streams():
+    """The eight rank streams, made ONCE per process: the co-residency probe and the solve must run on the same streams (which
+    hardware queue a stream lands on is decided when it is created)."""
+    if not _STREAMS:
+        _STREAMS.extend(torch.cuda.Stream(device=DEV) for _ in range(WORLD))
+    return _STREAMS
+
+
 def run_ranks(body):
     """body(rank) on WORLD threads, each on a stream of its own; the first exception of any rank is raised here."""
     errors, results = [], [None] * WORLD
-    streams = [torch.cuda.Stream(device=DEV) for _ in range(WORLD)]
+    streams = rank_streams()
     start = threading.Barrier(WORLD)
 
     def run(r):
@@ -105,7 +117,39 @@ def run_ranks(body):
     return results
 
 
+SKIP_EXIT = 77
+
+
+def co_residency_probe():
+    """Eight exchange launches that wait for one another can only finish if the eight streams run CONCURRENTLY, i.e. sit on eight
+    hardware queues.  Three rounds with a short bounded wait: if they do not come through, the box (or the runtime's stream-to-queue
+    mapping) does not give this process eight concurrent queues — an environment fact, reported as a skip (exit code 77), not as a
+    failure of the library; what follows in this process then has a real meaning."""
+    lib, mbs = mailboxes()
+    exs = [InProcessExchange(r, WORLD, mbs) for r in range(WORLD)]
+    for e in exs:
+        e.SPIN_LIMIT = 40_000_000  # ~2 s
+
+    def body(r):
+        sums = torch.zeros(32, dtype=torch.float64, device=DEV)
+        for i in range(3):
+            sums.fill_(float(r + i))
+            exs[r].exchange(sums, _hip.NORM_RMS)
+        torch.cuda.current_stream().synchronize()
+        return exs[r].error()
+
+    errs = run_ranks(body)
+    torch.cuda.synchronize()
+    for p in mbs:
+        lib.xde_p2p_free(p)
+    if any(errs):
+        print("SKIP: the eight rank streams of this process do not run concurrently (exchange errors {}): GPU_MAX_HW_QUEUES={} was not "
+              "honoured or the queues are oversubscribed".format(errs, os.environ.get("GPU_MAX_HW_QUEUES")), flush=True)
+        os._exit(SKIP_EXIT)
+
+
 def exchange():
+    co_residency_probe()
     lib, mbs = mailboxes()
     exs = [InProcessExchange(r, WORLD, mbs) for r in range(WORLD)]
     base = torch.arange(32, dtype=torch.float64)
@@ -146,6 +190,7 @@ def solve(pipeline):
     with torch.no_grad():
         _ = shards[0] @ A.T  # the framework picks its GEMM once, before eight threads ask for it at the same time
     torch.cuda.synchronize()
+    co_residency_probe()
     lib, mbs = mailboxes()
     exs = [InProcessExchange(r, WORLD, mbs) for r in range(WORLD)]
 

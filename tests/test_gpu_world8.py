@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _child(*args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_world8_child.py"), *args], capture_output=True, text=True, timeout=900,
                        cwd=ROOT)
+    if r.returncode == 77:  # the child's co-residency probe: this box does not run the eight rank streams concurrently
+        pytest.skip(r.stdout.strip().splitlines()[-1])
     assert r.returncode == 0, "exit code {}\n--- stdout\n{}\n--- stderr\n{}".format(r.returncode, r.stdout[-3000:], r.stderr[-6000:])
     return r.stdout.strip().splitlines()[-1]
 
